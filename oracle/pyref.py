@@ -1,0 +1,289 @@
+"""TEST INFRASTRUCTURE ONLY -- Python-integer restatement of the reference hot path.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module.  The product (mira_amd/) never does: it fails loudly when the HIP library is
+missing.
+
+What is restated, with the reference lines each function follows
+(paths relative to /root/reference):
+
+* radix-2 NTT                 src/fft.rs:12-27 (omega derivation), :51-115 (best_fft),
+                              :118-155 (recursive butterflies), :160-174 (fft/ifft),
+                              :178-226 (coset variants)
+* CommitmentKey::commit       src/commitment.rs:78-87 (prefix semantics, length check,
+                              affine output).  The MSM arithmetic itself lives in the
+                              un-vendored git dependency halo2_proofs (Cargo.toml:60-62,
+                              branch joshbeal/dev-mira, no lock file) on top of
+                              halo2curves; its *result* is a unique group element, so it is
+                              restated here as plain double-and-add.
+* concatenate_with_padding    src/util.rs:189-193
+
+Pinning (tests/test_oracle_pins.py):
+* NTT: the 8-point known-answer vector of src/fft.rs:240-257, and the ifft(fft(x)) == x
+  property of src/fft.rs:265-279.
+* Fr modulus: src/digest.rs:101-105 holds r-1 in decimal.
+* Fq modulus: derived from r through the BN parametrisation (t = 4965661367192848881);
+  the BN254 G2 generator held in src/gadgets/ecc2.rs:156-180 lies on the sextic twist
+  y^2 = x^3 + 3/(9+u) over Fq2 only for this p.
+* BN256 G1 (b = 3, generator (1,2), scalar mul): src/digest.rs:98-113 asserts
+  (r-1)*G == -G.
+* MSM: no known-answer vector exists in the reference.  Pinned by the homomorphic
+  identities the reference's folding tests assert on affine points
+  (src/nifs/vanilla/tests.rs:189,228 ; src/plonk/mod.rs:547-557):
+  Com(W1 + r*W2) == Com(W1) + r*Com(W2).
+* Grumpkin (y^2 = x^3 - 17 over Fr, order p), Fr::ZETA, CommitmentKey::setup output:
+  PARITY UNPINNED by any reference vector (checked here only for internal consistency:
+  group order, zeta^3 = 1).
+"""
+
+from __future__ import annotations
+
+# ----------------------------------------------------------------------------- fields
+R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001  # bn256::Fr
+P_MOD = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47  # bn256::Fq
+BN_T = 4965661367192848881
+MONT_R = 1 << 256
+
+FR_S = 28
+FR_GENERATOR = 7
+FR_ROOT_OF_UNITY = pow(FR_GENERATOR, (R_MOD - 1) >> FR_S, R_MOD)
+FR_ROOT_OF_UNITY_INV = pow(FR_ROOT_OF_UNITY, R_MOD - 2, R_MOD)
+FR_TWO_INV = pow(2, R_MOD - 2, R_MOD)
+FR_ZETA = 0x30644E72E131A029048B6E193FD84104CC37A73FEC2BC5E9B8CA0B2D36636F23
+
+CURVE_BN256 = 0     # y^2 = x^3 + 3 over Fq, scalars in Fr
+CURVE_GRUMPKIN = 1  # y^2 = x^3 - 17 over Fr, scalars in Fq
+
+
+class Curve:
+    def __init__(self, cid, base_mod, scalar_mod, b, gen):
+        self.id, self.p, self.r, self.b, self.gen = cid, base_mod, scalar_mod, b % base_mod, gen
+
+
+BN256 = Curve(CURVE_BN256, P_MOD, R_MOD, 3, (1, 2))
+GRUMPKIN = Curve(CURVE_GRUMPKIN, R_MOD, P_MOD, -17,
+                 (1, 17631683881184975370165255887551781615748388533673675138860))
+CURVES = {CURVE_BN256: BN256, CURVE_GRUMPKIN: GRUMPKIN}
+
+
+def to_mont(x, mod):
+    return (x * MONT_R) % mod
+
+
+def from_mont(x, mod):
+    return (x * pow(MONT_R, -1, mod)) % mod
+
+
+def limbs4(x):
+    """256-bit int -> 4 little-endian u64 limbs (the in-memory layout of halo2curves fields)."""
+    return [(x >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+
+
+def from_limbs4(l):
+    return sum(int(v) << (64 * i) for i, v in enumerate(l))
+
+
+# ----------------------------------------------------------------------------- curve
+def on_curve(P, cv):
+    if P is None:
+        return True
+    x, y = P
+    return (y * y - x * x * x - cv.b) % cv.p == 0
+
+
+def ec_neg(P, cv):
+    return None if P is None else (P[0], (-P[1]) % cv.p)
+
+
+def ec_add(P, Q, cv):
+    if P is None:
+        return Q
+    if Q is None:
+        return P
+    p = cv.p
+    if P[0] == Q[0]:
+        if (P[1] + Q[1]) % p == 0:
+            return None
+        lam = 3 * P[0] * P[0] * pow(2 * P[1], -1, p) % p
+    else:
+        lam = (Q[1] - P[1]) * pow(Q[0] - P[0], -1, p) % p
+    x = (lam * lam - P[0] - Q[0]) % p
+    return (x, (lam * (P[0] - x) - P[1]) % p)
+
+
+def ec_mul(k, P, cv):
+    k %= cv.r
+    acc = None
+    while k:
+        if k & 1:
+            acc = ec_add(acc, P, cv)
+        P = ec_add(P, P, cv)
+        k >>= 1
+    return acc
+
+
+def msm_naive(scalars, bases, cv):
+    """sum_i scalars[i] * bases[i]; scalars canonical ints, bases affine tuples or None."""
+    acc = None
+    for s, B in zip(scalars, bases):
+        acc = ec_add(acc, ec_mul(s, B, cv), cv)
+    return acc
+
+
+class TooLongInput(Exception):
+    """src/commitment.rs:21-24"""
+
+    def __init__(self, input_len, limit):
+        super().__init__(f"Can't commit too long input: input len: {input_len}, but limit is {limit}")
+        self.input_len, self.limit = input_len, limit
+
+
+def commit(ck, v, cv):
+    """src/commitment.rs:78-87: MSM over the PREFIX of the key, affine result."""
+    if len(ck) >= len(v):
+        return msm_naive(v, ck[:len(v)], cv)
+    raise TooLongInput(len(v), len(ck))
+
+
+def concatenate_with_padding(vs, pad_size):
+    """src/util.rs:189-193: each column zero-padded to pad_size, columns concatenated."""
+    out = []
+    for v in vs:
+        out.extend(v)
+        out.extend([0] * max(0, pad_size - len(v)))
+    return out
+
+
+# ----------------------------------------------------------------------------- NTT
+def get_omega_or_inv(k, is_inverse):
+    """src/fft.rs:12-23"""
+    assert k <= FR_S, f"k={k} should no larger than F::S={FR_S}"
+    w = FR_ROOT_OF_UNITY_INV if is_inverse else FR_ROOT_OF_UNITY
+    for _ in range(k, FR_S):
+        w = w * w % R_MOD
+    return w
+
+
+def get_ifft_divisor(k):
+    """src/fft.rs:25-27"""
+    return pow(FR_TWO_INV, k, R_MOD)
+
+
+def _bitreverse(x, bits):
+    return int(format(x, f"0{bits}b")[::-1], 2) if bits else 0
+
+
+def best_fft(a, omega, log_n):
+    """src/fft.rs:51-115 (iterative branch :83-111; the recursive branch :118-155 computes
+    the same butterflies in another order).  In place on a list of canonical ints."""
+    n = len(a)
+    assert n == 1 << log_n
+    q = R_MOD
+    for k in range(n):
+        rk = _bitreverse(k, log_n)
+        if k < rk:
+            a[rk], a[k] = a[k], a[rk]
+    twiddles = [1] * (n // 2)
+    for i in range(1, n // 2):
+        twiddles[i] = twiddles[i - 1] * omega % q
+    chunk, twiddle_chunk = 2, n // 2
+    for _ in range(log_n):
+        half = chunk // 2
+        for base in range(0, n, chunk):
+            for i in range(half):
+                t = a[base + half + i] * twiddles[i * twiddle_chunk] % q
+                u = a[base + i]
+                a[base + i] = (u + t) % q
+                a[base + half + i] = (u - t) % q
+        chunk *= 2
+        twiddle_chunk //= 2
+
+
+def fft(a, log_n):
+    """src/fft.rs:160-162"""
+    best_fft(a, get_omega_or_inv(log_n, False), log_n)
+
+
+def ifft(a, log_n):
+    """src/fft.rs:165-174"""
+    best_fft(a, get_omega_or_inv(log_n, True), log_n)
+    d = get_ifft_divisor(log_n)
+    for i in range(len(a)):
+        a[i] = a[i] * d % R_MOD
+
+
+def distribute_powers_zeta(a, into_coset):
+    """src/fft.rs:205-226"""
+    z, zi = FR_ZETA, FR_ZETA * FR_ZETA % R_MOD
+    powers = [z, zi] if into_coset else [zi, z]
+    for idx in range(len(a)):
+        i = idx % 3
+        if i:
+            a[idx] = a[idx] * powers[i - 1] % R_MOD
+
+
+def coset_fft(a):
+    """src/fft.rs:178-185"""
+    log_n = len(a).bit_length() - 1
+    assert len(a) == 1 << log_n
+    distribute_powers_zeta(a, True)
+    fft(a, log_n)
+
+
+def coset_ifft(a):
+    """src/fft.rs:189-196"""
+    log_n = len(a).bit_length() - 1
+    assert len(a) == 1 << log_n
+    ifft(a, log_n)
+    distribute_powers_zeta(a, False)
+    return list(a)
+
+
+# ----------------------------------------------------------------------------- synthetic inputs
+# One splitmix64 stream per index i, seeded seed + i * STREAM_MUL.  The C oracle
+# (oracle_synth_*) and the product's GPU generators (mira_synth_*) use the same definition,
+# so inputs can be produced independently on either side and compared bit for bit.
+MASK64 = (1 << 64) - 1
+STREAM_MUL = 0xD6E8FEB86659FD93
+SEED_SCALARS = 0x4D495241
+SEED_BASES = 0x42415345
+
+
+class SplitMix64:
+    def __init__(self, seed):
+        self.s = seed & MASK64
+
+    def next(self):
+        self.s = (self.s + 0x9E3779B97F4A7C15) & MASK64
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & MASK64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & MASK64
+        return z ^ (z >> 31)
+
+
+def synth_scalar(i, mod, seed=SEED_SCALARS, kind="uniform"):
+    """SURVEY.md 8(d).  kind 'witness': 70 % zero, 20 % < 2^32, 10 % uniform.  Canonical int."""
+    g = SplitMix64(seed + i * STREAM_MUL)
+    v = sum(g.next() << (64 * k) for k in range(4)) % mod
+    if kind == "witness":
+        sel = g.next() % 10
+        if sel < 7:
+            v = 0
+        elif sel < 9:
+            v &= 0xFFFFFFFF
+    return v
+
+
+def synth_scalars(n, mod, seed=SEED_SCALARS, kind="uniform"):
+    return [synth_scalar(i, mod, seed, kind) for i in range(n)]
+
+
+def synth_base(i, cv, seed=SEED_BASES):
+    """P_i = k_i * G with k_i an odd 128-bit integer from the stream."""
+    g = SplitMix64(seed + i * STREAM_MUL)
+    k = (g.next() | 1) | (g.next() << 64)
+    return ec_mul(k, cv.gen, cv)
+
+
+def synth_bases(n, cv, seed=SEED_BASES):
+    return [synth_base(i, cv, seed) for i in range(n)]

@@ -1,0 +1,126 @@
+/*
+ * mira_gpu.h -- C ABI of libmira_gpu.so, the MI355X (gfx950) MSM + NTT engine that drops in
+ * behind joshbeal/mira's commitment and FFT functions.
+ *
+ * The reference has no FFI for this path; these entry points are what a `cfg(feature="gpu")`
+ * shim in the reference would bind (INTEGRATION.md shows the Rust side).  Each one cites the
+ * reference interface it replaces (paths relative to the reference repository root).
+ *
+ * Data layout (the in-memory representation of halo2curves types, passed by pointer cast):
+ *   field element  = 4 x uint64_t little-endian limbs, Montgomery form, R = 2^256   (32 bytes)
+ *   affine point   = x || y                                                        (64 bytes)
+ *   identity point = all-zero bytes (src/poseidon/poseidon_hash.rs:137-140)
+ *   curve ids      : MIRA_CURVE_BN256 (G1, y^2 = x^3 + 3 over Fq, scalars Fr)
+ *                    MIRA_CURVE_GRUMPKIN (y^2 = x^3 - 17 over Fr, scalars Fq)
+ *
+ * Ownership: the caller owns every buffer; the library borrows it for the duration of a call.
+ * Registered bases are copied to (or, for *_device, referenced on) the GPU; the host copy is
+ * never retained.  Errors: every function returns MIRA_OK (0) or a negative MIRA_E_* code and
+ * never throws or aborts across the ABI; mira_last_error() describes the last failure on the
+ * calling thread.  Threading: all entry points are re-entrant (one process-wide lock).
+ * There is no CPU fallback: without a usable gfx950 device every compute call fails with
+ * MIRA_E_NO_DEVICE.
+ */
+#ifndef MIRA_GPU_H
+#define MIRA_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIRA_CURVE_BN256 0
+#define MIRA_CURVE_GRUMPKIN 1
+
+#define MIRA_OK 0
+#define MIRA_E_NO_DEVICE (-1)     /* no HIP device / HIP runtime error */
+#define MIRA_E_BAD_ARG (-2)       /* null pointer, unknown curve or handle, size out of range */
+#define MIRA_E_TOO_LONG (-3)      /* scalars longer than the registered key: Error::TooLongInput */
+#define MIRA_E_ALLOC (-4)         /* device allocation failed */
+#define MIRA_E_UNSUPPORTED (-5)   /* size not supported by this build */
+#define MIRA_E_INVALID_POINT (-6) /* a base is not on the curve */
+
+/* Largest number of windows any MSM configuration uses; sizes mira_msm_partial buffers. */
+#define MIRA_MAX_WINDOWS 64
+/* One partial = W XYZZ points of 16 u64 each (X, Y, ZZ, ZZZ), W <= MIRA_MAX_WINDOWS. */
+#define MIRA_PARTIAL_U64 (MIRA_MAX_WINDOWS * 16)
+
+/* ---- device / stream ------------------------------------------------------------------- */
+int mira_device_count(void);
+/* Bind the library to a HIP device (default 0) -- one process per GPU. */
+int mira_init(int device);
+/* Run all work on the caller's hipStream_t (e.g. torch's current stream); NULL = own stream. */
+int mira_set_stream(void *hip_stream);
+const char *mira_last_error(void);
+
+/* ---- MSM: CommitmentKey::commit (src/commitment.rs:78-87) ------------------------------
+ * register = upload the key once (`CommitmentKey { ck: Box<[C]> }`, src/commitment.rs:26-29;
+ * it is immutable and outlives every fold step, src/ivc/public_params.rs:50).               */
+int mira_msm_register_bases(int curve, const uint64_t *bases /* n * 8 limbs */, size_t n, uint64_t *handle_out);
+/* Same, for bases already resident in device memory (borrowed, not copied, not freed). */
+int mira_msm_register_bases_device(int curve, const void *d_bases, size_t n, uint64_t *handle_out);
+int mira_msm_unregister(uint64_t handle);
+/* Validate every registered base against the curve equation on the GPU, as
+ * load_or_setup_cache does with is_on_curve (src/commitment.rs:145-154). */
+int mira_msm_check_bases(uint64_t handle);
+
+/* out_affine = sum_i scalars[i] * bases[i], i < n <= registered length (the key's PREFIX is
+ * used, src/commitment.rs:80).  n > registered length -> MIRA_E_TOO_LONG (src/commitment.rs:21-24,
+ * 81-86).  Replaces best_multiexp(v, &ck[..v.len()]).to_affine().                            */
+int mira_msm(uint64_t handle, const uint64_t *scalars /* n * 4 limbs */, size_t n, uint64_t out_affine[8]);
+int mira_msm_device(uint64_t handle, const void *d_scalars, size_t n, uint64_t out_affine[8]);
+
+/* Point-chunk sharding across GPUs (one process per GPU): each rank runs mira_msm_partial on
+ * its chunk, the ranks all-gather the MIRA_PARTIAL_U64 words, and every rank combines.
+ * `first` = index of the chunk's first base inside the registered key.                       */
+int mira_msm_partial_device(uint64_t handle, size_t first, const void *d_scalars, size_t n,
+                            uint64_t out_partial[MIRA_PARTIAL_U64], int32_t *window_bits, int32_t *num_windows);
+int mira_msm_combine(int curve, const uint64_t *partials /* nparts * MIRA_PARTIAL_U64 */, size_t nparts,
+                     int32_t window_bits, int32_t num_windows, uint64_t out_affine[8]);
+/* Force the window width c (4..16) for every later MSM; 0 = choose from n.  All ranks of a
+ * sharded MSM must use the same c. */
+int mira_msm_set_window_bits(int32_t c);
+
+/* ---- NTT over bn256::Fr (src/fft.rs) -----------------------------------------------------
+ * In place, natural order in and out.  `a` = 2^log_n elements.  log_n <= 24 in this build
+ * (the field allows 28, src/fft.rs:13).                                                      */
+/* best_fft(a, omega, log_n), src/fft.rs:51 */
+int mira_ntt_bn256_fr(uint64_t *a, uint32_t log_n, const uint64_t omega[4]);
+int mira_ntt_bn256_fr_device(void *d_a, uint32_t log_n, const uint64_t omega[4]);
+/* fft / ifft, src/fft.rs:160-174 (omega from get_omega_or_inv, ifft scales by TWO_INV^log_n) */
+int mira_fft_bn256_fr(uint64_t *a, uint32_t log_n);
+int mira_ifft_bn256_fr(uint64_t *a, uint32_t log_n);
+int mira_fft_bn256_fr_device(void *d_a, uint32_t log_n);
+int mira_ifft_bn256_fr_device(void *d_a, uint32_t log_n);
+/* coset_fft / coset_ifft, src/fft.rs:178-196 (ZETA pattern of distribute_powers_zeta, :205-226) */
+int mira_coset_fft_bn256_fr(uint64_t *a, uint32_t log_n);
+int mira_coset_ifft_bn256_fr(uint64_t *a, uint32_t log_n);
+/* get_omega_or_inv(k, is_inverse), src/fft.rs:12-23; Montgomery form out */
+int mira_get_omega_or_inv(uint32_t k, int is_inverse, uint64_t out[4]);
+
+/* ---- synthetic inputs for benchmarks and tests -------------------------
+ * kind 0 = uniform field elements, 1 = witness-like (70 % zero, 20 % < 2^32, 10 % uniform).
+ * index0 = global index of the first element (lets ranks generate their own chunk).          */
+int mira_synth_scalars_device(int curve, size_t n, uint64_t index0, uint64_t seed, int kind, void *d_out);
+int mira_synth_bases_device(int curve, size_t n, uint64_t index0, uint64_t seed, void *d_out);
+
+/* ---- device memory helpers (thin hipMalloc/hipMemcpy wrappers for non-torch callers) ---- */
+int mira_dev_alloc(size_t bytes, void **d_out);
+int mira_dev_free(void *d);
+int mira_dev_upload(void *d_dst, const void *h_src, size_t bytes);
+int mira_dev_download(void *h_dst, const void *d_src, size_t bytes);
+int mira_dev_sync(void);
+
+/* ---- measurement ------------------------------------------------------------------------
+ * With timing on, every stage of the next MSM / NTT is bracketed by HIP events on the work
+ * stream.  mira_get_timings returns the stage count and fills names/ms (ms[i] = device time of
+ * stage i of the most recent call).  Stage names are static strings.                         */
+int mira_set_timing(int enabled);
+int mira_get_timings(const char **names, float *ms, int capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIRA_GPU_H */

@@ -1,0 +1,111 @@
+"""ctypes binding of the C ABI declared in include/mira_gpu.h.
+
+`load()` only ever opens the in-tree HIP library mira_amd/csrc/libmira_gpu.so and raises if it
+is missing: there is no CPU fallback anywhere in this package.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmira_gpu.so")
+
+MIRA_OK = 0
+MIRA_E_NO_DEVICE, MIRA_E_BAD_ARG, MIRA_E_TOO_LONG, MIRA_E_ALLOC, MIRA_E_UNSUPPORTED, MIRA_E_INVALID_POINT = -1, -2, -3, -4, -5, -6
+MIRA_MAX_WINDOWS = 64
+MIRA_PARTIAL_U64 = MIRA_MAX_WINDOWS * 16
+
+# every symbol include/mira_gpu.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "mira_device_count", "mira_init", "mira_set_stream", "mira_last_error",
+    "mira_msm_register_bases", "mira_msm_register_bases_device", "mira_msm_unregister", "mira_msm_check_bases",
+    "mira_msm", "mira_msm_device", "mira_msm_partial_device", "mira_msm_combine", "mira_msm_set_window_bits",
+    "mira_ntt_bn256_fr", "mira_ntt_bn256_fr_device", "mira_fft_bn256_fr", "mira_ifft_bn256_fr",
+    "mira_fft_bn256_fr_device", "mira_ifft_bn256_fr_device", "mira_coset_fft_bn256_fr", "mira_coset_ifft_bn256_fr",
+    "mira_get_omega_or_inv", "mira_synth_scalars_device", "mira_synth_bases_device",
+    "mira_dev_alloc", "mira_dev_free", "mira_dev_upload", "mira_dev_download", "mira_dev_sync",
+    "mira_set_timing", "mira_get_timings",
+]
+
+
+class MiraError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libmira_gpu error {code}: {msg}")
+        self.code = code
+
+
+class MiraLib:
+    """One loaded copy of the C ABI."""
+
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise ImportError(
+                f"{path} not found: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()'); "
+                "mira_amd has no CPU fallback")
+        self.path = path
+        self.c = ctypes.CDLL(path)
+        c = self.c
+        vp, u64p, sz, u64, u32, i32 = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int32
+        c.mira_last_error.restype = ctypes.c_char_p
+        sig = {
+            "mira_device_count": [], "mira_init": [ctypes.c_int], "mira_set_stream": [vp],
+            "mira_msm_register_bases": [ctypes.c_int, u64p, sz, vp], "mira_msm_register_bases_device": [ctypes.c_int, vp, sz, vp],
+            "mira_msm_unregister": [u64], "mira_msm_check_bases": [u64],
+            "mira_msm": [u64, u64p, sz, u64p], "mira_msm_device": [u64, vp, sz, u64p],
+            "mira_msm_partial_device": [u64, sz, vp, sz, u64p, vp, vp],
+            "mira_msm_combine": [ctypes.c_int, u64p, sz, i32, i32, u64p], "mira_msm_set_window_bits": [i32],
+            "mira_ntt_bn256_fr": [u64p, u32, u64p], "mira_ntt_bn256_fr_device": [vp, u32, u64p],
+            "mira_fft_bn256_fr": [u64p, u32], "mira_ifft_bn256_fr": [u64p, u32],
+            "mira_fft_bn256_fr_device": [vp, u32], "mira_ifft_bn256_fr_device": [vp, u32],
+            "mira_coset_fft_bn256_fr": [u64p, u32], "mira_coset_ifft_bn256_fr": [u64p, u32],
+            "mira_get_omega_or_inv": [u32, ctypes.c_int, u64p],
+            "mira_synth_scalars_device": [ctypes.c_int, sz, u64, u64, ctypes.c_int, vp],
+            "mira_synth_bases_device": [ctypes.c_int, sz, u64, u64, vp],
+            "mira_dev_alloc": [sz, vp], "mira_dev_free": [vp], "mira_dev_upload": [vp, vp, sz], "mira_dev_download": [vp, vp, sz],
+            "mira_dev_sync": [], "mira_set_timing": [ctypes.c_int], "mira_get_timings": [vp, vp, ctypes.c_int],
+        }
+        for name, args in sig.items():
+            fn = getattr(c, name)
+            fn.argtypes = args
+            fn.restype = ctypes.c_int
+
+    def check(self, rc):
+        if rc != MIRA_OK:
+            raise MiraError(rc, (self.c.mira_last_error() or b"").decode())
+        return rc
+
+    # -- small conveniences shared by the host layer ------------------------------------------
+    def alloc(self, nbytes):
+        p = ctypes.c_void_p()
+        self.check(self.c.mira_dev_alloc(nbytes, ctypes.byref(p)))
+        return p.value
+
+    def free(self, ptr):
+        self.c.mira_dev_free(ctypes.c_void_p(ptr))
+
+    def upload(self, ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self.check(self.c.mira_dev_upload(ctypes.c_void_p(ptr), arr.ctypes.data_as(ctypes.c_void_p), arr.nbytes))
+
+    def download(self, ptr, shape, dtype=np.uint64):
+        out = np.empty(shape, dtype=dtype)
+        self.check(self.c.mira_dev_download(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), out.nbytes))
+        return out
+
+    def timings(self):
+        names = (ctypes.c_char_p * 32)()
+        ms = (ctypes.c_float * 32)()
+        n = self.c.mira_get_timings(names, ms, 32)
+        return [(names[i].decode(), float(ms[i])) for i in range(min(n, 32))]
+
+
+_lib = None
+
+
+def load():
+    """The product library.  Raises ImportError when the HIP build is absent."""
+    global _lib
+    if _lib is None:
+        _lib = MiraLib(LIB_PATH)
+    return _lib

@@ -1,0 +1,155 @@
+"""Host-side mirror of the reference's `CommitmentKey` (src/commitment.rs:26-87) for the GPU path.
+
+Same names, argument meaning and error behaviour as the Rust type: `commit(v)` is the MSM of `v`
+against the PREFIX of the key and returns one affine point; a `v` longer than the key raises
+`TooLongInput` carrying `input_len` and `limit` (src/commitment.rs:21-24).  Points and scalars are
+numpy uint64 arrays in the in-memory layout of halo2curves: scalars (n, 4), points (n, 8),
+Montgomery form, identity = zeros.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+CURVE_BN256 = 0
+CURVE_GRUMPKIN = 1
+
+
+class TooLongInput(Exception):
+    """Error::TooLongInput { input_len, limit } (src/commitment.rs:21-24)."""
+
+    def __init__(self, input_len, limit):
+        super().__init__(f"Can't commit too long input: input len: {input_len}, but limit is {limit}")
+        self.input_len, self.limit = input_len, limit
+
+
+def _as_u64(a, width):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a.reshape(-1, width)
+
+
+class CommitmentKey:
+    """`CommitmentKey<C>`: a boxed slice of affine bases, resident in HBM for its whole life
+    (the reference keeps one key per curve for all fold steps, src/ivc/public_params.rs:50)."""
+
+    def __init__(self, curve, ck=None, *, device_ptr=None, length=None, lib=None):
+        self.lib = lib or _lib.load()
+        self.curve = curve
+        h = ctypes.c_uint64()
+        if device_ptr is not None:
+            self._len = int(length)
+            self.lib.check(self.lib.c.mira_msm_register_bases_device(curve, ctypes.c_void_p(device_ptr), self._len, ctypes.byref(h)))
+        else:
+            ck = _as_u64(ck if ck is not None else np.zeros((0, 8), np.uint64), 8)
+            self._len = len(ck)
+            self.lib.check(self.lib.c.mira_msm_register_bases(curve, ck.ctypes.data_as(ctypes.c_void_p), self._len, ctypes.byref(h)))
+        self.handle = h.value
+
+    @classmethod
+    def synthetic(cls, curve, n, seed=0x42415345, index0=0, lib=None):
+        """n deterministic bases P_i = k_i * G generated on the GPU; this is the
+        benchmark's stand-in for `setup` (src/commitment.rs:52-76), whose hash-to-curve lives in
+        the absent halo2curves crate."""
+        lib = lib or _lib.load()
+        ptr = lib.alloc(max(n, 1) * 64)
+        lib.check(lib.c.mira_synth_bases_device(curve, n, index0, seed, ctypes.c_void_p(ptr)))
+        key = cls(curve, device_ptr=ptr, length=n, lib=lib)
+        key._owned_ptr = ptr
+        return key
+
+    def __len__(self):
+        return self._len
+
+    def len(self):
+        return self._len
+
+    def is_empty(self):
+        return self._len == 0
+
+    @staticmethod
+    def default_value():
+        """C::identity() (src/commitment.rs:40-42)"""
+        return np.zeros(8, dtype=np.uint64)
+
+    def bases(self):
+        """Download the key (tests)."""
+        ptr = getattr(self, "_owned_ptr", None)
+        if ptr is None:
+            raise ValueError("bases were registered from host memory; keep your own copy")
+        return self.lib.download(ptr, (self._len, 8))
+
+    def check_on_curve(self):
+        """load_or_setup_cache's validation (src/commitment.rs:145-154), on the GPU."""
+        self.lib.check(self.lib.c.mira_msm_check_bases(self.handle))
+
+    def commit(self, v):
+        """src/commitment.rs:78-87.  v: (n, 4) uint64 Montgomery scalars in host memory."""
+        v = _as_u64(v, 4)
+        if len(v) > self._len:
+            raise TooLongInput(len(v), self._len)
+        out = np.empty(8, dtype=np.uint64)
+        self.lib.check(self.lib.c.mira_msm(self.handle, v.ctypes.data_as(ctypes.c_void_p), len(v), out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    def commit_device(self, d_scalars, n):
+        """Same with the scalars already in HBM (device pointer)."""
+        if n > self._len:
+            raise TooLongInput(n, self._len)
+        out = np.empty(8, dtype=np.uint64)
+        self.lib.check(self.lib.c.mira_msm_device(self.handle, ctypes.c_void_p(d_scalars), n, out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    def commit_partial_device(self, first, d_scalars, n):
+        """Window sums of sum_i v[i] * ck[first + i]; combine with `combine_partials`."""
+        if first + n > self._len:
+            raise TooLongInput(first + n, self._len)
+        part = np.zeros(_lib.MIRA_PARTIAL_U64, dtype=np.uint64)
+        c, w = ctypes.c_int32(), ctypes.c_int32()
+        self.lib.check(self.lib.c.mira_msm_partial_device(self.handle, first, ctypes.c_void_p(d_scalars), n,
+                                                          part.ctypes.data_as(ctypes.c_void_p), ctypes.byref(c), ctypes.byref(w)))
+        return part, c.value, w.value
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.c.mira_msm_unregister(self.handle)
+            self.handle = 0
+        ptr = getattr(self, "_owned_ptr", None)
+        if ptr:
+            self.lib.free(ptr)
+            self._owned_ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def combine_partials(curve, partials, window_bits, num_windows, lib=None):
+    """Sum per-GPU window sums, Horner over the windows, to_affine."""
+    lib = lib or _lib.load()
+    partials = np.ascontiguousarray(partials, dtype=np.uint64).reshape(-1, _lib.MIRA_PARTIAL_U64)
+    out = np.empty(8, dtype=np.uint64)
+    lib.check(lib.c.mira_msm_combine(curve, partials.ctypes.data_as(ctypes.c_void_p), len(partials), window_bits, num_windows,
+                                     out.ctypes.data_as(ctypes.c_void_p)))
+    return out
+
+
+def concatenate_with_padding(vs, pad_size):
+    """src/util.rs:189-193: the MSM scalar vector of a witness: columns zero-padded to pad_size."""
+    cols = []
+    for v in vs:
+        v = _as_u64(v, 4)
+        if len(v) < pad_size:
+            v = np.concatenate([v, np.zeros((pad_size - len(v), 4), dtype=np.uint64)])
+        cols.append(v)
+    return np.concatenate(cols) if cols else np.zeros((0, 4), dtype=np.uint64)
+
+
+def synth_scalars_device(curve, n, seed=0x4D495241, kind=0, index0=0, lib=None):
+    """Device buffer of n synthetic scalars (kind 0 uniform, 1 witness-like).  Returns pointer."""
+    lib = lib or _lib.load()
+    ptr = lib.alloc(max(n, 1) * 32)
+    lib.check(lib.c.mira_synth_scalars_device(curve, n, index0, seed, kind, ctypes.c_void_p(ptr)))
+    return ptr

@@ -1,0 +1,433 @@
+// libmira_gpu.so: process-wide context + the C ABI of include/mira_gpu.h.  The host side
+// mirrors the reference's compiled-language surface for this path: CommitmentKey::commit
+// (src/commitment.rs:78-87) and fft / ifft / coset_fft / coset_ifft / best_fft
+// (src/fft.rs:51-196).  Kernels live in the per-curve units and ntt.hip.
+#include "ctx.h"
+#include "host_field.hpp"
+
+#ifdef MIRA_CPU_EMU
+thread_local dim3 threadIdx, blockIdx;
+dim3 blockDim, gridDim;
+pthread_barrier_t *emu_barrier = nullptr;
+unsigned char *emu_dyn_shared = nullptr;
+#endif
+
+static thread_local std::string g_err;
+void set_error(const std::string &s) { g_err = s; }
+static std::mutex g_lock;
+Ctx g;
+static std::map<uint64_t, Bases> g_bases;
+
+// constants block on device: [0] gen bn256 (64 B) [64] gen grumpkin (64 B) [128] b bn256 (32 B) [160] b grumpkin (32 B)
+static int upload_consts();
+
+static int ensure_ctx() {
+    if (g.ready) return MIRA_OK;
+#ifndef MIRA_CPU_EMU
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) {
+        set_error("no HIP device visible (libmira_gpu has no CPU fallback)");
+        return MIRA_E_NO_DEVICE;
+    }
+    RT_CHECK(hipSetDevice(g.device));
+    if (!g.stream) {
+        RT_CHECK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+        g.own_stream = true;
+    }
+#endif
+    int rc;
+    if ((rc = curve_init_bn256())) return rc;
+    if ((rc = curve_init_grumpkin())) return rc;
+    if ((rc = ntt_init())) return rc;
+    g.ready = true;
+    rc = upload_consts();
+    if (rc != MIRA_OK) g.ready = false;
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+// timing
+void tm_begin() {
+    g.tm.names.clear(); g.tm.ms.clear();
+#ifndef MIRA_CPU_EMU
+    if (g.tm.enabled) {
+        if (g.tm.ev.empty()) {
+            g.tm.ev.resize(32);
+            for (auto &e : g.tm.ev) hipEventCreate(&e);
+        }
+        hipEventRecord(g.tm.ev[0], g.stream);
+    }
+#endif
+}
+void tm_mark(const char *name) {
+    if (!g.tm.enabled) return;
+    g.tm.names.push_back(name);
+#ifndef MIRA_CPU_EMU
+    if (g.tm.names.size() < g.tm.ev.size()) hipEventRecord(g.tm.ev[g.tm.names.size()], g.stream);
+#endif
+}
+void tm_end() {   // after stream sync
+    if (!g.tm.enabled) return;
+    g.tm.ms.assign(g.tm.names.size(), 0.f);
+#ifndef MIRA_CPU_EMU
+    for (size_t i = 0; i < g.tm.names.size() && i + 1 < g.tm.ev.size(); i++)
+        hipEventElapsedTime(&g.tm.ms[i], g.tm.ev[i], g.tm.ev[i + 1]);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------
+// curve dispatch helpers
+template <class FP> static hostf::HFe<FP> small_const(long v) {
+    hostf::HFe<FP> x = hostf::from_u64<FP>((uint64_t)(v < 0 ? -v : v));
+    return v < 0 ? hostf::sub(hostf::zero<FP>(), x) : x;
+}
+static int upload_consts() {
+    uint64_t blk[24];
+    memset(blk, 0, sizeof blk);
+    auto gx = small_const<FqP>(1), gy = small_const<FqP>(2);
+    memcpy(blk + 0, gx.l, 32); memcpy(blk + 4, gy.l, 32);
+    auto hx = small_const<FrP>(1);
+    // sqrt(-16) mod r = 17631683881184975370165255887551781615748388533673675138860
+    hostf::HFe<FrP> hy_plain = {{0x833fc48d823f272cULL, 0x2d270d45f1181294ULL, 0xcf135e7506a45d63ULL, 0x2ULL}};
+    auto hy = hostf::to_mont(hy_plain);
+    memcpy(blk + 8, hx.l, 32); memcpy(blk + 12, hy.l, 32);
+    auto b0 = small_const<FqP>(3);
+    auto b1 = small_const<FrP>(-17);
+    memcpy(blk + 16, b0.l, 32); memcpy(blk + 20, b1.l, 32);
+    int rc = g.consts.ensure(sizeof blk);
+    if (rc) return rc;
+    RT_CHECK(rt_h2d(g.consts.p, blk, sizeof blk, g.stream));
+    RT_CHECK(rt_sync(g.stream));
+    return MIRA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// MSM plan
+
+static MsmPlan make_plan(size_t n, int32_t forced_c) {
+    MsmPlan p;
+    uint32_t best_c = 4;
+    double best = 1e300;
+    for (uint32_t c = 4; c <= 16; c++) {
+        double W = std::ceil(256.0 / c);
+        double cost = (double)n * W + 6.0 * W * (double)(1u << (c - 1));
+        if (cost < best) { best = cost; best_c = c; }
+    }
+    p.c = forced_c ? (uint32_t)forced_c : best_c;
+    p.W = (256 + p.c - 1) / p.c;
+    p.B = 1u << (p.c - 1);
+    p.NB = p.W * p.B;
+    // histogram / scatter tiling: about two workgroups per CU, at least 1024 points per tile
+    uint32_t want_tiles = std::max<uint32_t>(1, 512 / p.W);
+    p.tile = std::max<uint32_t>(1024, ceil_div(n, want_tiles));
+    p.tile = (p.tile + 1023) / 1024 * 1024;
+    p.ntiles = ceil_div(n, p.tile);
+    // accumulate: L consecutive sorted entries per lane, about 4 waves per SIMD when n allows
+    uint64_t entries = (uint64_t)n * p.W;
+    uint64_t L = (entries + 262143) / 262144;
+    p.L = (uint32_t)std::min<uint64_t>(512, std::max<uint64_t>(16, L));
+    p.T = ceil_div(entries, p.L);
+    p.m = std::min<uint32_t>(16, p.B);
+    p.nchunks = p.B / p.m;
+    return p;
+}
+
+// Horner over the window sums: sum_w 2^(c w) * Wsum[w], then to_affine.
+template <class FB>
+static void horner_affine(const uint64_t *windows, uint32_t c, uint32_t W, uint64_t out[8]) {
+    using namespace hostf;
+    HXyzz<FB> acc = identity<FB>();
+    for (int w = (int)W - 1; w >= 0; w--) {
+        for (uint32_t k = 0; k < c; k++) acc = dbl_pt(acc);
+        HXyzz<FB> t;
+        memcpy(&t, windows + (size_t)w * 16, 128);
+        acc = add_pt(acc, t);
+    }
+    to_affine(acc, out);
+}
+template <class FB>
+static void sum_partials(const uint64_t *partials, size_t nparts, uint32_t W, uint64_t *out_windows) {
+    using namespace hostf;
+    for (uint32_t w = 0; w < W; w++) {
+        HXyzz<FB> acc = identity<FB>();
+        for (size_t k = 0; k < nparts; k++) {
+            HXyzz<FB> t;
+            memcpy(&t, partials + k * MIRA_PARTIAL_U64 + (size_t)w * 16, 128);
+            acc = add_pt(acc, t);
+        }
+        memcpy(out_windows + (size_t)w * 16, &acc, 128);
+    }
+}
+
+static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scalars, size_t n, uint64_t *out_partial,
+                              uint32_t *c_out, uint32_t *W_out) {
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    auto it = g_bases.find(handle);
+    if (it == g_bases.end()) { set_error("unknown bases handle"); return MIRA_E_BAD_ARG; }
+    const Bases &bs = it->second;
+    if (first > bs.n || n > bs.n - first) {
+        set_error("Can't commit too long input: input len: " + std::to_string(first + n) + ", but limit is " + std::to_string(bs.n));
+        return MIRA_E_TOO_LONG;
+    }
+    MsmPlan p = make_plan(n, g.forced_c);
+    if (n >= (1ull << 31) || (uint64_t)n * p.W >= (1ull << 32)) { set_error("n too large for 32-bit entry offsets"); return MIRA_E_UNSUPPORTED; }
+    if (p.W > MIRA_MAX_WINDOWS) { set_error("window configuration exceeds MIRA_MAX_WINDOWS"); return MIRA_E_UNSUPPORTED; }
+    *c_out = p.c; *W_out = p.W;
+    memset(out_partial, 0, MIRA_PARTIAL_U64 * 8);
+    if (n == 0) return MIRA_OK;
+    if (!d_scalars) { set_error("null scalars"); return MIRA_E_BAD_ARG; }
+    if (bs.curve == MIRA_CURVE_BN256) return msm_launch_bn256(bs, first, d_scalars, n, p, out_partial);
+    return msm_launch_grumpkin(bs, first, d_scalars, n, p, out_partial);
+}
+
+static int combine_locked(int curve, const uint64_t *partials, size_t nparts, uint32_t c, uint32_t W, uint64_t out[8]) {
+    if (curve != MIRA_CURVE_BN256 && curve != MIRA_CURVE_GRUMPKIN) { set_error("unknown curve"); return MIRA_E_BAD_ARG; }
+    if (!partials || !out || nparts == 0 || c < 1 || c > 16 || W < 1 || W > MIRA_MAX_WINDOWS) { set_error("bad combine arguments"); return MIRA_E_BAD_ARG; }
+    std::vector<uint64_t> win((size_t)W * 16);
+    if (curve == MIRA_CURVE_BN256) { sum_partials<FqP>(partials, nparts, W, win.data()); horner_affine<FqP>(win.data(), c, W, out); }
+    else { sum_partials<FrP>(partials, nparts, W, win.data()); horner_affine<FrP>(win.data(), c, W, out); }
+    return MIRA_OK;
+}
+
+
+static int ntt_kind_device_ctx(void *d_a, uint32_t log_n, NttKind kind, const uint64_t *omega_in) {
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    return ntt_kind_device(d_a, log_n, kind, omega_in);
+}
+static int ntt_kind_host_locked(uint64_t *a, uint32_t log_n, NttKind kind, const uint64_t *omega_in) {
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    if (!a) { set_error("null argument"); return MIRA_E_BAD_ARG; }
+    if (log_n > 28) { set_error("k=" + std::to_string(log_n) + " should no larger than F::S=28"); return MIRA_E_BAD_ARG; }
+    const size_t bytes = (size_t)32 << log_n;
+    if ((rc = g.ntt_stage.ensure(bytes))) return rc;
+    RT_CHECK(rt_h2d(g.ntt_stage.p, a, bytes, g.stream));
+    if ((rc = ntt_kind_device(g.ntt_stage.p, log_n, kind, omega_in))) return rc;
+    RT_CHECK(rt_d2h(a, g.ntt_stage.p, bytes, g.stream));
+    RT_CHECK(rt_sync(g.stream));
+    return MIRA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+extern "C" {
+
+int mira_device_count(void) {
+#ifndef MIRA_CPU_EMU
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+    return cnt;
+#else
+    return 1;
+#endif
+}
+int mira_init(int device) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    if (g.ready && device != g.device) { set_error("library already bound to device " + std::to_string(g.device)); return MIRA_E_BAD_ARG; }
+    g.device = device;
+    return ensure_ctx();
+}
+int mira_set_stream(void *hip_stream) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    int rc = ensure_ctx();
+    if (rc) return rc;
+#ifndef MIRA_CPU_EMU
+    if (hip_stream) {
+        if (g.own_stream && g.stream) { hipStreamSynchronize(g.stream); hipStreamDestroy(g.stream); }
+        g.stream = reinterpret_cast<hipStream_t>(hip_stream); g.own_stream = false;
+    } else if (!g.own_stream) {
+        RT_CHECK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking)); g.own_stream = true;
+    }
+#else
+    (void)hip_stream;
+#endif
+    return MIRA_OK;
+}
+const char *mira_last_error(void) { return g_err.c_str(); }
+
+int mira_msm_register_bases(int curve, const uint64_t *bases, size_t n, uint64_t *handle_out) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    if ((curve != MIRA_CURVE_BN256 && curve != MIRA_CURVE_GRUMPKIN) || !handle_out || (n && !bases)) { set_error("bad register arguments"); return MIRA_E_BAD_ARG; }
+    Bases b; b.curve = curve; b.n = n; b.owned = true;
+    if (rt_malloc(&b.d, std::max<size_t>(64, n * 64)) != hipSuccess || !b.d) { set_error("device allocation for bases failed"); return MIRA_E_ALLOC; }
+    if (n) {
+        RT_CHECK(rt_h2d(b.d, bases, n * 64, g.stream));
+        RT_CHECK(rt_sync(g.stream));
+    }
+    *handle_out = g.next_handle++;
+    g_bases[*handle_out] = b;
+    return MIRA_OK;
+}
+int mira_msm_register_bases_device(int curve, const void *d_bases, size_t n, uint64_t *handle_out) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    if ((curve != MIRA_CURVE_BN256 && curve != MIRA_CURVE_GRUMPKIN) || !handle_out || (n && !d_bases)) { set_error("bad register arguments"); return MIRA_E_BAD_ARG; }
+    Bases b; b.curve = curve; b.n = n; b.owned = false; b.d = const_cast<void *>(d_bases);
+    *handle_out = g.next_handle++;
+    g_bases[*handle_out] = b;
+    return MIRA_OK;
+}
+int mira_msm_unregister(uint64_t handle) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    auto it = g_bases.find(handle);
+    if (it == g_bases.end()) { set_error("unknown bases handle"); return MIRA_E_BAD_ARG; }
+    if (it->second.owned && it->second.d) rt_free(it->second.d);
+    g_bases.erase(it);
+    return MIRA_OK;
+}
+int mira_msm_check_bases(uint64_t handle) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    auto it = g_bases.find(handle);
+    if (it == g_bases.end()) { set_error("unknown bases handle"); return MIRA_E_BAD_ARG; }
+    const Bases &bs = it->second;
+    if (bs.n == 0) return MIRA_OK;
+    if ((rc = g.heavy.ensure(64))) return rc;
+    uint32_t *bad = reinterpret_cast<uint32_t *>(g.heavy.p);
+    RT_CHECK(rt_memset(bad, 0, 4, g.stream));
+    if ((rc = bs.curve == MIRA_CURVE_BN256 ? check_bases_bn256(bs, bad) : check_bases_grumpkin(bs, bad))) return rc;
+    uint32_t h = 0;
+    RT_CHECK(rt_d2h(&h, bad, 4, g.stream));
+    RT_CHECK(rt_sync(g.stream));
+    if (h) { set_error("Wrong key, " + std::to_string(h) + " points out of curve"); return MIRA_E_INVALID_POINT; }
+    return MIRA_OK;
+}
+
+static int msm_device_locked(uint64_t handle, const void *d_scalars, size_t n, uint64_t out_affine[8]) {
+    if (!out_affine) { set_error("null output"); return MIRA_E_BAD_ARG; }
+    uint64_t part[MIRA_PARTIAL_U64];
+    uint32_t c, W;
+    int rc = msm_partial_locked(handle, 0, d_scalars, n, part, &c, &W);
+    if (rc) return rc;
+    return combine_locked(g_bases[handle].curve, part, 1, c, W, out_affine);
+}
+int mira_msm_device(uint64_t handle, const void *d_scalars, size_t n, uint64_t out_affine[8]) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    return msm_device_locked(handle, d_scalars, n, out_affine);
+}
+int mira_msm(uint64_t handle, const uint64_t *scalars, size_t n, uint64_t out_affine[8]) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    if (n && !scalars) { set_error("null scalars"); return MIRA_E_BAD_ARG; }
+    auto it = g_bases.find(handle);
+    if (it == g_bases.end()) { set_error("unknown bases handle"); return MIRA_E_BAD_ARG; }
+    if (n > it->second.n) {   // length check before any copy, as commit does (src/commitment.rs:79)
+        set_error("Can't commit too long input: input len: " + std::to_string(n) + ", but limit is " + std::to_string(it->second.n));
+        return MIRA_E_TOO_LONG;
+    }
+    if (n) {
+        if ((rc = g.scalars_stage.ensure(n * 32))) return rc;
+        RT_CHECK(rt_h2d(g.scalars_stage.p, scalars, n * 32, g.stream));
+    }
+    return msm_device_locked(handle, g.scalars_stage.p, n, out_affine);
+}
+int mira_msm_partial_device(uint64_t handle, size_t first, const void *d_scalars, size_t n, uint64_t out_partial[MIRA_PARTIAL_U64],
+                            int32_t *window_bits, int32_t *num_windows) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    if (!out_partial || !window_bits || !num_windows) { set_error("null output"); return MIRA_E_BAD_ARG; }
+    uint32_t c, W;
+    int rc = msm_partial_locked(handle, first, d_scalars, n, out_partial, &c, &W);
+    if (rc) return rc;
+    *window_bits = (int32_t)c; *num_windows = (int32_t)W;
+    return MIRA_OK;
+}
+int mira_msm_combine(int curve, const uint64_t *partials, size_t nparts, int32_t window_bits, int32_t num_windows, uint64_t out_affine[8]) {
+    return combine_locked(curve, partials, nparts, (uint32_t)window_bits, (uint32_t)num_windows, out_affine);
+}
+int mira_msm_set_window_bits(int32_t c) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    if (c != 0 && (c < 4 || c > 16)) { set_error("window bits must be 0 or in [4,16]"); return MIRA_E_BAD_ARG; }
+    g.forced_c = c;
+    return MIRA_OK;
+}
+
+int mira_ntt_bn256_fr(uint64_t *a, uint32_t log_n, const uint64_t omega[4]) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    if (!omega) { set_error("null omega"); return MIRA_E_BAD_ARG; }
+    return ntt_kind_host_locked(a, log_n, NTT_BEST, omega);
+}
+int mira_ntt_bn256_fr_device(void *d_a, uint32_t log_n, const uint64_t omega[4]) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    if (!omega) { set_error("null omega"); return MIRA_E_BAD_ARG; }
+    return ntt_kind_device_ctx(d_a, log_n, NTT_BEST, omega);
+}
+int mira_fft_bn256_fr(uint64_t *a, uint32_t log_n) { std::lock_guard<std::mutex> lk(g_lock); return ntt_kind_host_locked(a, log_n, NTT_FFT, nullptr); }
+int mira_ifft_bn256_fr(uint64_t *a, uint32_t log_n) { std::lock_guard<std::mutex> lk(g_lock); return ntt_kind_host_locked(a, log_n, NTT_IFFT, nullptr); }
+int mira_fft_bn256_fr_device(void *d_a, uint32_t log_n) { std::lock_guard<std::mutex> lk(g_lock); return ntt_kind_device_ctx(d_a, log_n, NTT_FFT, nullptr); }
+int mira_ifft_bn256_fr_device(void *d_a, uint32_t log_n) { std::lock_guard<std::mutex> lk(g_lock); return ntt_kind_device_ctx(d_a, log_n, NTT_IFFT, nullptr); }
+int mira_coset_fft_bn256_fr(uint64_t *a, uint32_t log_n) { std::lock_guard<std::mutex> lk(g_lock); return ntt_kind_host_locked(a, log_n, NTT_COSET_FFT, nullptr); }
+int mira_coset_ifft_bn256_fr(uint64_t *a, uint32_t log_n) { std::lock_guard<std::mutex> lk(g_lock); return ntt_kind_host_locked(a, log_n, NTT_COSET_IFFT, nullptr); }
+int mira_get_omega_or_inv(uint32_t k, int is_inverse, uint64_t out[4]) {
+    if (!out || k > 28) { set_error("k=" + std::to_string(k) + " should no larger than F::S=28"); return MIRA_E_BAD_ARG; }
+    return ntt_get_omega_or_inv(k, is_inverse != 0, out);
+}
+
+int mira_synth_scalars_device(int curve, size_t n, uint64_t index0, uint64_t seed, int kind, void *d_out) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    if ((curve != MIRA_CURVE_BN256 && curve != MIRA_CURVE_GRUMPKIN) || (n && !d_out)) { set_error("bad synth arguments"); return MIRA_E_BAD_ARG; }
+    if (!n) return MIRA_OK;
+    return curve == MIRA_CURVE_BN256 ? synth_scalars_bn256(n, index0, seed, kind, d_out) : synth_scalars_grumpkin(n, index0, seed, kind, d_out);
+}
+int mira_synth_bases_device(int curve, size_t n, uint64_t index0, uint64_t seed, void *d_out) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    if ((curve != MIRA_CURVE_BN256 && curve != MIRA_CURVE_GRUMPKIN) || (n && !d_out)) { set_error("bad synth arguments"); return MIRA_E_BAD_ARG; }
+    if (!n) return MIRA_OK;
+    return curve == MIRA_CURVE_BN256 ? synth_bases_bn256(n, index0, seed, d_out) : synth_bases_grumpkin(n, index0, seed, d_out);
+}
+
+int mira_dev_alloc(size_t bytes, void **d_out) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    if (!d_out) { set_error("null output"); return MIRA_E_BAD_ARG; }
+    if (rt_malloc(d_out, std::max<size_t>(bytes, 64)) != hipSuccess || !*d_out) { set_error("device allocation failed"); return MIRA_E_ALLOC; }
+    return MIRA_OK;
+}
+int mira_dev_free(void *d) { std::lock_guard<std::mutex> lk(g_lock); if (d) rt_free(d); return MIRA_OK; }
+int mira_dev_upload(void *d_dst, const void *h_src, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    RT_CHECK(rt_h2d(d_dst, h_src, bytes, g.stream));
+    RT_CHECK(rt_sync(g.stream));
+    return MIRA_OK;
+}
+int mira_dev_download(void *h_dst, const void *d_src, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    RT_CHECK(rt_d2h(h_dst, d_src, bytes, g.stream));
+    RT_CHECK(rt_sync(g.stream));
+    return MIRA_OK;
+}
+int mira_dev_sync(void) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    RT_CHECK(rt_sync(g.stream));
+    return MIRA_OK;
+}
+
+int mira_set_timing(int enabled) { std::lock_guard<std::mutex> lk(g_lock); g.tm.enabled = enabled != 0; return MIRA_OK; }
+int mira_get_timings(const char **names, float *ms, int capacity) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    int cnt = (int)std::min(g.tm.names.size(), g.tm.ms.size());
+    for (int i = 0; i < cnt && i < capacity; i++) {
+        if (names) names[i] = g.tm.names[i];
+        if (ms) ms[i] = g.tm.ms[i];
+    }
+    return cnt;
+}
+
+}   // extern "C"

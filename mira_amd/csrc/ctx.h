@@ -1,0 +1,123 @@
+// Shared host-side state of libmira_gpu.so: the bound device, its work stream, grow-only
+// device workspaces and the stage timers.  One translation unit per curve keeps hipcc builds
+// parallel; they all meet here.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/mira_gpu.h"
+#include "platform.h"
+
+void set_error(const std::string &s);
+
+#ifndef MIRA_CPU_EMU
+#define RT_CHECK(expr)                                                                     \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+            return MIRA_E_NO_DEVICE;                                                       \
+        }                                                                                  \
+    } while (0)
+static inline hipError_t rt_malloc(void **p, size_t n) { return hipMalloc(p, n); }
+static inline hipError_t rt_free(void *p) { return hipFree(p); }
+static inline hipError_t rt_memset(void *p, int v, size_t n, hipStream_t s) { return hipMemsetAsync(p, v, n, s); }
+static inline hipError_t rt_h2d(void *d, const void *h, size_t n, hipStream_t s) { return hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s); }
+static inline hipError_t rt_d2h(void *h, const void *d, size_t n, hipStream_t s) { return hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s); }
+static inline hipError_t rt_sync(hipStream_t s) { return hipStreamSynchronize(s); }
+static inline hipError_t rt_last() { return hipGetLastError(); }
+#else
+#define RT_CHECK(expr) do { (void)(expr); } while (0)
+static inline int rt_malloc(void **p, size_t n) { *p = aligned_alloc(64, (n + 63) / 64 * 64); return *p ? 0 : 1; }
+static inline int rt_free(void *p) { free(p); return 0; }
+static inline int rt_memset(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+static inline int rt_h2d(void *d, const void *h, size_t n, hipStream_t) { memcpy(d, h, n); return 0; }
+static inline int rt_d2h(void *h, const void *d, size_t n, hipStream_t) { memcpy(h, d, n); return 0; }
+static inline int rt_sync(hipStream_t) { return 0; }
+static inline int rt_last() { return 0; }
+#endif
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return MIRA_OK;
+        if (p) (void)rt_free(p);
+        p = nullptr; cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        if (rt_malloc(&p, want) != hipSuccess || !p) {
+            p = nullptr;
+            set_error("device allocation of " + std::to_string(want) + " bytes failed");
+            return MIRA_E_ALLOC;
+        }
+        cap = want;
+        return MIRA_OK;
+    }
+};
+
+struct Timing {
+    bool enabled = false;
+    std::vector<const char *> names;
+    std::vector<float> ms;
+#ifndef MIRA_CPU_EMU
+    std::vector<hipEvent_t> ev;
+#endif
+};
+
+struct Ctx {
+    bool ready = false;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int32_t forced_c = 0;
+    Timing tm;
+    // MSM workspace (grow-only, shared by all handles: calls are serialised by the ABI lock)
+    DevBuf digits, counts, offsets, cursor, block_sums, sorted_idx, sorted_key, bucket_sums;
+    DevBuf head_part, tail_part, head_key, tail_key, heavy, chunks, window_sums, scalars_stage, consts;
+    // NTT workspace
+    DevBuf ntt_tmp, ntt_stage, ntt_tables, ntt_consts;
+    std::string ntt_tables_key;
+    uint64_t next_handle = 1;
+};
+extern Ctx g;
+
+struct Bases {
+    int curve;
+    size_t n;
+    void *d = nullptr;
+    bool owned = false;
+};
+
+void tm_begin();
+void tm_mark(const char *name);
+void tm_end();
+
+static inline uint32_t ceil_div(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// window width c, W windows, B = 2^(c-1) buckets per window, histogram tiling, accumulate
+// segment length L over T lanes, reduction chunk m
+struct MsmPlan {
+    uint32_t c, W, B, NB, tile, ntiles, L, T, m, nchunks;
+};
+
+// per-curve translation units (msm_bn256.hip / msm_grumpkin.hip)
+int msm_launch_bn256(const Bases &bs, size_t first, const void *d_scalars, size_t n, const MsmPlan &p, uint64_t *host_windows);
+int msm_launch_grumpkin(const Bases &bs, size_t first, const void *d_scalars, size_t n, const MsmPlan &p, uint64_t *host_windows);
+int curve_init_bn256();
+int curve_init_grumpkin();
+int synth_scalars_bn256(size_t n, uint64_t index0, uint64_t seed, int kind, void *d_out);
+int synth_scalars_grumpkin(size_t n, uint64_t index0, uint64_t seed, int kind, void *d_out);
+int synth_bases_bn256(size_t n, uint64_t index0, uint64_t seed, void *d_out);
+int synth_bases_grumpkin(size_t n, uint64_t index0, uint64_t seed, void *d_out);
+int check_bases_bn256(const Bases &bs, uint32_t *d_bad);
+int check_bases_grumpkin(const Bases &bs, uint32_t *d_bad);
+
+// ntt.hip
+enum NttKind { NTT_BEST, NTT_FFT, NTT_IFFT, NTT_COSET_FFT, NTT_COSET_IFFT };
+int ntt_init();
+int ntt_kind_device(void *d_a, uint32_t log_n, NttKind kind, const uint64_t *omega_in);
+int ntt_get_omega_or_inv(uint32_t k, bool inverse, uint64_t out[4]);

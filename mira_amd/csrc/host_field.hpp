@@ -1,0 +1,144 @@
+// Host-side (x86-64) field and XYZZ arithmetic used by the library's fixed-size epilogue:
+// Horner over the W window sums that come back from the GPU (<= 32 points), the single
+// inversion of Curve::to_affine() (reference src/commitment.rs:80), the combine of per-GPU
+// partial window sums, and the derivation of NTT roots (reference src/fft.rs:12-27).
+// O(1) work per call, independent of n; the MSM and NTT themselves run only on the GPU.
+#pragma once
+#include <cstdint>
+#include <cstring>
+
+#include "field.cuh"
+
+namespace hostf {
+typedef unsigned __int128 u128;
+
+template <class FP> struct HFe {
+    uint64_t l[4];
+};
+template <class FP> inline uint64_t P64(int i) { return (uint64_t)FP::P[2 * i] | ((uint64_t)FP::P[2 * i + 1] << 32); }
+template <class FP> inline uint64_t N064() {
+    uint64_t p0 = P64<FP>(0), inv = 1;
+    for (int i = 0; i < 6; i++) inv *= 2 - p0 * inv;
+    return (uint64_t)0 - inv;
+}
+template <class FP> inline HFe<FP> zero() { HFe<FP> r; memset(&r, 0, sizeof r); return r; }
+template <class FP> inline HFe<FP> one() {
+    HFe<FP> r;
+    for (int i = 0; i < 4; i++) r.l[i] = (uint64_t)FP::R1[2 * i] | ((uint64_t)FP::R1[2 * i + 1] << 32);
+    return r;
+}
+template <class FP> inline HFe<FP> r2() {
+    HFe<FP> r;
+    for (int i = 0; i < 4; i++) r.l[i] = (uint64_t)FP::R2[2 * i] | ((uint64_t)FP::R2[2 * i + 1] << 32);
+    return r;
+}
+template <class FP> inline bool is_zero(const HFe<FP> &a) { return (a.l[0] | a.l[1] | a.l[2] | a.l[3]) == 0; }
+template <class FP> inline bool geq_p(const HFe<FP> &a) {
+    for (int i = 3; i >= 0; i--) {
+        uint64_t p = P64<FP>(i);
+        if (a.l[i] > p) return true;
+        if (a.l[i] < p) return false;
+    }
+    return true;
+}
+template <class FP> inline void sub_p(HFe<FP> &a) {
+    uint64_t br = 0;
+    for (int i = 0; i < 4; i++) {
+        u128 d = (u128)a.l[i] - P64<FP>(i) - br;
+        a.l[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1;
+    }
+}
+template <class FP> inline HFe<FP> add(const HFe<FP> &a, const HFe<FP> &b) {
+    HFe<FP> r; u128 c = 0;
+    for (int i = 0; i < 4; i++) { c += (u128)a.l[i] + b.l[i]; r.l[i] = (uint64_t)c; c >>= 64; }
+    if (geq_p(r)) sub_p(r);
+    return r;
+}
+template <class FP> inline HFe<FP> sub(const HFe<FP> &a, const HFe<FP> &b) {
+    HFe<FP> r; uint64_t br = 0;
+    for (int i = 0; i < 4; i++) {
+        u128 d = (u128)a.l[i] - b.l[i] - br;
+        r.l[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1;
+    }
+    if (br) {
+        u128 c = 0;
+        for (int i = 0; i < 4; i++) { c += (u128)r.l[i] + P64<FP>(i); r.l[i] = (uint64_t)c; c >>= 64; }
+    }
+    return r;
+}
+template <class FP> inline HFe<FP> dbl(const HFe<FP> &a) { return add(a, a); }
+template <class FP> inline HFe<FP> mul(const HFe<FP> &a, const HFe<FP> &b) {
+    static const uint64_t n0 = N064<FP>();
+    uint64_t t[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+        u128 c = 0;
+        for (int j = 0; j < 4; j++) { c += (u128)a.l[j] * b.l[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
+        c += t[4];
+        uint64_t t4 = (uint64_t)c;   // < 2^64: value stays below 2P * 2^64
+        uint64_t m = t[0] * n0;
+        c = (u128)m * P64<FP>(0) + t[0]; c >>= 64;
+        for (int j = 1; j < 4; j++) { c += (u128)m * P64<FP>(j) + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
+        c += t4; t[3] = (uint64_t)c; t[4] = (uint64_t)(c >> 64);
+    }
+    HFe<FP> r = {{t[0], t[1], t[2], t[3]}};
+    if (t[4] || geq_p(r)) sub_p(r);
+    return r;
+}
+template <class FP> inline HFe<FP> sqr(const HFe<FP> &a) { return mul(a, a); }
+template <class FP> inline HFe<FP> to_mont(const HFe<FP> &a) { return mul(a, r2<FP>()); }
+template <class FP> inline HFe<FP> from_u64(uint64_t v) { HFe<FP> r = {{v, 0, 0, 0}}; return to_mont(r); }
+// a^e, e given as 4 plain u64 limbs
+template <class FP> inline HFe<FP> pow(const HFe<FP> &a, const uint64_t e[4]) {
+    HFe<FP> acc = one<FP>(), base = a;
+    for (int i = 0; i < 256; i++) {
+        if ((e[i / 64] >> (i % 64)) & 1) acc = mul(acc, base);
+        base = sqr(base);
+    }
+    return acc;
+}
+template <class FP> inline HFe<FP> inv(const HFe<FP> &a) {
+    uint64_t e[4];
+    for (int i = 0; i < 4; i++) e[i] = P64<FP>(i);
+    e[0] -= 2;   // P[0] >= 2, no borrow
+    return pow(a, e);
+}
+
+template <class FP> struct HXyzz {
+    HFe<FP> x, y, zz, zzz;
+};
+template <class FP> inline HXyzz<FP> identity() { HXyzz<FP> r; memset(&r, 0, sizeof r); return r; }
+template <class FP> inline bool is_identity(const HXyzz<FP> &p) { return is_zero(p.zz); }
+template <class FP> inline HXyzz<FP> dbl_pt(const HXyzz<FP> &p) {   // dbl-2008-s-1
+    if (is_identity(p)) return p;
+    HFe<FP> u = dbl(p.y);
+    if (is_zero(u)) return identity<FP>();
+    HFe<FP> v = sqr(u), w = mul(u, v), s = mul(p.x, v), xx = sqr(p.x), m = add(dbl(xx), xx);
+    HXyzz<FP> r;
+    r.x = sub(sqr(m), dbl(s));
+    r.y = sub(mul(m, sub(s, r.x)), mul(w, p.y));
+    r.zz = mul(v, p.zz); r.zzz = mul(w, p.zzz);
+    return r;
+}
+template <class FP> inline HXyzz<FP> add_pt(const HXyzz<FP> &a, const HXyzz<FP> &b) {   // add-2008-s
+    if (is_identity(b)) return a;
+    if (is_identity(a)) return b;
+    HFe<FP> u1 = mul(a.x, b.zz), u2 = mul(b.x, a.zz), s1 = mul(a.y, b.zzz), s2 = mul(b.y, a.zzz);
+    HFe<FP> p = sub(u2, u1), r = sub(s2, s1);
+    if (is_zero(p)) return is_zero(r) ? dbl_pt(a) : identity<FP>();
+    HFe<FP> pp = sqr(p), ppp = mul(p, pp), q = mul(u1, pp);
+    HXyzz<FP> o;
+    o.x = sub(sub(sqr(r), ppp), dbl(q));
+    o.y = sub(mul(r, sub(q, o.x)), mul(s1, ppp));
+    o.zz = mul(mul(a.zz, b.zz), pp);
+    o.zzz = mul(mul(a.zzz, b.zzz), ppp);
+    return o;
+}
+// x || y as 8 u64 limbs, identity -> (0, 0)
+template <class FP> inline void to_affine(const HXyzz<FP> &p, uint64_t out[8]) {
+    if (is_identity(p)) { memset(out, 0, 64); return; }
+    HFe<FP> zi = inv(p.zzz);
+    HFe<FP> zzi = sqr(mul(zi, p.zz));
+    HFe<FP> x = mul(p.x, zzi), y = mul(p.y, zi);
+    memcpy(out, x.l, 32); memcpy(out + 4, y.l, 32);
+}
+}   // namespace hostf

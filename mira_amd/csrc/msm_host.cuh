@@ -1,0 +1,112 @@
+// Host-side launch sequence of one MSM (see msm_kernels.cuh for the pipeline).  Included by
+// the per-curve translation units.
+#pragma once
+#include "ctx.h"
+#include "msm_kernels.cuh"
+
+template <class FB, class FS>
+static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size_t n, const MsmPlan &p,
+                      uint64_t *host_windows /* W * 16 u64 */) {
+    int rc;
+    const size_t entries = (size_t)n * p.W;
+    if ((rc = g.digits.ensure(entries * 2))) return rc;
+    if ((rc = g.counts.ensure(((size_t)p.NB + 1) * 4))) return rc;
+    if ((rc = g.offsets.ensure(((size_t)p.NB + 1) * 4))) return rc;
+    if ((rc = g.cursor.ensure(((size_t)p.NB + 1) * 4))) return rc;
+    const uint32_t scan_blocks = ceil_div(p.NB, SCAN_TILE);
+    if (scan_blocks > 1024) { set_error("window configuration exceeds the scan capacity"); return MIRA_E_UNSUPPORTED; }
+    if ((rc = g.block_sums.ensure(1024 * 4))) return rc;
+    if ((rc = g.sorted_idx.ensure(entries * 4 + 4))) return rc;
+    if ((rc = g.sorted_key.ensure(entries * 4 + 4))) return rc;
+    if ((rc = g.bucket_sums.ensure((size_t)p.NB * 128))) return rc;
+    if ((rc = g.head_part.ensure((size_t)p.T * 128))) return rc;
+    if ((rc = g.tail_part.ensure((size_t)p.T * 128))) return rc;
+    if ((rc = g.head_key.ensure((size_t)p.T * 4))) return rc;
+    if ((rc = g.tail_key.ensure((size_t)p.T * 4))) return rc;
+    if ((rc = g.heavy.ensure(((size_t)p.T * 3 + 4) * 4))) return rc;
+    if ((rc = g.chunks.ensure((size_t)p.W * p.nchunks * 128))) return rc;
+    if ((rc = g.window_sums.ensure((size_t)p.W * 128))) return rc;
+
+    hipStream_t st = g.stream;
+    const unsigned char *bases = reinterpret_cast<const unsigned char *>(bs.d) + first * 64;
+    uint32_t *heavy_count = reinterpret_cast<uint32_t *>(g.heavy.p);
+    uint32_t *heavy_list = heavy_count + 4;
+
+    tm_begin();
+    RT_CHECK(rt_memset(g.counts.p, 0, ((size_t)p.NB + 1) * 4, st));
+    RT_CHECK(rt_memset(g.bucket_sums.p, 0, (size_t)p.NB * 128, st));
+    RT_CHECK(rt_memset(g.head_key.p, 0xFF, (size_t)p.T * 4, st));
+    RT_CHECK(rt_memset(g.tail_key.p, 0xFF, (size_t)p.T * 4, st));
+    RT_CHECK(rt_memset(heavy_count, 0, 16, st));
+    tm_mark("memset");
+
+    LAUNCH(k_digits<FS>, ceil_div(n, 256), 256, 0, st, reinterpret_cast<const unsigned char *>(d_scalars), (uint32_t)n, p.c, p.W,
+           reinterpret_cast<int16_t *>(g.digits.p));
+    tm_mark("digits");
+    LAUNCH_BARRIER_FLEX(k_hist, dim3(p.ntiles, p.W), 1024, (size_t)p.B * 4, st, reinterpret_cast<const int16_t *>(g.digits.p), (uint32_t)n,
+                   p.B, p.tile, reinterpret_cast<uint32_t *>(g.counts.p));
+    tm_mark("hist");
+    LAUNCH_BARRIER(k_scan_a, scan_blocks, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.counts.p), p.NB,
+                   reinterpret_cast<uint32_t *>(g.block_sums.p));
+    LAUNCH_BARRIER(k_scan_b, 1, 1024, 0, st, reinterpret_cast<uint32_t *>(g.block_sums.p), scan_blocks);
+    LAUNCH_BARRIER(k_scan_c, scan_blocks, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.counts.p), p.NB,
+                   reinterpret_cast<const uint32_t *>(g.block_sums.p), reinterpret_cast<uint32_t *>(g.offsets.p),
+                   reinterpret_cast<uint32_t *>(g.cursor.p));
+    tm_mark("scan");
+    LAUNCH_BARRIER_FLEX(k_scatter, dim3(p.ntiles, p.W), 1024, (size_t)p.B * 4, st, reinterpret_cast<const int16_t *>(g.digits.p),
+                   (uint32_t)n, p.B, p.tile, reinterpret_cast<uint32_t *>(g.cursor.p), reinterpret_cast<uint32_t *>(g.sorted_idx.p),
+                   reinterpret_cast<uint32_t *>(g.sorted_key.p));
+    tm_mark("scatter");
+    const uint32_t *total_ptr = reinterpret_cast<const uint32_t *>(g.offsets.p) + p.NB;
+    LAUNCH(k_accumulate<FB>, ceil_div(p.T, 128), 128, 0, st, reinterpret_cast<const uint32_t *>(g.sorted_idx.p),
+           reinterpret_cast<const uint32_t *>(g.sorted_key.p), total_ptr, bases, p.L,
+           reinterpret_cast<unsigned char *>(g.bucket_sums.p), reinterpret_cast<unsigned char *>(g.head_part.p),
+           reinterpret_cast<uint32_t *>(g.head_key.p), reinterpret_cast<unsigned char *>(g.tail_part.p),
+           reinterpret_cast<uint32_t *>(g.tail_key.p));
+    tm_mark("accumulate");
+    LAUNCH(k_fixup<FB>, ceil_div(p.T, 128), 128, 0, st, p.T, p.L, reinterpret_cast<const uint32_t *>(g.offsets.p),
+           reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
+           reinterpret_cast<const uint32_t *>(g.tail_key.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p), heavy_count, heavy_list);
+    LAUNCH_BARRIER(k_fixup_heavy<FB>, 256, FIXUP_BLOCK, 0, st, heavy_count, heavy_list,
+                   reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
+                   reinterpret_cast<unsigned char *>(g.bucket_sums.p));
+    tm_mark("fixup");
+    LAUNCH(k_reduce_chunks<FB>, ceil_div((uint64_t)p.W * p.nchunks, 64), 64, 0, st,
+           reinterpret_cast<const unsigned char *>(g.bucket_sums.p), p.B, p.m, p.W, reinterpret_cast<unsigned char *>(g.chunks.p));
+    tm_mark("reduce_chunks");
+    LAUNCH_BARRIER(k_window_sum<FB>, p.W, FIXUP_BLOCK, 0, st, reinterpret_cast<const unsigned char *>(g.chunks.p), p.nchunks,
+                   reinterpret_cast<unsigned char *>(g.window_sums.p));
+    tm_mark("window_sum");
+    RT_CHECK(rt_last());
+    RT_CHECK(rt_d2h(host_windows, g.window_sums.p, (size_t)p.W * 128, st));
+    RT_CHECK(rt_sync(st));
+    tm_end();
+    return MIRA_OK;
+}
+
+
+template <class FB, class FS> static int curve_init() {
+#ifndef MIRA_CPU_EMU
+    // the LDS-staged histogram needs more than the 64 KiB default (128 KiB at c = 16)
+    RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#endif
+    return MIRA_OK;
+}
+template <class FS> static int synth_scalars(size_t n, uint64_t index0, uint64_t seed, int kind, void *d_out) {
+    LAUNCH(k_synth_scalars<FS>, ceil_div(n, 256), 256, 0, g.stream, (uint64_t)n, index0, seed, kind, reinterpret_cast<unsigned char *>(d_out));
+    RT_CHECK(rt_last());
+    RT_CHECK(rt_sync(g.stream));
+    return MIRA_OK;
+}
+template <class FB> static int synth_bases(size_t n, uint64_t index0, uint64_t seed, const unsigned char *d_gen, void *d_out) {
+    LAUNCH(k_synth_bases<FB>, ceil_div(n, 64), 64, 0, g.stream, (uint64_t)n, index0, seed, d_gen, reinterpret_cast<unsigned char *>(d_out));
+    RT_CHECK(rt_last());
+    RT_CHECK(rt_sync(g.stream));
+    return MIRA_OK;
+}
+template <class FB> static int check_bases(const Bases &bs, const unsigned char *d_b, uint32_t *d_bad) {
+    LAUNCH(k_check_on_curve<FB>, ceil_div(bs.n, 256), 256, 0, g.stream, (const unsigned char *)bs.d, (uint64_t)bs.n, d_b, d_bad);
+    RT_CHECK(rt_last());
+    return MIRA_OK;
+}

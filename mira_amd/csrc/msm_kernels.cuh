@@ -1,0 +1,362 @@
+// Pippenger MSM kernels for gfx950.  Replaces halo2_proofs::arithmetic::best_multiexp as
+// called by CommitmentKey::commit (reference src/commitment.rs:78-87).
+//
+// Pipeline (all on one HIP stream, no host round trip until the W window sums come back):
+//   k_digits      scalar (Montgomery) -> canonical integer -> W signed c-bit digits (int16)
+//   k_hist        per (window, point-tile) workgroup: bucket histogram staged in LDS
+//                 (2^(c-1) counters = 128 KiB at c = 16), flushed with coalesced atomics
+//   k_scan_*      exclusive scan of the W * 2^(c-1) counters
+//   k_scatter     same tiling; the workgroup claims a contiguous range per bucket (one global
+//                 atomic per non-empty LDS bin) and places (point index | sign) and bucket key
+//   k_accumulate  every lane owns exactly L consecutive sorted entries (perfect balance however
+//                 skewed the scalars are); complete bucket runs go straight to bucket_sums, runs
+//                 cut by a lane boundary leave a head/tail partial
+//   k_fixup*      joins the partials: short chains by one lane, long chains (heavy buckets such as
+//                 "all witness cells equal 1") by a workgroup-wide strided sum + LDS tree
+//   k_reduce_chunks / k_window_sum   sum_b (b+1) * S_b per window by chunked running sums
+// Host: Horner over the W window sums and the single inversion of to_affine().
+#pragma once
+#include "curve.cuh"
+
+static constexpr uint32_t KEY_NONE = 0xFFFFFFFFu;
+static constexpr int HEAVY_SPAN = 48;       // chains longer than this go to k_fixup_heavy
+static constexpr int FIXUP_BLOCK = 256;
+
+// ------------------------------------------------------------------------------------------
+template <class FS>
+KERNEL void k_digits(const unsigned char *__restrict__ scalars, uint32_t n, uint32_t c, uint32_t W,
+                     int16_t *__restrict__ digits) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fe<FS> s = fe_from_mont(fe_load<FS>(scalars + (size_t)i * 32));
+    const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
+    uint32_t carry = 0;
+    for (uint32_t w = 0; w < W; w++) {
+        uint32_t raw = (s.l[0] & mask) + carry;
+#pragma unroll
+        for (int k = 0; k < 7; k++) s.l[k] = (s.l[k] >> c) | (s.l[k + 1] << (32 - c));   // c in [1,16]
+        s.l[7] >>= c;
+        int32_t d;
+        if (raw >= half) { d = (int32_t)raw - (int32_t)(1u << c); carry = 1; }
+        else { d = (int32_t)raw; carry = 0; }
+        digits[(size_t)w * n + i] = (int16_t)d;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// grid = (ntiles, W), dynamic LDS = B * 4 bytes
+KERNEL void k_hist(const int16_t *__restrict__ digits, uint32_t n, uint32_t B, uint32_t tile,
+                   uint32_t *__restrict__ counts) {
+    DYN_SHARED(uint32_t, bins);
+    const uint32_t w = blockIdx.y;
+    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) bins[b] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * tile, end = (base + tile < n) ? base + tile : n;
+    const int16_t *dw = digits + (size_t)w * n;
+    for (uint32_t i = base + threadIdx.x; i < end; i += blockDim.x) {
+        int32_t d = dw[i];
+        if (d != 0) atomicAdd(&bins[(uint32_t)(d < 0 ? -d : d) - 1], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) {
+        uint32_t cnt = bins[b];
+        if (cnt) atomicAdd(&counts[(size_t)w * B + b], cnt);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Exclusive scan of counts[0..NB) in three launches.  SCAN_ITEMS consecutive counters per lane.
+static constexpr int SCAN_BLOCK = 256, SCAN_ITEMS = 8, SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
+
+KERNEL void k_scan_a(const uint32_t *__restrict__ counts, uint32_t NB, uint32_t *__restrict__ block_sums) {
+    __shared__ uint32_t red[SCAN_BLOCK];
+    uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS, s = 0;
+    for (int k = 0; k < SCAN_ITEMS; k++)
+        if (base + k < NB) s += counts[base + k];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (uint32_t st = SCAN_BLOCK / 2; st > 0; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = red[0];
+}
+// one workgroup of 1024 lanes; nblocks <= 1024
+KERNEL void k_scan_b(uint32_t *__restrict__ block_sums, uint32_t nblocks) {
+    __shared__ uint32_t buf[1024];
+    uint32_t v = threadIdx.x < nblocks ? block_sums[threadIdx.x] : 0;
+    buf[threadIdx.x] = v;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        uint32_t add = threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
+        __syncthreads();
+        buf[threadIdx.x] += add;
+        __syncthreads();
+    }
+    if (threadIdx.x < nblocks) block_sums[threadIdx.x] = buf[threadIdx.x] - v;   // exclusive
+}
+// offsets[NB] = total number of sorted entries; cursor = copy of offsets for k_scatter
+KERNEL void k_scan_c(const uint32_t *__restrict__ counts, uint32_t NB, const uint32_t *__restrict__ block_sums,
+                     uint32_t *__restrict__ offsets, uint32_t *__restrict__ cursor) {
+    __shared__ uint32_t buf[SCAN_BLOCK];
+    uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint32_t loc[SCAN_ITEMS], s = 0;
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        loc[k] = (base + k < NB) ? counts[base + k] : 0;
+        s += loc[k];
+    }
+    buf[threadIdx.x] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < SCAN_BLOCK; off <<= 1) {
+        uint32_t add = threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
+        __syncthreads();
+        buf[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = block_sums[blockIdx.x] + buf[threadIdx.x] - s;
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        if (base + k < NB) { offsets[base + k] = run; cursor[base + k] = run; }
+        run += loc[k];
+        if (base + k == NB - 1) offsets[NB] = run;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// grid = (ntiles, W), dynamic LDS = B * 4 bytes.  Same tiling as k_hist.
+KERNEL void k_scatter(const int16_t *__restrict__ digits, uint32_t n, uint32_t B, uint32_t tile,
+                      uint32_t *__restrict__ cursor, uint32_t *__restrict__ sorted_idx,
+                      uint32_t *__restrict__ sorted_key) {
+    DYN_SHARED(uint32_t, bins);
+    const uint32_t w = blockIdx.y;
+    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) bins[b] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * tile, end = (base + tile < n) ? base + tile : n;
+    const int16_t *dw = digits + (size_t)w * n;
+    for (uint32_t i = base + threadIdx.x; i < end; i += blockDim.x) {
+        int32_t d = dw[i];
+        if (d != 0) atomicAdd(&bins[(uint32_t)(d < 0 ? -d : d) - 1], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) {
+        uint32_t cnt = bins[b];
+        if (cnt) bins[b] = atomicAdd(&cursor[(size_t)w * B + b], cnt);   // claimed range start
+    }
+    __syncthreads();
+    for (uint32_t i = base + threadIdx.x; i < end; i += blockDim.x) {
+        int32_t d = dw[i];
+        if (d != 0) {
+            uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1;
+            uint32_t pos = atomicAdd(&bins[b], 1u);
+            sorted_idx[pos] = i | (d < 0 ? 0x80000000u : 0u);
+            sorted_key[pos] = w * B + b;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+template <class FB>
+KERNEL void __launch_bounds__(128) k_accumulate(const uint32_t *__restrict__ sorted_idx, const uint32_t *__restrict__ sorted_key,
+                         const uint32_t *__restrict__ total_ptr, const unsigned char *__restrict__ bases,
+                         uint32_t L, unsigned char *__restrict__ bucket_sums,
+                         unsigned char *__restrict__ head_part, uint32_t *__restrict__ head_key,
+                         unsigned char *__restrict__ tail_part, uint32_t *__restrict__ tail_key) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t total = *total_ptr;
+    const uint64_t start64 = (uint64_t)t * L;
+    if (start64 >= total) return;
+    const uint32_t start = (uint32_t)start64;
+    const uint32_t end = (total - start > L) ? start + L : total;
+    uint32_t cur = sorted_key[start];
+    const bool cont_prev = start > 0 && sorted_key[start - 1] == cur;
+    bool first = true;
+    Xyzz<FB> acc = xyzz_identity<FB>();
+    for (uint32_t j = start; j < end; j++) {
+        uint32_t k = sorted_key[j];
+        if (k != cur) {
+            if (first && cont_prev) { xyzz_store(head_part + (size_t)t * 128, acc); head_key[t] = cur; }
+            else xyzz_store(bucket_sums + (size_t)cur * 128, acc);
+            first = false;
+            acc = xyzz_identity<FB>();
+            cur = k;
+        }
+        uint32_t e = sorted_idx[j];
+        Aff<FB> p = aff_load<FB>(bases + (size_t)(e & 0x7FFFFFFFu) * 64);
+        if (e >> 31) p.y = fe_neg(p.y);
+        xyzz_add_affine(acc, p);
+    }
+    const bool cont_next = end < total && sorted_key[end] == cur;
+    if (first && cont_prev) { xyzz_store(head_part + (size_t)t * 128, acc); head_key[t] = cur; }
+    else if (cont_next) { xyzz_store(tail_part + (size_t)t * 128, acc); tail_key[t] = cur; }
+    else xyzz_store(bucket_sums + (size_t)cur * 128, acc);
+}
+
+// One lane per k_accumulate lane that owns the start of a cut run.
+template <class FB>
+KERNEL void __launch_bounds__(128) k_fixup(uint32_t T, uint32_t L, const uint32_t *__restrict__ offsets,
+                    const unsigned char *__restrict__ head_part, const unsigned char *__restrict__ tail_part,
+                    const uint32_t *__restrict__ tail_key, unsigned char *__restrict__ bucket_sums,
+                    uint32_t *__restrict__ heavy_count, uint32_t *__restrict__ heavy_list) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const uint32_t key = tail_key[t];
+    if (key == KEY_NONE) return;
+    const uint32_t run_end = offsets[key + 1];
+    const uint32_t span = (run_end - 1) / L - t;   // lanes t+1 .. t+span hold head partials of this run
+    if (span > (uint32_t)HEAVY_SPAN) {
+        uint32_t h = atomicAdd(heavy_count, 1u);
+        heavy_list[3 * h] = t; heavy_list[3 * h + 1] = span; heavy_list[3 * h + 2] = key;
+        return;
+    }
+    Xyzz<FB> acc = xyzz_load<FB>(tail_part + (size_t)t * 128);
+    for (uint32_t q = 1; q <= span; q++) xyzz_add(acc, xyzz_load<FB>(head_part + (size_t)(t + q) * 128));
+    xyzz_store(bucket_sums + (size_t)key * 128, acc);
+}
+
+// Workgroup per heavy run (grid-stride over the list).  blockDim.x == FIXUP_BLOCK.
+template <class FB>
+KERNEL void __launch_bounds__(256) k_fixup_heavy(const uint32_t *__restrict__ heavy_count, const uint32_t *__restrict__ heavy_list,
+                          const unsigned char *__restrict__ head_part, const unsigned char *__restrict__ tail_part,
+                          unsigned char *__restrict__ bucket_sums) {
+    __shared__ __attribute__((aligned(16))) unsigned char red[FIXUP_BLOCK * 128];
+    const uint32_t nheavy = *heavy_count;
+    for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
+        const uint32_t t = heavy_list[3 * h], span = heavy_list[3 * h + 1], key = heavy_list[3 * h + 2];
+        Xyzz<FB> acc = xyzz_identity<FB>();
+        for (uint32_t q = threadIdx.x; q < span; q += blockDim.x)
+            xyzz_add(acc, xyzz_load<FB>(head_part + (size_t)(t + 1 + q) * 128));
+        xyzz_store(red + threadIdx.x * 128, acc);
+        __syncthreads();
+        for (uint32_t st = FIXUP_BLOCK / 2; st > 0; st >>= 1) {
+            if (threadIdx.x < st) {
+                xyzz_add(acc, xyzz_load<FB>(red + (threadIdx.x + st) * 128));
+                xyzz_store(red + threadIdx.x * 128, acc);
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            xyzz_add(acc, xyzz_load<FB>(tail_part + (size_t)t * 128));
+            xyzz_store(bucket_sums + (size_t)key * 128, acc);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Lane (w, j) folds buckets [j*m, (j+1)*m) of window w:
+//   R[w][j] = sum_i (j*m + i + 1) * S[w][j*m + i]
+template <class FB>
+KERNEL void __launch_bounds__(64) k_reduce_chunks(const unsigned char *__restrict__ bucket_sums, uint32_t B, uint32_t m, uint32_t W,
+                            unsigned char *__restrict__ R) {
+    const uint32_t nchunks = B / m;
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nchunks * W) return;
+    const uint32_t w = g / nchunks, j = g % nchunks;
+    const unsigned char *S = bucket_sums + ((size_t)w * B + (size_t)j * m) * 128;
+    Xyzz<FB> running = xyzz_identity<FB>(), ws = xyzz_identity<FB>();
+    for (int i = (int)m - 1; i >= 0; i--) {
+        xyzz_add(running, xyzz_load<FB>(S + (size_t)i * 128));
+        xyzz_add(ws, running);
+    }
+    // + (j*m) * running, MSB-first double-and-add on the (<= 15-bit) chunk offset
+    const uint32_t k = j * m;
+    if (k != 0 && !xyzz_is_identity(running)) {
+        Xyzz<FB> acc = xyzz_identity<FB>();
+        for (int bit = 31 - __builtin_clz(k); bit >= 0; bit--) {
+            acc = xyzz_double(acc);
+            if ((k >> bit) & 1) xyzz_add(acc, running);
+        }
+        xyzz_add(ws, acc);
+    }
+    xyzz_store(R + (size_t)g * 128, ws);
+}
+
+// Workgroup per window: window_sums[w] = sum_j R[w][j].  blockDim.x == FIXUP_BLOCK.
+template <class FB>
+KERNEL void __launch_bounds__(256) k_window_sum(const unsigned char *__restrict__ R, uint32_t nchunks, unsigned char *__restrict__ window_sums) {
+    __shared__ __attribute__((aligned(16))) unsigned char red[FIXUP_BLOCK * 128];
+    const uint32_t w = blockIdx.x;
+    Xyzz<FB> acc = xyzz_identity<FB>();
+    for (uint32_t q = threadIdx.x; q < nchunks; q += blockDim.x)
+        xyzz_add(acc, xyzz_load<FB>(R + ((size_t)w * nchunks + q) * 128));
+    xyzz_store(red + threadIdx.x * 128, acc);
+    __syncthreads();
+    for (uint32_t st = FIXUP_BLOCK / 2; st > 0; st >>= 1) {
+        if (threadIdx.x < st) {
+            xyzz_add(acc, xyzz_load<FB>(red + (threadIdx.x + st) * 128));
+            xyzz_store(red + threadIdx.x * 128, acc);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) xyzz_store(window_sums + (size_t)w * 128, acc);
+}
+
+// ------------------------------------------------------------------------------------------
+// Synthetic inputs; same definition as oracle/pyref.py synth_* so that tests
+// can cross-check them.  One splitmix64 stream per index.
+HD uint64_t sm_next(uint64_t &s) {
+    s += 0x9E3779B97F4A7C15ull;
+    uint64_t z = s;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static constexpr uint64_t STREAM_MUL = 0xD6E8FEB86659FD93ull;
+
+// kind 0 uniform, 1 witness-like (70 % zero, 20 % < 2^32, 10 % uniform).  Montgomery out.
+template <class FS>
+KERNEL void k_synth_scalars(uint64_t n, uint64_t index0, uint64_t seed, int kind, unsigned char *__restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t s = seed + (index0 + i) * STREAM_MUL;
+    Fe<FS> v;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint64_t x = sm_next(s);
+        v.l[2 * k] = (uint32_t)x; v.l[2 * k + 1] = (uint32_t)(x >> 32);
+    }
+    for (int it = 0; it < 6; it++) {   // 2^256 < 6 P
+        Fe<FS> t;
+        if (!sub_p(t, v)) v = t;
+    }
+    if (kind == 1) {
+        uint64_t sel = sm_next(s) % 10;
+        if (sel < 7) v = fe_zero<FS>();
+        else if (sel < 9) {
+#pragma unroll
+            for (int k = 1; k < 8; k++) v.l[k] = 0;
+        }
+    }
+    fe_store(out + i * 32, fe_to_mont(v));
+}
+
+// P_i = k_i * G, k_i = odd 128-bit integer from the stream; affine Montgomery out.
+template <class FB>
+KERNEL void __launch_bounds__(64) k_synth_bases(uint64_t n, uint64_t index0, uint64_t seed, const unsigned char *__restrict__ gen,
+                          unsigned char *__restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t s = seed + (index0 + i) * STREAM_MUL;
+    uint64_t k0 = sm_next(s) | 1ull, k1 = sm_next(s);
+    Aff<FB> g = aff_load<FB>(gen);
+    Xyzz<FB> acc = xyzz_identity<FB>();
+    for (int bit = 127; bit >= 0; bit--) {
+        acc = xyzz_double(acc);
+        uint64_t word = bit >= 64 ? k1 : k0;
+        if ((word >> (bit & 63)) & 1) xyzz_add_affine(acc, g);
+    }
+    aff_store(out + i * 64, xyzz_to_affine(acc));
+}
+
+// out[i] = 1 when bases[i] satisfies y^2 = x^3 + b (or is the identity); b in Montgomery form.
+// The reference validates a cached key this way (src/commitment.rs:145-154).
+template <class FB>
+KERNEL void k_check_on_curve(const unsigned char *__restrict__ bases, uint64_t n, const unsigned char *__restrict__ b_mont,
+                             uint32_t *__restrict__ bad_count) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Aff<FB> p = aff_load<FB>(bases + i * 64);
+    if (aff_is_identity(p)) return;
+    Fe<FB> lhs = fe_sqr(p.y);
+    Fe<FB> rhs = fe_add(fe_mul(fe_sqr(p.x), p.x), fe_load<FB>(b_mont));
+    if (!fe_eq(lhs, rhs)) atomicAdd(bad_count, 1u);
+}

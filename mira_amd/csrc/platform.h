@@ -1,0 +1,27 @@
+// Platform layer for the kernels in this directory.
+//
+// The product build is hipcc --offload-arch=gfx950 (everything below the #else).  The
+// MIRA_CPU_EMU branch exists ONLY for tests/emu: it runs the same kernel sources on host
+// threads (one OS thread per lane of a workgroup when the kernel uses a barrier) so kernel
+// indexing can be checked, and sanitizers run, in a container without a GPU.  It is never
+// part of libmira_gpu.so and mira_amd/ never loads it.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#ifndef MIRA_CPU_EMU
+#include <hip/hip_runtime.h>
+#define HD __host__ __device__ __forceinline__
+#define DEV __device__ __forceinline__
+#define KERNEL static __global__
+#define LAUNCH(kern, grid, block, shmem, stream, ...) \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), (shmem), (stream), __VA_ARGS__)
+#define LAUNCH_BARRIER LAUNCH
+#define LAUNCH_BARRIER_FLEX LAUNCH   // kernel is correct for any blockDim (strided loops)
+#define DYN_SHARED(type, name) extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw[]; type *name = reinterpret_cast<type *>(name##_raw)
+#else
+#include "../../tests/emu/emu.h"
+#endif

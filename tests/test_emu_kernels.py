@@ -1,0 +1,98 @@
+"""Kernel-logic checks without a GPU: the same kernel sources built against the test-only host
+emulation (tests/emu/emu.h), compared with the oracle.  Sizes are tiny: every emulated lane is
+a host loop iteration or an OS thread.  The GPU parity tests proper are test_gpu_*.py."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from helpers import golden_msm_case, load_golden, mont_to_ints
+from mira_amd import commitment as cm
+from mira_amd import fft as F
+from oracle import cref as C
+from oracle import pyref as P
+
+
+def test_emu_synth_matches_oracle(emu_lib):
+    for cid in (0, 1):
+        p = cm.synth_scalars_device(cid, 70, seed=3, kind=1, lib=emu_lib)
+        assert (emu_lib.download(p, (70, 4)) == C.synth_scalars(cid, 70, seed=3, kind=1)).all()
+        key = cm.CommitmentKey.synthetic(cid, 6, seed=4, lib=emu_lib)
+        assert (key.bases() == C.synth_bases(cid, 6, seed=4)).all()
+        key.check_on_curve()
+
+
+def test_emu_check_on_curve_rejects_bad_point(emu_lib):
+    from mira_amd._lib import MiraError, MIRA_E_INVALID_POINT
+    bs = C.synth_bases(0, 4)
+    bs[2, 0] ^= np.uint64(1)
+    key = cm.CommitmentKey(0, bs, lib=emu_lib)
+    with pytest.raises(MiraError) as e:
+        key.check_on_curve()
+    assert e.value.code == MIRA_E_INVALID_POINT
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_emu_msm_golden(emu_lib, cid):
+    for case in load_golden("msm_vectors.json")[str(cid)]:
+        if case["n"] > 33:
+            continue
+        sc, bs, expected = golden_msm_case(cid, case)
+        key = cm.CommitmentKey(cid, bs, lib=emu_lib)
+        assert (key.commit(sc) == expected).all()
+
+
+@pytest.mark.parametrize("c", [4, 7])
+def test_emu_msm_skewed_and_forced_window(emu_lib, c):
+    """Small windows make every bucket heavy: exercises cut runs, the short fix-up chain and the
+    workgroup-wide heavy fix-up."""
+    cid, n = 0, 1500
+    bs = C.synth_bases(cid, 16)
+    bs = np.tile(bs, (n // 16 + 1, 1))[:n]
+    key = cm.CommitmentKey(cid, bs, lib=emu_lib)
+    emu_lib.check(emu_lib.c.mira_msm_set_window_bits(c))
+    try:
+        ones = np.tile(C.to_mont(C.FIELD_FR, np.array([1, 0, 0, 0], dtype=np.uint64)), (n, 1))
+        for sc in (ones, C.synth_scalars(cid, n, seed=8, kind=1), C.synth_scalars(cid, n, seed=9)):
+            assert (key.commit(sc) == C.msm_pippenger(cid, sc, bs)).all()
+    finally:
+        emu_lib.check(emu_lib.c.mira_msm_set_window_bits(0))
+
+
+def test_emu_partial_and_combine(emu_lib):
+    cid, n = 1, 600
+    bs, sc = C.synth_bases(cid, n, seed=2), C.synth_scalars(cid, n, seed=3)
+    key = cm.CommitmentKey(cid, bs, lib=emu_lib)
+    d = emu_lib.alloc(n * 32)
+    emu_lib.upload(d, sc)
+    parts = []
+    for first, cnt in ((0, 250), (250, 350)):
+        part, c, w = key.commit_partial_device(first, d + first * 32, cnt)
+        parts.append(part)
+    got = cm.combine_partials(cid, np.stack(parts), c, w, lib=emu_lib)
+    assert (got == C.msm_pippenger(cid, sc, bs)).all()
+
+
+@pytest.mark.parametrize("k", [0, 1, 3, 4, 10])
+def test_emu_ntt(emu_lib, k):
+    a = C.synth_scalars(0, 1 << k, seed=1000 + k)
+    assert (F.fft(a, k, lib=emu_lib) == C.fft(a, k)).all()
+    assert (F.ifft(a, k, lib=emu_lib) == C.ifft(a, k)).all()
+    if k in (4, 10):
+        g = load_golden("ntt_vectors.json")[str(k)]
+        assert mont_to_ints(F.coset_fft(a, lib=emu_lib), P.R_MOD) == [int(v, 16) for v in g["coset_fft"]]
+        assert mont_to_ints(F.coset_ifft(a, lib=emu_lib), P.R_MOD) == [int(v, 16) for v in g["coset_ifft"]]
+
+
+def test_emu_ntt_four_step(emu_lib):
+    k = 13   # first size that takes the two-pass (column / twiddle / row) route
+    a = C.synth_scalars(0, 1 << k, seed=5)
+    assert (F.fft(a, k, lib=emu_lib) == C.fft(a, k)).all()
+    w = C.get_omega_or_inv(k, True)
+    assert (F.best_fft(a, w, k, lib=emu_lib) == C.best_fft(a, w, k)).all()
+
+
+def test_emu_omega(emu_lib):
+    for k in (0, 3, 24, 28):
+        for inv in (False, True):
+            assert (F.get_omega_or_inv(k, inv, lib=emu_lib) == C.get_omega_or_inv(k, inv)).all()

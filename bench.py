@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""Headline benchmark: BN256 G1 MSM throughput through CommitmentKey::commit on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one MSM (the whole commit hot path: digit recoding, bucket sort, bucket accumulation,
+bucket reduction, window combine, to_affine) over one batch of synthetic scalars, with scalars and
+bases already resident in HBM.  N = 1: BASELINE.json configs[1] (2^22 pairs, 16-bit windows).
+N > 1: one process per GPU; the (scalar, base) pairs are sharded by point chunk, 2^22 pairs per
+GPU (weak scaling); each rank reduces its chunk to W window sums, one RCCL all-gather exchanges
+them (W * 128 bytes per rank) and every rank combines -- EC addition is not an RCCL reduction
+operator, so all-gather + local add is the exchange.
+
+Prints ONE JSON line on rank 0.  Extra keys: `roofline` (dominant kernel k_accumulate, algorithmic
+bytes = 96 B per pair), `cpu_baseline` (the C restatement of the reference's
+best_multiexp on the host cores, bounded sample), `stages_ms`, and at N = 1 `extras` with the
+2^24 NTT and the k = 17 fold-step MSM schedule beside their CPU timings.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+MSM_BYTES_PER_PAIR = 96        # 64 B affine base + 32 B scalar, each read once
+NTT_BYTES_PER_ELEM = 64        # 32 B read + 32 B written
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log-n", type=int, default=22, help="log2 of pairs per GPU")
+    ap.add_argument("--window-bits", type=int, default=16)
+    ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = max(world, 1)
+
+    from mira_amd import _lib
+    from mira_amd import commitment as cm
+    lib = _lib.load()
+    lib.check(lib.c.mira_init(local_rank))
+    lib.check(lib.c.mira_msm_set_window_bits(args.window_bits))
+
+    cid = cm.CURVE_BN256
+    n = 1 << args.log_n
+    index0 = rank * n
+    t0 = time.time()
+    key = cm.CommitmentKey.synthetic(cid, n, index0=index0)
+    d_scalars = cm.synth_scalars_device(cid, n, index0=index0)
+    log(f"[rank {rank}] inputs generated on GPU in {time.time() - t0:.1f}s (n = 2^{args.log_n} per GPU)")
+
+    def sync_all():
+        lib.check(lib.c.mira_dev_sync())
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    def step():
+        if dist is None:
+            return key.commit_device(d_scalars, n)
+        import torch
+        part, c, w = key.commit_partial_device(0, d_scalars, n)
+        mine = torch.from_numpy(part[: w * 16].view(np.int64)).cuda()
+        allp = torch.empty(world * w * 16, dtype=torch.int64, device="cuda")
+        dist.all_gather_into_tensor(allp, mine)
+        parts = np.zeros((world, _lib.MIRA_PARTIAL_U64), dtype=np.uint64)
+        parts[:, : w * 16] = allp.cpu().numpy().view(np.uint64).reshape(world, w * 16)
+        return cm.combine_partials(cid, parts, c, w)
+
+    for _ in range(args.warmup):
+        result = step()
+    lib.check(lib.c.mira_set_timing(1))
+    stage_acc = {}
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        result = step()
+        for name, ms in lib.timings():
+            stage_acc[name] = stage_acc.get(name, 0.0) + ms
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    lib.check(lib.c.mira_set_timing(0))
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    total_pairs = n * n_gpus
+    value = total_pairs / (elapsed / args.steps) / 1e6
+    stages = {k: v / args.steps for k, v in stage_acc.items()}
+    t_acc = stages.get("accumulate", 0.0)
+    achieved = (MSM_BYTES_PER_PAIR * n / (t_acc * 1e-3) / 1e9) if t_acc > 0 else None
+
+    out = {
+        "metric": "bn256_g1_msm_throughput", "value": round(value, 3), "unit": "M scalar-point pairs/s",
+        "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u256 (8 x u32 limbs, Montgomery)",
+        "data": "synthetic",
+        "config": {"workload": f"BN256 G1 MSM 2^{args.log_n} pairs per GPU via CommitmentKey::commit, {args.window_bits}-bit signed windows",
+                   "pairs_per_gpu": n, "total_pairs": total_pairs, "window_bits": args.window_bits,
+                   "parallelism": f"point-chunk x{n_gpus}" if n_gpus > 1 else "single GPU",
+                   "inputs": "uniform Fr scalars, bases k_i*G, resident in HBM"},
+        "roofline": {"bound": "hbm", "kernel": "k_accumulate", "achieved": None if achieved is None else round(achieved, 2),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 5),
+                     "traffic": load_traffic(args.log_n), "algorithmic_bytes_per_launch": MSM_BYTES_PER_PAIR * n,
+                     "avg_launch_ms": round(t_acc, 4),
+                     "note": "integer-ALU bound (about 160 modular multiplications per pair); see DESIGN.md"},
+        "stages_ms": {k: round(v, 4) for k, v in stages.items()},
+    }
+
+    if rank == 0 and n_gpus == 1 and not args.no_cpu:
+        out["cpu_baseline"], parity = cpu_baseline_msm(lib, cm, key, d_scalars, n, args.window_bits)
+        out["parity"] = parity
+    if rank == 0 and n_gpus == 1 and not args.no_extras:
+        out["extras"] = extras(lib, cm, not args.no_cpu)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+def load_traffic(log_n):
+    """HBM bytes per k_accumulate launch from the committed PMC profile (collected in a separate
+    rocprofv3 --pmc pass, corrected as MI355X_MICROARCH.md prescribes), or null."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(f"k_accumulate_2p{log_n}")
+    except Exception:
+        return None
+
+
+def cpu_baseline_msm(lib, cm, key, d_scalars, n, window_bits):
+    """The oracle's restatement of best_multiexp (kind "port") on a bounded sample of the same
+    workload, all host cores; the same sample re-run on the GPU gives the parity flag."""
+    from oracle import cref as C
+    sample = min(n, 1 << 20)
+    bases = lib.download(key._owned_ptr, (sample, 8))
+    sc = lib.download(d_scalars, (sample, 4))
+    threads = C.num_threads()
+    t0 = time.perf_counter()
+    want = C.msm_pippenger(cm.CURVE_BN256, sc, bases, threads)
+    dt = time.perf_counter() - t0
+    got = key.commit_device(d_scalars, sample)
+    base = {"value": round(sample / dt / 1e6, 4), "unit": "M scalar-point pairs/s", "cores": threads, "kind": "port",
+            "sample": f"first 2^{sample.bit_length() - 1} of the 2^{n.bit_length() - 1} pairs, {dt:.2f} s, C restatement of halo2 best_multiexp"}
+    return base, {"sample_pairs": sample, "bit_exact_vs_oracle": bool((got == want).all())}
+
+
+def extras(lib, cm, with_cpu):
+    ex = {}
+    lib.check(lib.c.mira_msm_set_window_bits(0))
+    # ---- NTT 2^24 over bn256::Fr (BASELINE configs[2]) ---------------------------------------
+    try:
+        k = 24
+        n = 1 << k
+        d = cm.synth_scalars_device(cm.CURVE_BN256, n, seed=0x4E5454)
+        from mira_amd import fft as F
+        F.fft_device(d, k)                       # warm-up: builds the twiddle tables
+        lib.check(lib.c.mira_set_timing(1))
+        reps = 5
+        t0 = time.perf_counter()
+        acc = {}
+        for _ in range(reps):
+            F.fft_device(d, k)
+            for name, ms in lib.timings():
+                acc[name] = acc.get(name, 0.0) + ms / reps
+        dt = (time.perf_counter() - t0) / reps
+        lib.check(lib.c.mira_set_timing(0))
+        kern = acc.get("ntt_pass1", 0) + acc.get("ntt_pass2", 0)
+        ex["ntt_2p24"] = {"ms": round(dt * 1e3, 3), "M_elements_per_s": round(n / dt / 1e6, 2), "stages_ms": {a: round(b, 4) for a, b in acc.items()},
+                          "roofline": {"bound": "hbm", "achieved": round(NTT_BYTES_PER_ELEM * n / (kern * 1e-3) / 1e9, 2) if kern else None,
+                                       "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": round(NTT_BYTES_PER_ELEM * n / (kern * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if kern else None}}
+        if with_cpu:
+            from oracle import cref as C
+            ks = 20
+            a = lib.download(d, (1 << ks, 4))
+            t0 = time.perf_counter()
+            want = C.fft(a, ks)
+            dtc = time.perf_counter() - t0
+            got = F.fft(a, ks)
+            ex["ntt_2p24"]["cpu_baseline"] = {"value": round((1 << ks) / dtc / 1e6, 3), "unit": "M elements/s", "cores": C.num_threads(), "kind": "port",
+                                              "sample": f"2^{ks}-point fft, {dtc:.2f} s, restatement of src/fft.rs best_fft"}
+            ex["ntt_2p24"]["bit_exact_vs_oracle_2p20"] = bool((got == want).all())
+        lib.free(d)
+    except Exception as e:   # extras never take the headline down
+        ex["ntt_2p24"] = {"error": repr(e)}
+
+    # ---- fold-step MSM schedule at k = 17 -----------------------------
+    try:
+        k = 17
+        sched = [(cm.CURVE_BN256, 14 << k, 1)] + [(cm.CURVE_BN256, 1 << k, 0)] * 6 + \
+                [(cm.CURVE_GRUMPKIN, 7 << k, 1)] + [(cm.CURVE_GRUMPKIN, 1 << k, 0)] * 5
+        keys = {c: cm.CommitmentKey.synthetic(c, max(nn for cc, nn, _ in sched if cc == c), seed=0x464F4C44 + c) for c in (0, 1)}
+        bufs = [cm.synth_scalars_device(c, nn, seed=0x1000 + i, kind=kind) for i, (c, nn, kind) in enumerate(sched)]
+        for (c, nn, _), d in zip(sched, bufs):          # warm-up
+            keys[c].commit_device(d, nn)
+        t0 = time.perf_counter()
+        gpu_pts = [keys[c].commit_device(d, nn) for (c, nn, _), d in zip(sched, bufs)]
+        gpu_ms = (time.perf_counter() - t0) * 1e3
+        ex["fold_step_k17"] = {"msm_calls": len(sched), "pairs": sum(nn for _, nn, _ in sched), "gpu_ms": round(gpu_ms, 3),
+                               "note": "13-call MSM schedule of one IVC fold step (witness-like scalars on the two large calls); "
+                                       "the Rust driver (examples/groth16) cannot be built here"}
+        if with_cpu:
+            from oracle import cref as C
+            host = [(lib.download(keys[c]._owned_ptr, (nn, 8)), lib.download(d, (nn, 4))) for (c, nn, _), d in zip(sched, bufs)]
+            t0 = time.perf_counter()
+            cpu_pts = [C.msm_pippenger(c, sc, bs) for (c, _, _), (bs, sc) in zip(sched, host)]
+            cpu_ms = (time.perf_counter() - t0) * 1e3
+            ex["fold_step_k17"].update({"cpu_ms": round(cpu_ms, 1), "cpu_cores": C.num_threads(), "cpu_kind": "port",
+                                        "bit_exact_all_13": bool(all((a == b).all() for a, b in zip(gpu_pts, cpu_pts)))})
+    except Exception as e:
+        ex["fold_step_k17"] = {"error": repr(e)}
+    return ex
+
+
+if __name__ == "__main__":
+    main()

@@ -29,6 +29,24 @@ SYMBOLS = [
 ]
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  The PyTorch wheel bundles its own libamdhip64.so (same
+    SONAME as /opt/rocm's); if libmira_gpu.so pulled in the system copy first and torch (needed
+    for torch.distributed / RCCL) were imported later, the process would hold two runtimes and
+    the second would see no device.  Loading torch's copy by path first makes both resolve to
+    it, in either import order.  Without torch installed the system runtime is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+
+
 class MiraError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"libmira_gpu error {code}: {msg}")
@@ -38,12 +56,14 @@ class MiraError(RuntimeError):
 class MiraLib:
     """One loaded copy of the C ABI."""
 
-    def __init__(self, path):
+    def __init__(self, path, preload_hip=False):
         if not os.path.exists(path):
             raise ImportError(
                 f"{path} not found: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()'); "
                 "mira_amd has no CPU fallback")
         self.path = path
+        if preload_hip:
+            _preload_hip_runtime()
         self.c = ctypes.CDLL(path)
         c = self.c
         vp, u64p, sz, u64, u32, i32 = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int32
@@ -107,5 +127,5 @@ def load():
     """The product library.  Raises ImportError when the HIP build is absent."""
     global _lib
     if _lib is None:
-        _lib = MiraLib(LIB_PATH)
+        _lib = MiraLib(LIB_PATH, preload_hip=True)
     return _lib

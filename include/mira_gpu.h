@@ -14,8 +14,8 @@
  *                    MIRA_CURVE_GRUMPKIN (y^2 = x^3 - 17 over Fr, scalars Fq)
  *
  * Ownership: the caller owns every buffer; the library borrows it for the duration of a call.
- * Registered bases are copied to (or, for *_device, referenced on) the GPU; the host copy is
- * never retained.  Errors: every function returns MIRA_OK (0) or a negative MIRA_E_* code and
+ * Registered bases are copied into a library-owned device buffer; the caller's copy is never
+ * retained.  Errors: every function returns MIRA_OK (0) or a negative MIRA_E_* code and
  * never throws or aborts across the ABI; mira_last_error() describes the last failure on the
  * calling thread.  Threading: all entry points are re-entrant (one process-wide lock).
  * There is no CPU fallback: without a usable gfx950 device every compute call fails with
@@ -59,7 +59,8 @@ const char *mira_last_error(void);
  * register = upload the key once (`CommitmentKey { ck: Box<[C]> }`, src/commitment.rs:26-29;
  * it is immutable and outlives every fold step, src/ivc/public_params.rs:50).               */
 int mira_msm_register_bases(int curve, const uint64_t *bases /* n * 8 limbs */, size_t n, uint64_t *handle_out);
-/* Same, for bases already resident in device memory (borrowed, not copied, not freed). */
+/* Same, for bases already in device memory.  Either way the library keeps its own resident copy
+ * in the engine's layout, so the caller's buffer is free again when the call returns. */
 int mira_msm_register_bases_device(int curve, const void *d_bases, size_t n, uint64_t *handle_out);
 int mira_msm_unregister(uint64_t handle);
 /* Validate every registered base against the curve equation on the GPU, as

@@ -18,7 +18,8 @@ static std::mutex g_lock;
 Ctx g;
 static std::map<uint64_t, Bases> g_bases;
 
-// constants block on device: [0] gen bn256 (64 B) [64] gen grumpkin (64 B) [128] b bn256 (32 B) [160] b grumpkin (32 B)
+// constants block on device: [0] gen bn256 (64 B, R form) [64] gen grumpkin (64 B, R form)
+// [128] b bn256 (32 B, R' form) [160] b grumpkin (32 B, R' form)
 static int upload_consts();
 
 static int ensure_ctx() {
@@ -91,8 +92,9 @@ static int upload_consts() {
     hostf::HFe<FrP> hy_plain = {{0x833fc48d823f272cULL, 0x2d270d45f1181294ULL, 0xcf135e7506a45d63ULL, 0x2ULL}};
     auto hy = hostf::to_mont(hy_plain);
     memcpy(blk + 8, hx.l, 32); memcpy(blk + 12, hy.l, 32);
-    auto b0 = small_const<FqP>(3);
-    auto b1 = small_const<FrP>(-17);
+    // curve constants in the resident R' = 2^261 form: b * 2^261 = (32 b) * 2^256
+    auto b0 = small_const<FqP>(3 * 32);
+    auto b1 = small_const<FrP>(-17 * 32);
     memcpy(blk + 16, b0.l, 32); memcpy(blk + 20, b1.l, 32);
     int rc = g.consts.ensure(sizeof blk);
     if (rc) return rc;
@@ -247,30 +249,35 @@ int mira_set_stream(void *hip_stream) {
 }
 const char *mira_last_error(void) { return g_err.c_str(); }
 
-int mira_msm_register_bases(int curve, const uint64_t *bases, size_t n, uint64_t *handle_out) {
-    std::lock_guard<std::mutex> lk(g_lock);
+// Both register calls leave a library-owned resident copy of the key in the engine's layout
+// (canonical x * 2^261, y * 2^261; k_convert_bases), so the caller's buffer -- host or device --
+// is free again when the call returns.
+static int register_common(int curve, const void *src, bool src_on_device, size_t n, uint64_t *handle_out) {
     int rc = ensure_ctx();
     if (rc) return rc;
-    if ((curve != MIRA_CURVE_BN256 && curve != MIRA_CURVE_GRUMPKIN) || !handle_out || (n && !bases)) { set_error("bad register arguments"); return MIRA_E_BAD_ARG; }
+    if ((curve != MIRA_CURVE_BN256 && curve != MIRA_CURVE_GRUMPKIN) || !handle_out || (n && !src)) { set_error("bad register arguments"); return MIRA_E_BAD_ARG; }
     Bases b; b.curve = curve; b.n = n; b.owned = true;
     if (rt_malloc(&b.d, std::max<size_t>(64, n * 64)) != hipSuccess || !b.d) { set_error("device allocation for bases failed"); return MIRA_E_ALLOC; }
     if (n) {
-        RT_CHECK(rt_h2d(b.d, bases, n * 64, g.stream));
-        RT_CHECK(rt_sync(g.stream));
+        const void *conv_src = src;
+        if (!src_on_device) {
+            RT_CHECK(rt_h2d(b.d, src, n * 64, g.stream));
+            conv_src = b.d;   // convert in place
+        }
+        rc = curve == MIRA_CURVE_BN256 ? convert_bases_bn256(conv_src, b.d, n) : convert_bases_grumpkin(conv_src, b.d, n);
+        if (rc) { (void)rt_free(b.d); return rc; }
     }
     *handle_out = g.next_handle++;
     g_bases[*handle_out] = b;
     return MIRA_OK;
 }
+int mira_msm_register_bases(int curve, const uint64_t *bases, size_t n, uint64_t *handle_out) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    return register_common(curve, bases, false, n, handle_out);
+}
 int mira_msm_register_bases_device(int curve, const void *d_bases, size_t n, uint64_t *handle_out) {
     std::lock_guard<std::mutex> lk(g_lock);
-    int rc = ensure_ctx();
-    if (rc) return rc;
-    if ((curve != MIRA_CURVE_BN256 && curve != MIRA_CURVE_GRUMPKIN) || !handle_out || (n && !d_bases)) { set_error("bad register arguments"); return MIRA_E_BAD_ARG; }
-    Bases b; b.curve = curve; b.n = n; b.owned = false; b.d = const_cast<void *>(d_bases);
-    *handle_out = g.next_handle++;
-    g_bases[*handle_out] = b;
-    return MIRA_OK;
+    return register_common(curve, d_bases, true, n, handle_out);
 }
 int mira_msm_unregister(uint64_t handle) {
     std::lock_guard<std::mutex> lk(g_lock);

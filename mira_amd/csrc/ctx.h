@@ -108,6 +108,8 @@ struct MsmPlan {
 int msm_launch_bn256(const Bases &bs, size_t first, const void *d_scalars, size_t n, const MsmPlan &p, uint64_t *host_windows);
 int msm_launch_grumpkin(const Bases &bs, size_t first, const void *d_scalars, size_t n, const MsmPlan &p, uint64_t *host_windows);
 int curve_init_bn256();
+int convert_bases_bn256(const void *d_src, void *d_dst, size_t n);
+int convert_bases_grumpkin(const void *d_src, void *d_dst, size_t n);
 int curve_init_grumpkin();
 int synth_scalars_bn256(size_t n, uint64_t index0, uint64_t seed, int kind, void *d_out);
 int synth_scalars_grumpkin(size_t n, uint64_t index0, uint64_t seed, int kind, void *d_out);

@@ -1,14 +1,15 @@
-// bn256: instantiates the MSM pipeline for this curve (base field FqP, scalar field FrP).
+// bn256: instantiates the MSM pipeline for this curve (coordinates Fq29 / FqP, scalars FrP).
 #include "msm_host.cuh"
 
 int msm_launch_bn256(const Bases &bs, size_t first, const void *d_scalars, size_t n, const MsmPlan &p, uint64_t *host_windows) {
-    return msm_launch<FqP, FrP>(bs, first, d_scalars, n, p, host_windows);
+    return msm_launch<Fq29, FrP>(bs, first, d_scalars, n, p, host_windows);
 }
-int curve_init_bn256() { return curve_init<FqP, FrP>(); }
+int curve_init_bn256() { return curve_init<Fq29, FrP>(); }
+int convert_bases_bn256(const void *d_src, void *d_dst, size_t n) { return convert_bases<Fq29>(d_src, d_dst, n); }
 int synth_scalars_bn256(size_t n, uint64_t index0, uint64_t seed, int kind, void *d_out) { return synth_scalars<FrP>(n, index0, seed, kind, d_out); }
 int synth_bases_bn256(size_t n, uint64_t index0, uint64_t seed, void *d_out) {
     return synth_bases<FqP>(n, index0, seed, reinterpret_cast<const unsigned char *>(g.consts.p) + 0, d_out);
 }
 int check_bases_bn256(const Bases &bs, uint32_t *d_bad) {
-    return check_bases<FqP>(bs, reinterpret_cast<const unsigned char *>(g.consts.p) + 128, d_bad);
+    return check_bases<Fq29>(bs, reinterpret_cast<const unsigned char *>(g.consts.p) + 128, d_bad);
 }

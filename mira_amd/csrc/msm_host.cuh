@@ -4,7 +4,7 @@
 #include "ctx.h"
 #include "msm_kernels.cuh"
 
-template <class FB, class FS>
+template <class F, class FS>
 static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size_t n, const MsmPlan &p,
                       uint64_t *host_windows /* W * 16 u64 */) {
     int rc;
@@ -18,13 +18,13 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size
     if ((rc = g.block_sums.ensure(1024 * 4))) return rc;
     if ((rc = g.sorted_idx.ensure(entries * 4 + 4))) return rc;
     if ((rc = g.sorted_key.ensure(entries * 4 + 4))) return rc;
-    if ((rc = g.bucket_sums.ensure((size_t)p.NB * 128))) return rc;
-    if ((rc = g.head_part.ensure((size_t)p.T * 128))) return rc;
-    if ((rc = g.tail_part.ensure((size_t)p.T * 128))) return rc;
+    if ((rc = g.bucket_sums.ensure((size_t)p.NB * XYZZ29_BYTES))) return rc;
+    if ((rc = g.head_part.ensure((size_t)p.T * XYZZ29_BYTES))) return rc;
+    if ((rc = g.tail_part.ensure((size_t)p.T * XYZZ29_BYTES))) return rc;
     if ((rc = g.head_key.ensure((size_t)p.T * 4))) return rc;
     if ((rc = g.tail_key.ensure((size_t)p.T * 4))) return rc;
     if ((rc = g.heavy.ensure(((size_t)p.T * 3 + 4) * 4))) return rc;
-    if ((rc = g.chunks.ensure((size_t)p.W * p.nchunks * 128))) return rc;
+    if ((rc = g.chunks.ensure((size_t)p.W * p.nchunks * XYZZ29_BYTES))) return rc;
     if ((rc = g.window_sums.ensure((size_t)p.W * 128))) return rc;
 
     hipStream_t st = g.stream;
@@ -34,7 +34,7 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size
 
     tm_begin();
     RT_CHECK(rt_memset(g.counts.p, 0, ((size_t)p.NB + 1) * 4, st));
-    RT_CHECK(rt_memset(g.bucket_sums.p, 0, (size_t)p.NB * 128, st));
+    RT_CHECK(rt_memset(g.bucket_sums.p, 0, (size_t)p.NB * XYZZ29_BYTES, st));
     RT_CHECK(rt_memset(g.head_key.p, 0xFF, (size_t)p.T * 4, st));
     RT_CHECK(rt_memset(g.tail_key.p, 0xFF, (size_t)p.T * 4, st));
     RT_CHECK(rt_memset(heavy_count, 0, 16, st));
@@ -58,23 +58,23 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size
                    reinterpret_cast<uint32_t *>(g.sorted_key.p));
     tm_mark("scatter");
     const uint32_t *total_ptr = reinterpret_cast<const uint32_t *>(g.offsets.p) + p.NB;
-    LAUNCH(k_accumulate<FB>, ceil_div(p.T, 128), 128, 0, st, reinterpret_cast<const uint32_t *>(g.sorted_idx.p),
+    LAUNCH(k_accumulate<F>, ceil_div(p.T, 128), 128, 0, st, reinterpret_cast<const uint32_t *>(g.sorted_idx.p),
            reinterpret_cast<const uint32_t *>(g.sorted_key.p), total_ptr, bases, p.L,
            reinterpret_cast<unsigned char *>(g.bucket_sums.p), reinterpret_cast<unsigned char *>(g.head_part.p),
            reinterpret_cast<uint32_t *>(g.head_key.p), reinterpret_cast<unsigned char *>(g.tail_part.p),
            reinterpret_cast<uint32_t *>(g.tail_key.p));
     tm_mark("accumulate");
-    LAUNCH(k_fixup<FB>, ceil_div(p.T, 128), 128, 0, st, p.T, p.L, reinterpret_cast<const uint32_t *>(g.offsets.p),
+    LAUNCH(k_fixup<F>, ceil_div(p.T, 128), 128, 0, st, p.T, p.L, reinterpret_cast<const uint32_t *>(g.offsets.p),
            reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
            reinterpret_cast<const uint32_t *>(g.tail_key.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p), heavy_count, heavy_list);
-    LAUNCH_BARRIER(k_fixup_heavy<FB>, 256, FIXUP_BLOCK, 0, st, heavy_count, heavy_list,
+    LAUNCH_BARRIER(k_fixup_heavy<F>, 256, FIXUP_BLOCK, 0, st, heavy_count, heavy_list,
                    reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
                    reinterpret_cast<unsigned char *>(g.bucket_sums.p));
     tm_mark("fixup");
-    LAUNCH(k_reduce_chunks<FB>, ceil_div((uint64_t)p.W * p.nchunks, 64), 64, 0, st,
+    LAUNCH(k_reduce_chunks<F>, ceil_div((uint64_t)p.W * p.nchunks, 64), 64, 0, st,
            reinterpret_cast<const unsigned char *>(g.bucket_sums.p), p.B, p.m, p.W, reinterpret_cast<unsigned char *>(g.chunks.p));
     tm_mark("reduce_chunks");
-    LAUNCH_BARRIER(k_window_sum<FB>, p.W, FIXUP_BLOCK, 0, st, reinterpret_cast<const unsigned char *>(g.chunks.p), p.nchunks,
+    LAUNCH_BARRIER(k_window_sum<F>, p.W, FIXUP_BLOCK, 0, st, reinterpret_cast<const unsigned char *>(g.chunks.p), p.nchunks,
                    reinterpret_cast<unsigned char *>(g.window_sums.p));
     tm_mark("window_sum");
     RT_CHECK(rt_last());
@@ -85,7 +85,7 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size
 }
 
 
-template <class FB, class FS> static int curve_init() {
+template <class F, class FS> static int curve_init() {
 #ifndef MIRA_CPU_EMU
     // the LDS-staged histogram needs more than the 64 KiB default (128 KiB at c = 16)
     RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -105,8 +105,16 @@ template <class FB> static int synth_bases(size_t n, uint64_t index0, uint64_t s
     RT_CHECK(rt_sync(g.stream));
     return MIRA_OK;
 }
-template <class FB> static int check_bases(const Bases &bs, const unsigned char *d_b, uint32_t *d_bad) {
-    LAUNCH(k_check_on_curve<FB>, ceil_div(bs.n, 256), 256, 0, g.stream, (const unsigned char *)bs.d, (uint64_t)bs.n, d_b, d_bad);
+template <class F> static int check_bases(const Bases &bs, const unsigned char *d_b, uint32_t *d_bad) {
+    LAUNCH(k_check_on_curve<F>, ceil_div(bs.n, 256), 256, 0, g.stream, (const unsigned char *)bs.d, (uint64_t)bs.n, d_b, d_bad);
     RT_CHECK(rt_last());
+    return MIRA_OK;
+}
+template <class F> static int convert_bases(const void *d_src, void *d_dst, size_t n) {
+    if (!n) return MIRA_OK;
+    LAUNCH(k_convert_bases<F>, ceil_div(n, 256), 256, 0, g.stream, reinterpret_cast<const unsigned char *>(d_src),
+           reinterpret_cast<unsigned char *>(d_dst), (uint64_t)n);
+    RT_CHECK(rt_last());
+    RT_CHECK(rt_sync(g.stream));
     return MIRA_OK;
 }

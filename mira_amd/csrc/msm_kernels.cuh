@@ -8,7 +8,7 @@
 //   k_scan_*      exclusive scan of the W * 2^(c-1) counters
 //   k_scatter     same tiling; the workgroup claims a contiguous range per bucket (one global
 //                 atomic per non-empty LDS bin) and places (point index | sign) and bucket key
-//   k_accumulate  every lane owns exactly L consecutive sorted entries (perfect balance however
+//   k_accumulate  (9 x 29-bit limb field, curve29.cuh) every lane owns exactly L consecutive sorted entries (perfect balance however
 //                 skewed the scalars are); complete bucket runs go straight to bucket_sums, runs
 //                 cut by a lane boundary leave a head/tail partial
 //   k_fixup*      joins the partials: short chains by one lane, long chains (heavy buckets such as
@@ -17,6 +17,7 @@
 // Host: Horner over the W window sums and the single inversion of to_affine().
 #pragma once
 #include "curve.cuh"
+#include "curve29.cuh"
 
 static constexpr uint32_t KEY_NONE = 0xFFFFFFFFu;
 static constexpr int HEAVY_SPAN = 48;       // chains longer than this go to k_fixup_heavy
@@ -154,7 +155,40 @@ KERNEL void k_scatter(const int16_t *__restrict__ digits, uint32_t n, uint32_t B
 }
 
 // ------------------------------------------------------------------------------------------
-template <class FB>
+// Key registration: reference layout (x * 2^256, y * 2^256; src/commitment.rs:26-29) -> the
+// engine's resident layout: canonical saturated limbs of x * 2^261, y * 2^261 (field29.cuh).
+// In place when src == dst.
+template <class F>
+KERNEL void k_convert_bases(const unsigned char *__restrict__ src, unsigned char *__restrict__ dst, uint64_t n) {
+    using S = typename F::Sat;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fe<S> x = fe_load<S>(src + i * 64), y = fe_load<S>(src + i * 64 + 32);
+    if (!(fe_is_zero(x) && fe_is_zero(y))) {
+        x = reduce_once(f29_pack(f29_from_r256<F>(x)));
+        y = reduce_once(f29_pack(f29_from_r256<F>(y)));
+    }
+    fe_store(dst + i * 64, x);
+    fe_store(dst + i * 64 + 32, y);
+}
+
+// bad_count += 1 for every resident base off the curve y^2 = x^3 + b (b given as b * 2^261,
+// canonical saturated).  The reference validates a cached key this way (src/commitment.rs:145-154).
+template <class F>
+KERNEL void k_check_on_curve(const unsigned char *__restrict__ bases, uint64_t n, const unsigned char *__restrict__ b_r261,
+                             uint32_t *__restrict__ bad_count) {
+    using S = typename F::Sat;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Aff29<F> p = aff29_load<F>(bases + i * 64, false);
+    if (aff29_is_identity(p)) return;
+    Fe29<F> lhs = f29_sqr(p.y);
+    Fe29<F> rhs = f29_add(f29_mul(f29_sqr(p.x), p.x), f29_unpack_canonical<F>(fe_load<S>(b_r261)));
+    if (!f29_is_zero_mod_p<6>(f29_sub<4>(lhs, rhs))) atomicAdd(bad_count, 1u);
+}
+
+// ------------------------------------------------------------------------------------------
+template <class F>
 KERNEL void __launch_bounds__(128) k_accumulate(const uint32_t *__restrict__ sorted_idx, const uint32_t *__restrict__ sorted_key,
                          const uint32_t *__restrict__ total_ptr, const unsigned char *__restrict__ bases,
                          uint32_t L, unsigned char *__restrict__ bucket_sums,
@@ -169,29 +203,28 @@ KERNEL void __launch_bounds__(128) k_accumulate(const uint32_t *__restrict__ sor
     uint32_t cur = sorted_key[start];
     const bool cont_prev = start > 0 && sorted_key[start - 1] == cur;
     bool first = true;
-    Xyzz<FB> acc = xyzz_identity<FB>();
+    Xyzz29<F> acc = xyzz29_identity<F>();
     for (uint32_t j = start; j < end; j++) {
         uint32_t k = sorted_key[j];
         if (k != cur) {
-            if (first && cont_prev) { xyzz_store(head_part + (size_t)t * 128, acc); head_key[t] = cur; }
-            else xyzz_store(bucket_sums + (size_t)cur * 128, acc);
+            if (first && cont_prev) { xyzz29_store(head_part + (size_t)t * XYZZ29_BYTES, acc); head_key[t] = cur; }
+            else xyzz29_store(bucket_sums + (size_t)cur * XYZZ29_BYTES, acc);
             first = false;
-            acc = xyzz_identity<FB>();
+            acc = xyzz29_identity<F>();
             cur = k;
         }
         uint32_t e = sorted_idx[j];
-        Aff<FB> p = aff_load<FB>(bases + (size_t)(e & 0x7FFFFFFFu) * 64);
-        if (e >> 31) p.y = fe_neg(p.y);
-        xyzz_add_affine(acc, p);
+        Aff29<F> p = aff29_load<F>(bases + (size_t)(e & 0x7FFFFFFFu) * 64, (e >> 31) != 0);
+        xyzz29_add_affine(acc, p);
     }
     const bool cont_next = end < total && sorted_key[end] == cur;
-    if (first && cont_prev) { xyzz_store(head_part + (size_t)t * 128, acc); head_key[t] = cur; }
-    else if (cont_next) { xyzz_store(tail_part + (size_t)t * 128, acc); tail_key[t] = cur; }
-    else xyzz_store(bucket_sums + (size_t)cur * 128, acc);
+    if (first && cont_prev) { xyzz29_store(head_part + (size_t)t * XYZZ29_BYTES, acc); head_key[t] = cur; }
+    else if (cont_next) { xyzz29_store(tail_part + (size_t)t * XYZZ29_BYTES, acc); tail_key[t] = cur; }
+    else xyzz29_store(bucket_sums + (size_t)cur * XYZZ29_BYTES, acc);
 }
 
 // One lane per k_accumulate lane that owns the start of a cut run.
-template <class FB>
+template <class F>
 KERNEL void __launch_bounds__(128) k_fixup(uint32_t T, uint32_t L, const uint32_t *__restrict__ offsets,
                     const unsigned char *__restrict__ head_part, const unsigned char *__restrict__ tail_part,
                     const uint32_t *__restrict__ tail_key, unsigned char *__restrict__ bucket_sums,
@@ -207,35 +240,35 @@ KERNEL void __launch_bounds__(128) k_fixup(uint32_t T, uint32_t L, const uint32_
         heavy_list[3 * h] = t; heavy_list[3 * h + 1] = span; heavy_list[3 * h + 2] = key;
         return;
     }
-    Xyzz<FB> acc = xyzz_load<FB>(tail_part + (size_t)t * 128);
-    for (uint32_t q = 1; q <= span; q++) xyzz_add(acc, xyzz_load<FB>(head_part + (size_t)(t + q) * 128));
-    xyzz_store(bucket_sums + (size_t)key * 128, acc);
+    Xyzz29<F> acc = xyzz29_load<F>(tail_part + (size_t)t * XYZZ29_BYTES);
+    for (uint32_t q = 1; q <= span; q++) xyzz29_add(acc, xyzz29_load<F>(head_part + (size_t)(t + q) * XYZZ29_BYTES));
+    xyzz29_store(bucket_sums + (size_t)key * XYZZ29_BYTES, acc);
 }
 
 // Workgroup per heavy run (grid-stride over the list).  blockDim.x == FIXUP_BLOCK.
-template <class FB>
+template <class F>
 KERNEL void __launch_bounds__(256) k_fixup_heavy(const uint32_t *__restrict__ heavy_count, const uint32_t *__restrict__ heavy_list,
                           const unsigned char *__restrict__ head_part, const unsigned char *__restrict__ tail_part,
                           unsigned char *__restrict__ bucket_sums) {
-    __shared__ __attribute__((aligned(16))) unsigned char red[FIXUP_BLOCK * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char red[FIXUP_BLOCK * XYZZ29_BYTES];
     const uint32_t nheavy = *heavy_count;
     for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
         const uint32_t t = heavy_list[3 * h], span = heavy_list[3 * h + 1], key = heavy_list[3 * h + 2];
-        Xyzz<FB> acc = xyzz_identity<FB>();
+        Xyzz29<F> acc = xyzz29_identity<F>();
         for (uint32_t q = threadIdx.x; q < span; q += blockDim.x)
-            xyzz_add(acc, xyzz_load<FB>(head_part + (size_t)(t + 1 + q) * 128));
-        xyzz_store(red + threadIdx.x * 128, acc);
+            xyzz29_add(acc, xyzz29_load<F>(head_part + (size_t)(t + 1 + q) * XYZZ29_BYTES));
+        xyzz29_store(red + threadIdx.x * XYZZ29_BYTES, acc);
         __syncthreads();
         for (uint32_t st = FIXUP_BLOCK / 2; st > 0; st >>= 1) {
             if (threadIdx.x < st) {
-                xyzz_add(acc, xyzz_load<FB>(red + (threadIdx.x + st) * 128));
-                xyzz_store(red + threadIdx.x * 128, acc);
+                xyzz29_add(acc, xyzz29_load<F>(red + (threadIdx.x + st) * XYZZ29_BYTES));
+                xyzz29_store(red + threadIdx.x * XYZZ29_BYTES, acc);
             }
             __syncthreads();
         }
         if (threadIdx.x == 0) {
-            xyzz_add(acc, xyzz_load<FB>(tail_part + (size_t)t * 128));
-            xyzz_store(bucket_sums + (size_t)key * 128, acc);
+            xyzz29_add(acc, xyzz29_load<F>(tail_part + (size_t)t * XYZZ29_BYTES));
+            xyzz29_store(bucket_sums + (size_t)key * XYZZ29_BYTES, acc);
         }
         __syncthreads();
     }
@@ -244,50 +277,51 @@ KERNEL void __launch_bounds__(256) k_fixup_heavy(const uint32_t *__restrict__ he
 // ------------------------------------------------------------------------------------------
 // Lane (w, j) folds buckets [j*m, (j+1)*m) of window w:
 //   R[w][j] = sum_i (j*m + i + 1) * S[w][j*m + i]
-template <class FB>
+template <class F>
 KERNEL void __launch_bounds__(64) k_reduce_chunks(const unsigned char *__restrict__ bucket_sums, uint32_t B, uint32_t m, uint32_t W,
                             unsigned char *__restrict__ R) {
     const uint32_t nchunks = B / m;
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nchunks * W) return;
     const uint32_t w = g / nchunks, j = g % nchunks;
-    const unsigned char *S = bucket_sums + ((size_t)w * B + (size_t)j * m) * 128;
-    Xyzz<FB> running = xyzz_identity<FB>(), ws = xyzz_identity<FB>();
+    const unsigned char *S = bucket_sums + ((size_t)w * B + (size_t)j * m) * XYZZ29_BYTES;
+    Xyzz29<F> running = xyzz29_identity<F>(), ws = xyzz29_identity<F>();
     for (int i = (int)m - 1; i >= 0; i--) {
-        xyzz_add(running, xyzz_load<FB>(S + (size_t)i * 128));
-        xyzz_add(ws, running);
+        xyzz29_add(running, xyzz29_load<F>(S + (size_t)i * XYZZ29_BYTES));
+        xyzz29_add(ws, running);
     }
     // + (j*m) * running, MSB-first double-and-add on the (<= 15-bit) chunk offset
     const uint32_t k = j * m;
-    if (k != 0 && !xyzz_is_identity(running)) {
-        Xyzz<FB> acc = xyzz_identity<FB>();
+    if (k != 0 && !xyzz29_is_identity(running)) {
+        Xyzz29<F> acc = xyzz29_identity<F>();
         for (int bit = 31 - __builtin_clz(k); bit >= 0; bit--) {
-            acc = xyzz_double(acc);
-            if ((k >> bit) & 1) xyzz_add(acc, running);
+            acc = xyzz29_double(acc);
+            if ((k >> bit) & 1) xyzz29_add(acc, running);
         }
-        xyzz_add(ws, acc);
+        xyzz29_add(ws, acc);
     }
-    xyzz_store(R + (size_t)g * 128, ws);
+    xyzz29_store(R + (size_t)g * XYZZ29_BYTES, ws);
 }
 
-// Workgroup per window: window_sums[w] = sum_j R[w][j].  blockDim.x == FIXUP_BLOCK.
-template <class FB>
+// Workgroup per window: window_sums[w] = sum_j R[w][j], exported as X, Y, ZZ, ZZZ in the
+// reference's canonical R = 2^256 form (128 B) for the host epilogue.  blockDim.x == FIXUP_BLOCK.
+template <class F>
 KERNEL void __launch_bounds__(256) k_window_sum(const unsigned char *__restrict__ R, uint32_t nchunks, unsigned char *__restrict__ window_sums) {
-    __shared__ __attribute__((aligned(16))) unsigned char red[FIXUP_BLOCK * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char red[FIXUP_BLOCK * XYZZ29_BYTES];
     const uint32_t w = blockIdx.x;
-    Xyzz<FB> acc = xyzz_identity<FB>();
+    Xyzz29<F> acc = xyzz29_identity<F>();
     for (uint32_t q = threadIdx.x; q < nchunks; q += blockDim.x)
-        xyzz_add(acc, xyzz_load<FB>(R + ((size_t)w * nchunks + q) * 128));
-    xyzz_store(red + threadIdx.x * 128, acc);
+        xyzz29_add(acc, xyzz29_load<F>(R + ((size_t)w * nchunks + q) * XYZZ29_BYTES));
+    xyzz29_store(red + threadIdx.x * XYZZ29_BYTES, acc);
     __syncthreads();
     for (uint32_t st = FIXUP_BLOCK / 2; st > 0; st >>= 1) {
         if (threadIdx.x < st) {
-            xyzz_add(acc, xyzz_load<FB>(red + (threadIdx.x + st) * 128));
-            xyzz_store(red + threadIdx.x * 128, acc);
+            xyzz29_add(acc, xyzz29_load<F>(red + (threadIdx.x + st) * XYZZ29_BYTES));
+            xyzz29_store(red + threadIdx.x * XYZZ29_BYTES, acc);
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) xyzz_store(window_sums + (size_t)w * 128, acc);
+    if (threadIdx.x == 0) xyzz29_export_r256(window_sums + (size_t)w * 128, acc);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -345,18 +379,4 @@ KERNEL void __launch_bounds__(64) k_synth_bases(uint64_t n, uint64_t index0, uin
         if ((word >> (bit & 63)) & 1) xyzz_add_affine(acc, g);
     }
     aff_store(out + i * 64, xyzz_to_affine(acc));
-}
-
-// out[i] = 1 when bases[i] satisfies y^2 = x^3 + b (or is the identity); b in Montgomery form.
-// The reference validates a cached key this way (src/commitment.rs:145-154).
-template <class FB>
-KERNEL void k_check_on_curve(const unsigned char *__restrict__ bases, uint64_t n, const unsigned char *__restrict__ b_mont,
-                             uint32_t *__restrict__ bad_count) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Aff<FB> p = aff_load<FB>(bases + i * 64);
-    if (aff_is_identity(p)) return;
-    Fe<FB> lhs = fe_sqr(p.y);
-    Fe<FB> rhs = fe_add(fe_mul(fe_sqr(p.x), p.x), fe_load<FB>(b_mont));
-    if (!fe_eq(lhs, rhs)) atomicAdd(bad_count, 1u);
 }

@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "curve.cuh"
+#include "curve29.cuh"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
@@ -86,6 +87,27 @@ template <class FP> __global__ void __launch_bounds__(128) mb_madd(unsigned char
     xyzz_store(out + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * 128, acc);
 }
 
+template <class F> __global__ void mb_f29mul(unsigned char *out) {
+    Fe29<F> x = f29_one<F>(), y = f29_one<F>();
+    x.l[0] += threadIdx.x; y.l[1] += blockIdx.x;
+    for (int i = 0; i < FE_ITERS; i++) { x = f29_mul(x, y); y = f29_mul(y, x); }
+    f29_store_raw(out + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * 36, f29_add(x, y));
+}
+template <class F> __global__ void mb_f29sqr(unsigned char *out) {
+    Fe29<F> x = f29_one<F>(), y = f29_one<F>();
+    x.l[0] += threadIdx.x; y.l[1] += blockIdx.x;
+    for (int i = 0; i < FE_ITERS; i++) { x = f29_sqr(x); y = f29_sqr(y); }
+    f29_store_raw(out + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * 36, f29_add(x, y));
+}
+template <class F, int LB> __global__ void __launch_bounds__(128, LB) mb_madd29(unsigned char *out, const unsigned char *pts) {
+    Aff29<F> p = aff29_load<F>(pts + (threadIdx.x & 7) * 64, false);
+    Xyzz29<F> acc = xyzz29_identity<F>();
+    xyzz29_add_affine(acc, p);
+    p.x.l[1] += 7;
+    for (int i = 0; i < FE_ITERS; i++) { xyzz29_add_affine(acc, p); p.x.l[2] = (p.x.l[2] + 1) & M29; }
+    xyzz29_store(out + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * XYZZ29_BYTES, acc);
+}
+
 template <class F> float time_kernel(F launch, int reps = 5) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     launch();
@@ -134,6 +156,28 @@ int main() {
         double adds = (double)blocks * threads * FE_ITERS;
         t = time_kernel([&] { mb_madd<FqP><<<blocks, threads>>>((unsigned char *)buf); });
         printf("xyzz madd<Fq> %d waves/SIMD: %7.2f G add/s  (= %.2f G modmul-equiv/s at 10 per add)\n", wps, adds / t / 1e6, adds * 10 / t / 1e6);
+    }
+    CK(hipMemset(buf, 1, 4096));
+    for (int wps : {1, 2, 3, 4, 6, 8}) {
+        int blocks = CU * wps * 2, threads = 128;
+        double muls = (double)blocks * threads * FE_ITERS * 2;
+        float t = time_kernel([&] { mb_f29mul<Fq29><<<blocks, threads>>>((unsigned char *)buf + 4096); });
+        printf("f29_mul<Fq> %d waves/SIMD: %7.2f G modmul/s  (%.0f cyc per wave-modmul per SIMD)\n", wps, muls / t / 1e6, 2.4e9 * CU * 4 / (muls / 64 / (t / 1e3)));
+        t = time_kernel([&] { mb_f29sqr<Fq29><<<blocks, threads>>>((unsigned char *)buf + 4096); });
+        printf("f29_sqr<Fq> %d waves/SIMD: %7.2f G modsqr/s\n", wps, muls / t / 1e6);
+        double adds = (double)blocks * threads * FE_ITERS;
+        t = time_kernel([&] { mb_madd29<Fq29, 2><<<blocks, threads>>>((unsigned char *)buf + 4096, (const unsigned char *)buf); });
+        printf("xyzz29 madd<Fq> min2w %d waves/SIMD: %7.2f G add/s  (= %.2f G modmul-equiv/s at 10 per add)\n", wps, adds / t / 1e6, adds * 10 / t / 1e6);
+        t = time_kernel([&] { mb_madd29<Fq29, 3><<<blocks, threads>>>((unsigned char *)buf + 4096, (const unsigned char *)buf); });
+        printf("xyzz29 madd<Fq> min3w %d waves/SIMD: %7.2f G add/s\n", wps, adds / t / 1e6);
+        t = time_kernel([&] { mb_madd29<Fq29, 4><<<blocks, threads>>>((unsigned char *)buf + 4096, (const unsigned char *)buf); });
+        printf("xyzz29 madd<Fq> min4w %d waves/SIMD: %7.2f G add/s\n", wps, adds / t / 1e6);
+    }
+    {
+        float t = time_kernel([&] { mb_f29mul<Fq29><<<1, 64>>>((unsigned char *)buf + 4096); });
+        printf("single wave: %.3f us per dependent f29_mul\n", t * 1e3 / (FE_ITERS * 2));
+        t = time_kernel([&] { mb_madd29<Fq29, 2><<<1, 64>>>((unsigned char *)buf + 4096, (const unsigned char *)buf); });
+        printf("single wave: %.3f us per dependent xyzz29 madd\n", t * 1e3 / FE_ITERS);
     }
     // single-wave latency of one fe_mul chain
     {

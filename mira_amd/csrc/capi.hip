@@ -124,11 +124,12 @@ static MsmPlan make_plan(size_t n, int32_t forced_c) {
     p.tile = std::max<uint32_t>(1024, ceil_div(n, want_tiles));
     p.tile = (p.tile + 1023) / 1024 * 1024;
     p.ntiles = ceil_div(n, p.tile);
-    // accumulate: L consecutive sorted entries per lane, about 4 waves per SIMD when n allows
+    // accumulate: one segment of consecutive sorted entries per resident lane (k_plan fixes the
+    // segment length on the device from the number of non-zero digits); 142 VGPRs -> 3 waves/SIMD
     uint64_t entries = (uint64_t)n * p.W;
-    uint64_t L = (entries + 262143) / 262144;
-    p.L = (uint32_t)std::min<uint64_t>(512, std::max<uint64_t>(16, L));
-    p.T = ceil_div(entries, p.L);
+    p.lanes = 256u * 4u * 3u * 64u;
+    p.L = 16;                                                    // minimum segment length
+    p.T = (uint32_t)std::min<uint64_t>(p.lanes, ceil_div(entries, p.L));   // upper bound of segments
     p.m = std::min<uint32_t>(16, p.B);
     p.nchunks = p.B / p.m;
     return p;

@@ -98,10 +98,10 @@ void tm_end();
 
 static inline uint32_t ceil_div(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
-// window width c, W windows, B = 2^(c-1) buckets per window, histogram tiling, accumulate
-// segment length L over T lanes, reduction chunk m
+// window width c, W windows, B = 2^(c-1) buckets per window, histogram tiling; accumulate:
+// `lanes` resident lanes, minimum segment length L, at most T segments; reduction chunk m
 struct MsmPlan {
-    uint32_t c, W, B, NB, tile, ntiles, L, T, m, nchunks;
+    uint32_t c, W, B, NB, tile, ntiles, L, T, m, nchunks, lanes;
 };
 
 // per-curve translation units (msm_bn256.hip / msm_grumpkin.hip)

@@ -118,6 +118,17 @@ template <class F> HD Aff29<F> aff29_load(const void *p, bool negate) {
     if (negate && !f29_is_literal_zero(r.y)) r.y = f29_neg<2>(r.y);   // 2P - y < 2 P ... stays an exact negation mod P
     return r;
 }
+template <class F> HD Aff29<F> aff29_from_raw(const U4 &a, const U4 &b, const U4 &c, const U4 &d, bool negate) {
+    using S = typename F::Sat;
+    Fe<S> x, y;
+    x.l[0] = a.x; x.l[1] = a.y; x.l[2] = a.z; x.l[3] = a.w; x.l[4] = b.x; x.l[5] = b.y; x.l[6] = b.z; x.l[7] = b.w;
+    y.l[0] = c.x; y.l[1] = c.y; y.l[2] = c.z; y.l[3] = c.w; y.l[4] = d.x; y.l[5] = d.y; y.l[6] = d.z; y.l[7] = d.w;
+    Aff29<F> r;
+    r.x = f29_unpack_canonical<F>(x);
+    r.y = f29_unpack_canonical<F>(y);
+    if (negate && !f29_is_literal_zero(r.y)) r.y = f29_neg<2>(r.y);
+    return r;
+}
 // XYZZ partial sums: 4 x 9 raw loose limbs = 144 B
 template <class F> HD void f29_store_raw(void *p, const Fe29<F> &v) {
     uint32_t *q = reinterpret_cast<uint32_t *>(p);

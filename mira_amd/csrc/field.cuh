@@ -187,6 +187,9 @@ template <class FP> HD Fe<FP> fe_pow_u64(const Fe<FP> &a, uint64_t e) {
 struct alignas(16) U4 {
     uint32_t x, y, z, w;
 };
+struct alignas(8) U2 {
+    uint32_t x, y;
+};
 template <class FP> HD Fe<FP> fe_load(const void *p) {
     const U4 *q = reinterpret_cast<const U4 *>(p);
     U4 a = q[0], b = q[1];

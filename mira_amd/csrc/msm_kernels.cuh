@@ -125,8 +125,7 @@ KERNEL void k_scan_c(const uint32_t *__restrict__ counts, uint32_t NB, const uin
 // ------------------------------------------------------------------------------------------
 // grid = (ntiles, W), dynamic LDS = B * 4 bytes.  Same tiling as k_hist.
 KERNEL void k_scatter(const int16_t *__restrict__ digits, uint32_t n, uint32_t B, uint32_t tile,
-                      uint32_t *__restrict__ cursor, uint32_t *__restrict__ sorted_idx,
-                      uint32_t *__restrict__ sorted_key) {
+                      uint32_t *__restrict__ cursor, U2 *__restrict__ sorted) {
     DYN_SHARED(uint32_t, bins);
     const uint32_t w = blockIdx.y;
     for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) bins[b] = 0;
@@ -148,8 +147,7 @@ KERNEL void k_scatter(const int16_t *__restrict__ digits, uint32_t n, uint32_t B
         if (d != 0) {
             uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1;
             uint32_t pos = atomicAdd(&bins[b], 1u);
-            sorted_idx[pos] = i | (d < 0 ? 0x80000000u : 0u);
-            sorted_key[pos] = w * B + b;
+            sorted[pos] = U2{i | (d < 0 ? 0x80000000u : 0u), w * B + b};   // one 8-byte store per entry
         }
     }
 }
@@ -188,24 +186,50 @@ KERNEL void k_check_on_curve(const unsigned char *__restrict__ bases, uint64_t n
 }
 
 // ------------------------------------------------------------------------------------------
+// Segment length for k_accumulate, chosen on the device once the number of non-zero digits is
+// known: exactly one segment per resident lane (every SIMD slot busy for the whole kernel and all
+// lanes finishing together), never shorter than min_L.  plan = {L, T}.
+KERNEL void k_plan(const uint32_t *__restrict__ total_ptr, uint32_t resident_lanes, uint32_t min_L, uint32_t *__restrict__ plan) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const uint32_t total = *total_ptr;
+    uint32_t L = (uint32_t)(((uint64_t)total + resident_lanes - 1) / resident_lanes);
+    if (L < min_L) L = min_L;
+    plan[0] = L;
+    plan[1] = (uint32_t)(((uint64_t)total + L - 1) / L);
+}
+
 template <class F>
-KERNEL void __launch_bounds__(128) k_accumulate(const uint32_t *__restrict__ sorted_idx, const uint32_t *__restrict__ sorted_key,
+KERNEL void __launch_bounds__(128) k_accumulate(const U2 *__restrict__ sorted,
                          const uint32_t *__restrict__ total_ptr, const unsigned char *__restrict__ bases,
-                         uint32_t L, unsigned char *__restrict__ bucket_sums,
+                         const uint32_t *__restrict__ plan, unsigned char *__restrict__ bucket_sums,
                          unsigned char *__restrict__ head_part, uint32_t *__restrict__ head_key,
                          unsigned char *__restrict__ tail_part, uint32_t *__restrict__ tail_key) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total = *total_ptr;
+    const uint32_t L = plan[0];
     const uint64_t start64 = (uint64_t)t * L;
     if (start64 >= total) return;
     const uint32_t start = (uint32_t)start64;
     const uint32_t end = (total - start > L) ? start + L : total;
-    uint32_t cur = sorted_key[start];
-    const bool cont_prev = start > 0 && sorted_key[start - 1] == cur;
+    // two-deep software pipeline: the entry two ahead and the base one ahead are in flight while
+    // the current mixed add (about 9k issue cycles per wave) runs
+    U2 ent0 = sorted[start];
+    U2 ent1 = (start + 1 < end) ? sorted[start + 1] : ent0;
+    uint32_t cur = ent0.y;
+    const bool cont_prev = start > 0 && sorted[start - 1].y == cur;
     bool first = true;
     Xyzz29<F> acc = xyzz29_identity<F>();
+    const U4 *bp = reinterpret_cast<const U4 *>(bases + (size_t)(ent0.x & 0x7FFFFFFFu) * 64);
+    U4 r0 = bp[0], r1 = bp[1], r2 = bp[2], r3 = bp[3];
     for (uint32_t j = start; j < end; j++) {
-        uint32_t k = sorted_key[j];
+        const uint32_t k = ent0.y, e = ent0.x;
+        const U4 c0 = r0, c1 = r1, c2 = r2, c3 = r3;
+        if (j + 1 < end) {
+            bp = reinterpret_cast<const U4 *>(bases + (size_t)(ent1.x & 0x7FFFFFFFu) * 64);
+            r0 = bp[0]; r1 = bp[1]; r2 = bp[2]; r3 = bp[3];
+        }
+        ent0 = ent1;
+        if (j + 2 < end) ent1 = sorted[j + 2];
         if (k != cur) {
             if (first && cont_prev) { xyzz29_store(head_part + (size_t)t * XYZZ29_BYTES, acc); head_key[t] = cur; }
             else xyzz29_store(bucket_sums + (size_t)cur * XYZZ29_BYTES, acc);
@@ -213,11 +237,9 @@ KERNEL void __launch_bounds__(128) k_accumulate(const uint32_t *__restrict__ sor
             acc = xyzz29_identity<F>();
             cur = k;
         }
-        uint32_t e = sorted_idx[j];
-        Aff29<F> p = aff29_load<F>(bases + (size_t)(e & 0x7FFFFFFFu) * 64, (e >> 31) != 0);
-        xyzz29_add_affine(acc, p);
+        xyzz29_add_affine(acc, aff29_from_raw<F>(c0, c1, c2, c3, (e >> 31) != 0));
     }
-    const bool cont_next = end < total && sorted_key[end] == cur;
+    const bool cont_next = end < total && sorted[end].y == cur;
     if (first && cont_prev) { xyzz29_store(head_part + (size_t)t * XYZZ29_BYTES, acc); head_key[t] = cur; }
     else if (cont_next) { xyzz29_store(tail_part + (size_t)t * XYZZ29_BYTES, acc); tail_key[t] = cur; }
     else xyzz29_store(bucket_sums + (size_t)cur * XYZZ29_BYTES, acc);
@@ -225,11 +247,12 @@ KERNEL void __launch_bounds__(128) k_accumulate(const uint32_t *__restrict__ sor
 
 // One lane per k_accumulate lane that owns the start of a cut run.
 template <class F>
-KERNEL void __launch_bounds__(128) k_fixup(uint32_t T, uint32_t L, const uint32_t *__restrict__ offsets,
+KERNEL void __launch_bounds__(128) k_fixup(const uint32_t *__restrict__ plan, const uint32_t *__restrict__ offsets,
                     const unsigned char *__restrict__ head_part, const unsigned char *__restrict__ tail_part,
                     const uint32_t *__restrict__ tail_key, unsigned char *__restrict__ bucket_sums,
                     uint32_t *__restrict__ heavy_count, uint32_t *__restrict__ heavy_list) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t L = plan[0], T = plan[1];
     if (t >= T) return;
     const uint32_t key = tail_key[t];
     if (key == KEY_NONE) return;

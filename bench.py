@@ -38,6 +38,10 @@ def log(*a):
 
 
 def main():
+    # Libraries (RCCL prints its version banner) write to stdout; the contract is ONE JSON line
+    # there.  Keep the real stdout aside and point fd 1 at stderr for the duration of the run.
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -52,12 +56,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("MIRA_BENCH_FORCE_DIST"):      # FORCE_DIST: exercise the RCCL path with one rank
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     n_gpus = max(world, 1)
+    world = n_gpus
 
     from mira_amd import _lib
     from mira_amd import commitment as cm
@@ -69,7 +74,12 @@ def main():
     n = 1 << args.log_n
     index0 = rank * n
     t0 = time.time()
-    key = cm.CommitmentKey.synthetic(cid, n, index0=index0)
+    if dist is None:
+        key = cm.CommitmentKey.synthetic(cid, n)
+    else:
+        from mira_amd.dist import ShardedCommitmentKey
+        skey = ShardedCommitmentKey.synthetic(cid, n * world)        # rank r holds bases [r*n, (r+1)*n)
+        key = skey.key
     d_scalars = cm.synth_scalars_device(cid, n, index0=index0)
     log(f"[rank {rank}] inputs generated on GPU in {time.time() - t0:.1f}s (n = 2^{args.log_n} per GPU)")
 
@@ -83,14 +93,7 @@ def main():
     def step():
         if dist is None:
             return key.commit_device(d_scalars, n)
-        import torch
-        part, c, w = key.commit_partial_device(0, d_scalars, n)
-        mine = torch.from_numpy(part[: w * 16].view(np.int64)).cuda()
-        allp = torch.empty(world * w * 16, dtype=torch.int64, device="cuda")
-        dist.all_gather_into_tensor(allp, mine)
-        parts = np.zeros((world, _lib.MIRA_PARTIAL_U64), dtype=np.uint64)
-        parts[:, : w * 16] = allp.cpu().numpy().view(np.uint64).reshape(world, w * 16)
-        return cm.combine_partials(cid, parts, c, w)
+        return skey.commit_device(d_scalars, n * world)           # partial MSM + RCCL all-gather + combine
 
     for _ in range(args.warmup):
         result = step()
@@ -145,7 +148,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        real_stdout.write(json.dumps(out) + "\n")
+        real_stdout.flush()
 
 
 def load_traffic(log_n):

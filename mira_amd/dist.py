@@ -1,0 +1,74 @@
+"""Point-chunk sharding of one MSM across the GPUs of a node: one process per GPU
+(`torch.distributed`, backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests).
+
+The (scalar, base) pairs are cut into `world` contiguous chunks; rank g keeps the bases of chunk g
+resident on its GPU and reduces its chunk to W window sums.  The only exchange is one all-gather of
+W * 128 bytes per rank (elliptic-curve addition is not an RCCL reduction operator, so
+all-gather + local add is the "reduce"); every rank then holds the same affine commitment.
+Message size is <= 8 KiB per rank: latency-bound, xGMI bandwidth is irrelevant.
+"""
+import numpy as np
+
+from . import _lib
+from .commitment import CommitmentKey, TooLongInput, combine_partials
+
+
+def chunk_bounds(n, world, rank):
+    """Contiguous chunk [lo, hi) of rank `rank`; sizes differ by at most one."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class ShardedCommitmentKey:
+    """`CommitmentKey` whose bases are spread over the ranks of a process group.
+
+    `local_key` holds this rank's chunk [lo, hi) of a key of global length `total_len`.
+    `commit_device(d_scalars_local, n_global)` commits the first n_global scalars of the global
+    vector; this rank passes the device pointer of ITS part of that prefix."""
+
+    def __init__(self, curve, local_key, total_len, group=None, lib=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.curve = curve
+        self.key = local_key
+        self.total_len = total_len
+        self.lo, self.hi = chunk_bounds(total_len, self.world, self.rank)
+        self.lib = lib or local_key.lib
+        assert len(local_key) == self.hi - self.lo, "local key does not match this rank's chunk"
+
+    @classmethod
+    def synthetic(cls, curve, total_len, group=None, seed=0x42415345, lib=None):
+        import torch.distributed as dist
+        lo, hi = chunk_bounds(total_len, dist.get_world_size(group), dist.get_rank(group))
+        return cls(curve, CommitmentKey.synthetic(curve, hi - lo, seed=seed, index0=lo, lib=lib), total_len, group, lib)
+
+    def len(self):
+        return self.total_len
+
+    def local_prefix(self, n_global):
+        """How many of the first n_global pairs live on this rank."""
+        return max(0, min(self.hi, n_global) - self.lo)
+
+    def _all_gather(self, part_words):
+        import torch
+        backend = self.dist.get_backend(self.group)
+        dev = "cuda" if backend == "nccl" else "cpu"
+        mine = torch.from_numpy(part_words.view(np.int64)).to(dev)
+        out = torch.empty(self.world * mine.numel(), dtype=torch.int64, device=dev)
+        self.dist.all_gather_into_tensor(out, mine, group=self.group)
+        return out.cpu().numpy().view(np.uint64).reshape(self.world, -1)
+
+    def commit_device(self, d_scalars_local, n_global):
+        """src/commitment.rs:78-87 over the sharded key; every rank returns the same point."""
+        if n_global > self.total_len:
+            raise TooLongInput(n_global, self.total_len)
+        n_local = self.local_prefix(n_global)
+        part, c, w = self.key.commit_partial_device(0, d_scalars_local, n_local)
+        gathered = self._all_gather(np.ascontiguousarray(part[: w * 16]))
+        parts = np.zeros((self.world, _lib.MIRA_PARTIAL_U64), dtype=np.uint64)
+        parts[:, : w * 16] = gathered
+        return combine_partials(self.curve, parts, c, w, lib=self.lib)

@@ -6,6 +6,7 @@
 // ------------------------------------------------------------------------------------------
 // NTT host side
 using HFr = hostf::HFe<FrP>;
+static constexpr uint32_t NTT_PERSISTENT_GRID = 256;   // one 1024-lane workgroup per CU (144 KiB of LDS each)
 static HFr fr_root_of_unity(bool inverse) {
     // ROOT_OF_UNITY = 7^((r-1) >> 28); multiplicative generator 7, S = 28 (halo2curves bn256::Fr)
     uint64_t e[4];
@@ -35,23 +36,23 @@ static int ntt_prepare_tables(uint32_t log_n, const uint64_t omega[4], NttTables
     t.h = t.m1;   // exponent split for omega^(i2 * k1): low h bits / rest
     const size_t n_tw1 = t.m1 ? (size_t)1 << (t.m1 - 1) : 1, n_tw2 = t.m2 ? (size_t)1 << (t.m2 - 1) : 1;
     const size_t n_lo = (size_t)1 << t.h, n_hi = (size_t)1 << (log_n - t.h);
-    t.off_tw1 = 0; t.off_tw2 = t.off_tw1 + n_tw1 * 32; t.off_lo = t.off_tw2 + n_tw2 * 32; t.off_hi = t.off_lo + n_lo * 32;
+    t.off_tw1 = 0; t.off_tw2 = t.off_tw1 + n_tw1 * TW_BYTES; t.off_lo = t.off_tw2 + n_tw2 * TW_BYTES; t.off_hi = t.off_lo + n_lo * TW_BYTES;
     std::string key((const char *)omega, 32);
     key += std::to_string(log_n);
     if (key == g.ntt_tables_key) return MIRA_OK;
     int rc;
-    if ((rc = g.ntt_tables.ensure(t.off_hi + n_hi * 32))) return rc;
+    if ((rc = g.ntt_tables.ensure(t.off_hi + n_hi * TW_BYTES))) return rc;
     if ((rc = g.ntt_consts.ensure(256))) return rc;
     RT_CHECK(rt_h2d(g.ntt_consts.p, omega, 32, g.stream));
     unsigned char *tab = reinterpret_cast<unsigned char *>(g.ntt_tables.p);
     const unsigned char *w = reinterpret_cast<const unsigned char *>(g.ntt_consts.p);
     const unsigned char *none = nullptr;
     const uint64_t n = (uint64_t)1 << log_n;
-    LAUNCH(k_pow_table<FrP>, ceil_div(n_tw1, 256), 256, 0, g.stream, w, n >> t.m1, (uint32_t)n_tw1, none, tab + t.off_tw1);
+    LAUNCH(k_pow_table<Fr29>, ceil_div(n_tw1, 256), 256, 0, g.stream, w, n >> t.m1, (uint32_t)n_tw1, none, tab + t.off_tw1);
     if (t.m2) {
-        LAUNCH(k_pow_table<FrP>, ceil_div(n_tw2, 256), 256, 0, g.stream, w, n >> t.m2, (uint32_t)n_tw2, none, tab + t.off_tw2);
-        LAUNCH(k_pow_table<FrP>, ceil_div(n_lo, 256), 256, 0, g.stream, w, (uint64_t)1, (uint32_t)n_lo, none, tab + t.off_lo);
-        LAUNCH(k_pow_table<FrP>, ceil_div(n_hi, 256), 256, 0, g.stream, w, (uint64_t)1 << t.h, (uint32_t)n_hi, none, tab + t.off_hi);
+        LAUNCH(k_pow_table<Fr29>, ceil_div(n_tw2, 256), 256, 0, g.stream, w, n >> t.m2, (uint32_t)n_tw2, none, tab + t.off_tw2);
+        LAUNCH(k_pow_table<Fr29>, ceil_div(n_lo, 256), 256, 0, g.stream, w, (uint64_t)1, (uint32_t)n_lo, none, tab + t.off_lo);
+        LAUNCH(k_pow_table<Fr29>, ceil_div(n_hi, 256), 256, 0, g.stream, w, (uint64_t)1 << t.h, (uint32_t)n_hi, none, tab + t.off_hi);
     }
     RT_CHECK(rt_last());
     g.ntt_tables_key = key;
@@ -70,16 +71,30 @@ static int ntt_device_locked(void *d_a, uint32_t log_n, const uint64_t omega[4],
     tm_mark("twiddle_tables");
     const unsigned char *tab = reinterpret_cast<const unsigned char *>(g.ntt_tables.p);
     unsigned char *scale_d = nullptr;
-    if (scale) {
-        RT_CHECK(rt_h2d(reinterpret_cast<unsigned char *>(g.ntt_consts.p) + 64, scale, 32, g.stream));
+    uint32_t scale36[12] = {0};
+    {
+        // the last pass multiplies by the ifft scale, or by one: reference form (x * 2^256) ->
+        // multiplier-operand form (x * 2^261 = (32 x) * 2^256), 9 x 29-bit limbs
+        HFr s = hostf::one<FrP>();
+        if (scale) memcpy(s.l, scale, 32);
+        s = hostf::mul(s, hostf::from_u64<FrP>(32));
+        for (int i = 0; i < 9; i++) {
+            const int bit = 29 * i, w = bit / 64, sh = bit % 64;
+            uint64_t v = s.l[w] >> sh;
+            if (sh > 35 && w + 1 < 4) v |= s.l[w + 1] << (64 - sh);
+            scale36[i] = (uint32_t)(v & 0x1FFFFFFFu);
+        }
+        RT_CHECK(rt_h2d(reinterpret_cast<unsigned char *>(g.ntt_consts.p) + 64, scale36, 48, g.stream));
         scale_d = reinterpret_cast<unsigned char *>(g.ntt_consts.p) + 64;
     }
     unsigned char *a = reinterpret_cast<unsigned char *>(d_a);
     const unsigned char *cnull = nullptr;
+    const char *dbg_env = getenv("MIRA_NTT_DEBUG_SKIP");
+    const uint32_t dbg = dbg_env ? (uint32_t)atoi(dbg_env) : 0u;
     auto threads_for = [](uint32_t m) { return std::min<uint32_t>(1024, std::max<uint32_t>(64, (1u << m) / 2)); };
     if (t.m2 == 0) {
-        NttPass ps{t.m1, 1, 0, 1, 0, 1, 0xFFFFFFFFu, scale ? 1u : 0u};
-        LAUNCH_BARRIER_FLEX(k_ntt_lines<FrP>, 1, threads_for(t.m1), ((size_t)32 << t.m1), g.stream, (const unsigned char *)a, a, ps,
+        NttPass ps{t.m1, 1, 0, 1, 0, 1, 0xFFFFFFFFu, dbg};
+        LAUNCH_BARRIER(k_ntt_lines<Fr29>, 1, threads_for(t.m1), ((size_t)NTT_LDS_BYTES_PER_ELEM << t.m1), g.stream, (const unsigned char *)a, a, ps,
                        tab + t.off_tw1, cnull, cnull, (const unsigned char *)scale_d);
         tm_mark("ntt_single");
     } else {
@@ -87,13 +102,13 @@ static int ntt_device_locked(void *d_a, uint32_t log_n, const uint64_t omega[4],
         if ((rc = g.ntt_tmp.ensure(((size_t)32) << log_n))) return rc;
         unsigned char *tmp = reinterpret_cast<unsigned char *>(g.ntt_tmp.p);
         // pass 1: columns i2 of the n1 x n2 view; B[k1][i2] * omega^(i2 k1) -> tmp[i2 * n1 + k1]
-        NttPass p1{t.m1, (uint32_t)n2, 1, n2, n1, 1, t.h, 0u};
-        LAUNCH_BARRIER_FLEX(k_ntt_lines<FrP>, (uint32_t)n2, threads_for(t.m1), ((size_t)32 << t.m1), g.stream, (const unsigned char *)a, tmp, p1,
+        NttPass p1{t.m1, (uint32_t)n2, 1, n2, n1, 1, t.h, dbg};
+        LAUNCH_BARRIER(k_ntt_lines<Fr29>, std::min<uint32_t>((uint32_t)n2, NTT_PERSISTENT_GRID), threads_for(t.m1), ((size_t)NTT_LDS_BYTES_PER_ELEM << t.m1), g.stream, (const unsigned char *)a, tmp, p1,
                        tab + t.off_tw1, tab + t.off_lo, tab + t.off_hi, cnull);
         tm_mark("ntt_pass1");
         // pass 2: for each k1 the length-n2 transform over i2; X[k1 + n1 k2] -> a
-        NttPass p2{t.m2, (uint32_t)n1, 1, n1, 1, n1, 0xFFFFFFFFu, scale ? 1u : 0u};
-        LAUNCH_BARRIER_FLEX(k_ntt_lines<FrP>, (uint32_t)n1, threads_for(t.m2), ((size_t)32 << t.m2), g.stream, (const unsigned char *)tmp, a, p2,
+        NttPass p2{t.m2, (uint32_t)n1, 1, n1, 1, n1, 0xFFFFFFFFu, dbg};
+        LAUNCH_BARRIER(k_ntt_lines<Fr29>, std::min<uint32_t>((uint32_t)n1, NTT_PERSISTENT_GRID), threads_for(t.m2), ((size_t)NTT_LDS_BYTES_PER_ELEM << t.m2), g.stream, (const unsigned char *)tmp, a, p2,
                        tab + t.off_tw2, cnull, cnull, (const unsigned char *)scale_d);
         tm_mark("ntt_pass2");
     }
@@ -115,7 +130,7 @@ static int distribute_powers_locked(void *d_a, uint32_t log_n, bool into_coset) 
     unsigned char *d_pw = reinterpret_cast<unsigned char *>(g.ntt_consts.p) + 128;
     RT_CHECK(rt_h2d(d_pw, pw, 64, g.stream));
     const uint64_t n = (uint64_t)1 << log_n;
-    LAUNCH(k_distribute_powers<FrP>, ceil_div(n, 256), 256, 0, g.stream, reinterpret_cast<unsigned char *>(d_a), n, (const unsigned char *)d_pw);
+    LAUNCH(k_distribute_powers<Fr29>, ceil_div(n, 256), 256, 0, g.stream, reinterpret_cast<unsigned char *>(d_a), n, (const unsigned char *)d_pw);
     RT_CHECK(rt_last());
     RT_CHECK(rt_sync(g.stream));
     return MIRA_OK;
@@ -143,7 +158,7 @@ int ntt_kind_device(void *d_a, uint32_t log_n, NttKind kind, const uint64_t *ome
 int ntt_init() {
 #ifndef MIRA_CPU_EMU
     // a 4096-point line is 128 KiB of LDS, above the 64 KiB default
-    RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_lines<FrP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_lines<Fr29>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #endif
     return MIRA_OK;
 }

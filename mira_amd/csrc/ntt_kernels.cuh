@@ -8,19 +8,43 @@
 // instead of log2(n).  The field results are canonical, so every element is bit-identical to
 // the reference's whatever order the butterflies run in.
 #pragma once
-#include "field.cuh"
+#include "field29.cuh"
 
-static constexpr int NTT_MAX_LOG_LINE = 12;   // 4096 elements * 32 B = 128 KiB of the 160 KiB LDS
+static constexpr int NTT_MAX_LOG_LINE = 12;   // 4096 elements * 36 B = 144 KiB of the 160 KiB LDS
 
-// table[j] = base^(j * stride), j < count   (base, table entries in Montgomery form)
-template <class FP>
+// 9 raw limbs (padded to 48 B) per table entry: canonical value in R' = 2^261 Montgomery form, ready to be a
+// multiplier operand.  Multiplying a reference-form element (x * 2^256) by such an entry with
+// f29_mul (which divides by 2^261) leaves the product in the reference form again.
+static constexpr int TW_BYTES = 48;   // 9 limbs padded to three 16-byte loads
+template <class F> HD void tw_store(unsigned char *p, const Fe29<F> &v) {
+    U4 *q = reinterpret_cast<U4 *>(p);
+    q[0] = U4{v.l[0], v.l[1], v.l[2], v.l[3]};
+    q[1] = U4{v.l[4], v.l[5], v.l[6], v.l[7]};
+    q[2] = U4{v.l[8], 0, 0, 0};
+}
+template <class F> HD Fe29<F> tw_load(const unsigned char *p) {
+    const U4 *q = reinterpret_cast<const U4 *>(p);
+    U4 a = q[0], b = q[1], c = q[2];
+    Fe29<F> r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w; r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w; r.l[8] = c.x;
+    F29_SET(r, 1.0);
+    return r;
+}
+// loose value < 2 P -> canonical saturated limbs of the same residue
+template <class F> HD Fe<typename F::Sat> f29_canonical(const Fe29<F> &v) {
+    F29_ASSERT(F29_GET(v) <= 2.0);
+    return reduce_once(f29_pack(v));
+}
+// table[j] = base^(j * stride) * scale, j < count   (base, scale in reference form; table in R' form)
+template <class F>
 KERNEL void k_pow_table(const unsigned char *__restrict__ base, uint64_t stride, uint32_t count,
                         const unsigned char *__restrict__ scale, unsigned char *__restrict__ table) {
+    using S = typename F::Sat;
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
-    Fe<FP> v = fe_pow_u64(fe_load<FP>(base), (uint64_t)j * stride);
-    if (scale) v = fe_mul(v, fe_load<FP>(scale));
-    fe_store(table + (size_t)j * 32, v);
+    Fe<S> v = fe_pow_u64(fe_load<S>(base), (uint64_t)j * stride);
+    if (scale) v = fe_mul(v, fe_load<S>(scale));
+    tw_store(table + (size_t)j * TW_BYTES, f29_unpack_canonical<F>(f29_canonical(f29_from_r256<F>(v))));
 }
 
 struct NttPass {
@@ -31,73 +55,119 @@ struct NttPass {
     uint64_t out_line_stride;
     uint64_t out_elem_stride;
     uint32_t tw_shift;         // post-twiddle omega^(l * k): T_hi[e >> tw_shift] * T_lo[e & mask]; 0xFFFFFFFF = none
-    uint32_t has_scale;        // multiply every output by *scale
+    uint32_t debug_skip;       // development only (MIRA_NTT_DEBUG_SKIP): 1 = skip butterfly layers, 2 = skip output multiply, 4 = skip LDS fill
 };
 
-// One workgroup per line.  blockDim.x = max(64, N/2) capped at 1024.  dynamic LDS = N * 32 B.
-template <class FP>
-KERNEL void k_ntt_lines(const unsigned char *__restrict__ src, unsigned char *__restrict__ dst, NttPass ps,
-                        const unsigned char *__restrict__ line_tw,   // omega_N^j, j < N/2
+// One workgroup per line.  blockDim.x = max(64, N/2) capped at 1024.  dynamic LDS = N * 36 B.
+//
+// Inside the line every value stays a loose 9 x 29-bit element (field29.cuh): a butterfly is one
+// multiplication (whose result is < 2 P whatever its input), one carry-free addition and one
+// biased subtraction; entering layer s all values are < (1 + 3 s) P, 37 P after 12 layers, well
+// inside the multiplier's input budget.  Values are made canonical once, when they leave the line
+// -- by the four-step twiddle product in pass 1, by the scale (ifft) or a multiplication by one
+// in the last pass.
+static constexpr int NTT_LDS_BYTES_PER_ELEM = 36;
+template <class F> struct NttLds {
+    U4 *p0, *p1;
+    uint32_t *p2;
+    DEV Fe29<F> load(uint32_t i, double bound) const {
+        U4 a = p0[i], b = p1[i];
+        Fe29<F> r;
+        r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w; r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w; r.l[8] = p2[i];
+        F29_SET(r, bound);
+        (void)bound;
+        return r;
+    }
+    DEV void store(uint32_t i, const Fe29<F> &v) const {
+        p0[i] = U4{v.l[0], v.l[1], v.l[2], v.l[3]};
+        p1[i] = U4{v.l[4], v.l[5], v.l[6], v.l[7]};
+        p2[i] = v.l[8];
+    }
+};
+
+template <class F>
+KERNEL void __launch_bounds__(1024) k_ntt_lines(const unsigned char *__restrict__ src, unsigned char *__restrict__ dst, NttPass ps,
+                        const unsigned char *__restrict__ line_tw,   // omega_N^j, j < N/2, TW_BYTES each
                         const unsigned char *__restrict__ t_lo, const unsigned char *__restrict__ t_hi,
-                        const unsigned char *__restrict__ scale) {
+                        const unsigned char *__restrict__ scale) {   // multiplier-form scale, or one, for the last pass
+    using S = typename F::Sat;
     DYN_SHARED(U4, lds);
     const uint32_t N = 1u << ps.log_len;
-    U4 *plane0 = lds, *plane1 = lds + N;
-    // XCD-aware line order: workgroups b and b+8 share an XCD (and its L2); give each XCD a
-    // contiguous range of lines so neighbouring strided lines (which share 128-B lines) meet in
-    // one L2.  Speed only; any mapping is correct.
-    uint32_t line = blockIdx.x;
-    if ((ps.nlines & 7u) == 0) line = (blockIdx.x & 7u) * (ps.nlines >> 3) + (blockIdx.x >> 3);
-
-    const unsigned char *in = src + (size_t)line * ps.in_line_stride * 32;
-    for (uint32_t q = threadIdx.x; q < N; q += blockDim.x) {
-        const U4 *g = reinterpret_cast<const U4 *>(in + (size_t)q * ps.in_elem_stride * 32);
-        uint32_t r = ps.log_len ? (__brev(q) >> (32 - ps.log_len)) : 0;
-        plane0[r] = g[0];
-        plane1[r] = g[1];
-    }
-    __syncthreads();
-    for (uint32_t s = 0; s < ps.log_len; s++) {
-        const uint32_t half = 1u << s;
-        for (uint32_t bf = threadIdx.x; bf < N / 2; bf += blockDim.x) {
-            const uint32_t j = bf & (half - 1);
-            const uint32_t i0 = ((bf >> s) << (s + 1)) + j, i1 = i0 + half;
-            U4 a0 = plane0[i0], a1 = plane1[i0], b0 = plane0[i1], b1 = plane1[i1];
-            Fe<FP> u, v;
-            u.l[0] = a0.x; u.l[1] = a0.y; u.l[2] = a0.z; u.l[3] = a0.w; u.l[4] = a1.x; u.l[5] = a1.y; u.l[6] = a1.z; u.l[7] = a1.w;
-            v.l[0] = b0.x; v.l[1] = b0.y; v.l[2] = b0.z; v.l[3] = b0.w; v.l[4] = b1.x; v.l[5] = b1.y; v.l[6] = b1.z; v.l[7] = b1.w;
-            if (s != 0) v = fe_mul(v, fe_load<FP>(line_tw + (size_t)(j << (ps.log_len - 1 - s)) * 32));
-            Fe<FP> hi = fe_add(u, v), lo = fe_sub(u, v);
-            plane0[i0] = U4{hi.l[0], hi.l[1], hi.l[2], hi.l[3]};
-            plane1[i0] = U4{hi.l[4], hi.l[5], hi.l[6], hi.l[7]};
-            plane0[i1] = U4{lo.l[0], lo.l[1], lo.l[2], lo.l[3]};
-            plane1[i1] = U4{lo.l[4], lo.l[5], lo.l[6], lo.l[7]};
+    NttLds<F> L{lds, lds + N, reinterpret_cast<uint32_t *>(lds + 2 * (size_t)N)};
+    const uint32_t lo_mask = ps.tw_shift == 0xFFFFFFFFu ? 0 : ((1u << ps.tw_shift) - 1u);
+    // Persistent workgroups: each walks lines blockIdx.x, blockIdx.x + gridDim.x, ...  The next
+    // line's elements are fetched into registers before the butterfly layers of the current line
+    // start, so the strided HBM gather is hidden behind ~100k cycles of arithmetic.
+    // XCD-aware order: workgroups b and b+8 share an XCD (and its L2); each XCD gets a contiguous
+    // range of lines so neighbouring strided lines (which share 128-B lines) meet in one L2.
+    // Speed only; any mapping is correct.
+    auto line_of = [&](uint32_t idx) {
+        return ((ps.nlines & 7u) == 0) ? (idx & 7u) * (ps.nlines >> 3) + (idx >> 3) : idx;
+    };
+    constexpr int PRE = 4;                               // N / blockDim.x <= 4 (4096 points, 1024 lanes)
+    Fe<S> pre[PRE];
+    auto fetch = [&](uint32_t idx) {
+        const unsigned char *in = src + (size_t)line_of(idx) * ps.in_line_stride * 32;
+#pragma unroll
+        for (int k = 0; k < PRE; k++) {
+            uint32_t q = threadIdx.x + k * blockDim.x;
+            if (q < N) pre[k] = fe_load<S>(in + (size_t)q * ps.in_elem_stride * 32);
+        }
+    };
+    uint32_t idx = blockIdx.x;
+    if (idx < ps.nlines) fetch(idx);
+    for (; idx < ps.nlines; idx += gridDim.x) {
+        const uint32_t line = line_of(idx);
+#pragma unroll
+        for (int k = 0; k < PRE; k++) {
+            uint32_t q = threadIdx.x + k * blockDim.x;
+            if (q < N) {
+                uint32_t r = ps.log_len ? (__brev(q) >> (32 - ps.log_len)) : 0;
+                L.store(r, f29_unpack_canonical<F>(pre[k]));
+            }
         }
         __syncthreads();
-    }
-    unsigned char *out = dst + (size_t)line * ps.out_line_stride * 32;
-    const uint32_t lo_mask = ps.tw_shift == 0xFFFFFFFFu ? 0 : ((1u << ps.tw_shift) - 1u);
-    for (uint32_t k = threadIdx.x; k < N; k += blockDim.x) {
-        U4 a0 = plane0[k], a1 = plane1[k];
-        Fe<FP> v;
-        v.l[0] = a0.x; v.l[1] = a0.y; v.l[2] = a0.z; v.l[3] = a0.w; v.l[4] = a1.x; v.l[5] = a1.y; v.l[6] = a1.z; v.l[7] = a1.w;
-        if (ps.tw_shift != 0xFFFFFFFFu) {
-            uint64_t e = (uint64_t)line * k;
-            Fe<FP> tw = fe_mul(fe_load<FP>(t_hi + (size_t)(e >> ps.tw_shift) * 32), fe_load<FP>(t_lo + (size_t)(e & lo_mask) * 32));
-            v = fe_mul(v, tw);
+        if (idx + gridDim.x < ps.nlines) fetch(idx + gridDim.x);
+        for (uint32_t s = 0; s < ((ps.debug_skip & 1u) ? 0u : ps.log_len); s++) {
+            const uint32_t half = 1u << s;
+            const double bound = 1.0 + 3.0 * s;
+            for (uint32_t bf = threadIdx.x; bf < N / 2; bf += blockDim.x) {
+                const uint32_t j = bf & (half - 1);
+                const uint32_t i0 = ((bf >> s) << (s + 1)) + j, i1 = i0 + half;
+                Fe29<F> u = L.load(i0, bound), v = L.load(i1, bound);
+                if (s != 0) v = f29_mul(v, tw_load<F>(line_tw + (size_t)(j << (ps.log_len - 1 - s)) * TW_BYTES));
+                L.store(i0, f29_add(u, v));
+                L.store(i1, f29_sub<3>(u, v));
+            }
+            __syncthreads();
         }
-        if (ps.has_scale) v = fe_mul(v, fe_load<FP>(scale));
-        fe_store(out + (size_t)k * ps.out_elem_stride * 32, v);
+        unsigned char *out = dst + (size_t)line * ps.out_line_stride * 32;
+        const double bound = 1.0 + 3.0 * ps.log_len;
+        for (uint32_t k = threadIdx.x; k < N; k += blockDim.x) {
+            Fe29<F> v = L.load(k, bound);
+            if (ps.debug_skip & 2u) {
+                v = f29_carry(v); F29_SET(v, 1.0);
+            } else if (ps.tw_shift != 0xFFFFFFFFu) {
+                uint64_t e = (uint64_t)line * k;
+                Fe29<F> tw = f29_mul(tw_load<F>(t_hi + (size_t)(e >> ps.tw_shift) * TW_BYTES), tw_load<F>(t_lo + (size_t)(e & lo_mask) * TW_BYTES));
+                v = f29_mul(v, tw);
+            } else {
+                v = f29_mul(v, tw_load<F>(scale));
+            }
+            fe_store(out + (size_t)k * ps.out_elem_stride * 32, f29_canonical(v));
+        }
+        __syncthreads();                                 // LDS is rewritten by the next line
     }
 }
 
 // a[i] *= powers[i % 3 - 1] for i % 3 != 0   (distribute_powers_zeta, reference src/fft.rs:205-226)
-template <class FP>
+template <class F>
 KERNEL void k_distribute_powers(unsigned char *__restrict__ a, uint64_t n, const unsigned char *__restrict__ powers2) {
+    using S = typename F::Sat;
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t r = (uint32_t)(i % 3);
     if (r == 0) return;
-    Fe<FP> v = fe_mul(fe_load<FP>(a + i * 32), fe_load<FP>(powers2 + (size_t)(r - 1) * 32));
+    Fe<S> v = fe_mul(fe_load<S>(a + i * 32), fe_load<S>(powers2 + (size_t)(r - 1) * 32));
     fe_store(a + i * 32, v);
 }

@@ -73,6 +73,14 @@ int mira_msm_check_bases(uint64_t handle);
 int mira_msm(uint64_t handle, const uint64_t *scalars /* n * 4 limbs */, size_t n, uint64_t out_affine[8]);
 int mira_msm_device(uint64_t handle, const void *d_scalars, size_t n, uint64_t out_affine[8]);
 
+/* `count` commitments over the same key in one submission -- the cross-term commits of one
+ * fold step (`cross_terms.iter().map(|v| ck.commit(v))`, src/nifs/vanilla/mod.rs:124-127) are
+ * count vectors of equal length n.  Each result is bit-identical to a separate mira_msm call.
+ * scalars[b] = host pointer of vector b; device form: vector b starts at element b * stride_elems.
+ * out_affine = count * 8 limbs. */
+int mira_msm_batch(uint64_t handle, const uint64_t *const *scalars, size_t n, size_t count, uint64_t *out_affine);
+int mira_msm_batch_device(uint64_t handle, const void *d_scalars, size_t n, size_t count, size_t stride_elems, uint64_t *out_affine);
+
 /* Point-chunk sharding across GPUs (one process per GPU): each rank runs mira_msm_partial on
  * its chunk, the ranks all-gather the MIRA_PARTIAL_U64 words, and every rank combines.
  * `first` = index of the chunk's first base inside the registered key.                       */

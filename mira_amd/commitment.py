@@ -100,6 +100,31 @@ class CommitmentKey:
         self.lib.check(self.lib.c.mira_msm_device(self.handle, ctypes.c_void_p(d_scalars), n, out.ctypes.data_as(ctypes.c_void_p)))
         return out
 
+    def commit_batch(self, vs):
+        """`vs.iter().map(|v| ck.commit(v))` for equal-length vectors (the cross-term commits of
+        src/nifs/vanilla/mod.rs:124-127) in one submission; returns (count, 8)."""
+        vs = [_as_u64(v, 4) for v in vs]
+        if not vs:
+            return np.zeros((0, 8), dtype=np.uint64)
+        n = len(vs[0])
+        if any(len(v) != n for v in vs):
+            raise ValueError("commit_batch needs vectors of equal length")
+        if n > self._len:
+            raise TooLongInput(n, self._len)
+        ptrs = (ctypes.c_void_p * len(vs))(*[v.ctypes.data for v in vs])
+        out = np.empty((len(vs), 8), dtype=np.uint64)
+        self.lib.check(self.lib.c.mira_msm_batch(self.handle, ptrs, n, len(vs), out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    def commit_batch_device(self, d_scalars, n, count, stride=None):
+        """Same with the vectors in HBM: vector b starts at element b * stride (default n)."""
+        if n > self._len:
+            raise TooLongInput(n, self._len)
+        out = np.empty((count, 8), dtype=np.uint64)
+        self.lib.check(self.lib.c.mira_msm_batch_device(self.handle, ctypes.c_void_p(d_scalars), n, count, n if stride is None else stride,
+                                                        out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
     def commit_partial_device(self, first, d_scalars, n):
         """Window sums of sum_i v[i] * ck[first + i]; combine with `combine_partials`."""
         if first + n > self._len:

@@ -106,7 +106,7 @@ static int upload_consts() {
 // ------------------------------------------------------------------------------------------
 // MSM plan
 
-static MsmPlan make_plan(size_t n, int32_t forced_c) {
+static MsmPlan make_plan(size_t n, int32_t forced_c, uint32_t count = 1, uint64_t stride = 0) {
     MsmPlan p;
     uint32_t best_c = 4;
     double best = 1e300;
@@ -118,17 +118,18 @@ static MsmPlan make_plan(size_t n, int32_t forced_c) {
     p.c = forced_c ? (uint32_t)forced_c : best_c;
     p.W = (256 + p.c - 1) / p.c;
     p.B = 1u << (p.c - 1);
-    p.NB = p.W * p.B;
+    p.count = count; p.stride = stride; p.Wt = p.W * count;
+    p.NB = p.Wt * p.B;
     // histogram / scatter tiling: about two workgroups per CU, at least 1024 points per tile
-    uint32_t want_tiles = std::max<uint32_t>(1, 512 / p.W);
+    uint32_t want_tiles = std::max<uint32_t>(1, 512 / p.Wt);
     p.tile = std::max<uint32_t>(1024, ceil_div(n, want_tiles));
     p.tile = (p.tile + 1023) / 1024 * 1024;
     p.ntiles = ceil_div(n, p.tile);
     // accumulate: one segment of consecutive sorted entries per resident lane (k_plan fixes the
     // segment length on the device from the number of non-zero digits); 142 VGPRs -> 3 waves/SIMD
-    uint64_t entries = (uint64_t)n * p.W;
+    uint64_t entries = (uint64_t)n * p.Wt;
     p.lanes = 256u * 4u * 3u * 64u;
-    p.L = 16;                                                    // minimum segment length
+    p.L = 16;   // minimum segment length (small MSMs: more, shorter segments beat fewer fix-up links)
     p.T = (uint32_t)std::min<uint64_t>(p.lanes, ceil_div(entries, p.L));   // upper bound of segments
     p.m = std::min<uint32_t>(16, p.B);
     p.nchunks = p.B / p.m;
@@ -193,6 +194,42 @@ static int combine_locked(int curve, const uint64_t *partials, size_t nparts, ui
     return MIRA_OK;
 }
 
+
+// count MSMs over the prefix of one key in a single pass of the pipeline (a batch is count * W
+// windows).  Chunked so that the window-counter scan and the 32-bit entry offsets stay in range.
+static int msm_batch_device_locked(uint64_t handle, const void *d_scalars, size_t n, size_t count, size_t stride, uint64_t *out_affine) {
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    auto it = g_bases.find(handle);
+    if (it == g_bases.end()) { set_error("unknown bases handle"); return MIRA_E_BAD_ARG; }
+    const Bases &bs = it->second;
+    if (!out_affine || (count && n && !d_scalars) || (count > 1 && stride < n)) { set_error("bad batch arguments"); return MIRA_E_BAD_ARG; }
+    if (n > bs.n) {
+        set_error("Can't commit too long input: input len: " + std::to_string(n) + ", but limit is " + std::to_string(bs.n));
+        return MIRA_E_TOO_LONG;
+    }
+    if (n == 0) { memset(out_affine, 0, count * 64); return MIRA_OK; }
+    MsmPlan p1 = make_plan(n, g.forced_c);
+    if (n >= (1ull << 31)) { set_error("n too large for 32-bit entry offsets"); return MIRA_E_UNSUPPORTED; }
+    // per launch: W_total * B counters <= 2^21 (three-launch scan) and n * W_total entries < 2^32
+    size_t per = std::max<size_t>(1, std::min<size_t>((size_t)((1ull << 21) / ((uint64_t)p1.W * p1.B)),
+                                                      (size_t)(((1ull << 32) - 1) / ((uint64_t)n * p1.W))));
+    std::vector<uint64_t> win;
+    for (size_t done = 0; done < count; done += per) {
+        const size_t cnt = std::min(per, count - done);
+        MsmPlan p = make_plan(n, g.forced_c, (uint32_t)cnt, stride);
+        win.assign((size_t)p.Wt * 16, 0);
+        const unsigned char *sc = reinterpret_cast<const unsigned char *>(d_scalars) + done * stride * 32;
+        rc = bs.curve == MIRA_CURVE_BN256 ? msm_launch_bn256(bs, 0, sc, n, p, win.data()) : msm_launch_grumpkin(bs, 0, sc, n, p, win.data());
+        if (rc) return rc;
+        for (size_t b = 0; b < cnt; b++) {
+            const uint64_t *w = win.data() + b * p.W * 16;
+            if (bs.curve == MIRA_CURVE_BN256) horner_affine<FqP>(w, p.c, p.W, out_affine + (done + b) * 8);
+            else horner_affine<FrP>(w, p.c, p.W, out_affine + (done + b) * 8);
+        }
+    }
+    return MIRA_OK;
+}
 
 static int ntt_kind_device_ctx(void *d_a, uint32_t log_n, NttKind kind, const uint64_t *omega_in) {
     int rc = ensure_ctx();
@@ -335,6 +372,30 @@ int mira_msm(uint64_t handle, const uint64_t *scalars, size_t n, uint64_t out_af
         RT_CHECK(rt_h2d(g.scalars_stage.p, scalars, n * 32, g.stream));
     }
     return msm_device_locked(handle, g.scalars_stage.p, n, out_affine);
+}
+int mira_msm_batch_device(uint64_t handle, const void *d_scalars, size_t n, size_t count, size_t stride_elems, uint64_t *out_affine) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    return msm_batch_device_locked(handle, d_scalars, n, count, stride_elems, out_affine);
+}
+int mira_msm_batch(uint64_t handle, const uint64_t *const *scalars, size_t n, size_t count, uint64_t *out_affine) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    if (count && n && !scalars) { set_error("null scalars"); return MIRA_E_BAD_ARG; }
+    auto it = g_bases.find(handle);
+    if (it == g_bases.end()) { set_error("unknown bases handle"); return MIRA_E_BAD_ARG; }
+    if (n > it->second.n) {
+        set_error("Can't commit too long input: input len: " + std::to_string(n) + ", but limit is " + std::to_string(it->second.n));
+        return MIRA_E_TOO_LONG;
+    }
+    if (n && count) {
+        if ((rc = g.scalars_stage.ensure(n * count * 32))) return rc;
+        for (size_t b = 0; b < count; b++) {
+            if (!scalars[b]) { set_error("null scalars"); return MIRA_E_BAD_ARG; }
+            RT_CHECK(rt_h2d(reinterpret_cast<unsigned char *>(g.scalars_stage.p) + b * n * 32, scalars[b], n * 32, g.stream));
+        }
+    }
+    return msm_batch_device_locked(handle, g.scalars_stage.p, n, count, n, out_affine);
 }
 int mira_msm_partial_device(uint64_t handle, size_t first, const void *d_scalars, size_t n, uint64_t out_partial[MIRA_PARTIAL_U64],
                             int32_t *window_bits, int32_t *num_windows) {

@@ -102,6 +102,8 @@ static inline uint32_t ceil_div(uint64_t a, uint64_t b) { return (uint32_t)((a +
 // `lanes` resident lanes, minimum segment length L, at most T segments; reduction chunk m
 struct MsmPlan {
     uint32_t c, W, B, NB, tile, ntiles, L, T, m, nchunks, lanes;
+    uint32_t count, Wt;   // MSMs in this submission, total windows count * W
+    uint64_t stride;      // scalars of MSM b start at element b * stride
 };
 
 // per-curve translation units (msm_bn256.hip / msm_grumpkin.hip)

@@ -6,9 +6,9 @@
 
 template <class F, class FS>
 static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size_t n, const MsmPlan &p,
-                      uint64_t *host_windows /* W * 16 u64 */) {
+                      uint64_t *host_windows /* count * W * 16 u64 */) {
     int rc;
-    const size_t entries = (size_t)n * p.W;
+    const size_t entries = (size_t)n * p.Wt;
     if ((rc = g.digits.ensure(entries * 2))) return rc;
     if ((rc = g.counts.ensure(((size_t)p.NB + 1) * 4))) return rc;
     if ((rc = g.offsets.ensure(((size_t)p.NB + 1) * 4))) return rc;
@@ -23,8 +23,8 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size
     if ((rc = g.head_key.ensure((size_t)p.T * 4))) return rc;
     if ((rc = g.tail_key.ensure((size_t)p.T * 4))) return rc;
     if ((rc = g.heavy.ensure(((size_t)p.T * 3 + 4) * 4))) return rc;
-    if ((rc = g.chunks.ensure((size_t)p.W * p.nchunks * XYZZ29_BYTES))) return rc;
-    if ((rc = g.window_sums.ensure((size_t)p.W * 128))) return rc;
+    if ((rc = g.chunks.ensure((size_t)p.Wt * p.nchunks * XYZZ29_BYTES))) return rc;
+    if ((rc = g.window_sums.ensure((size_t)p.Wt * 128))) return rc;
 
     hipStream_t st = g.stream;
     const unsigned char *bases = reinterpret_cast<const unsigned char *>(bs.d) + first * 64;
@@ -39,10 +39,10 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size
     RT_CHECK(rt_memset(heavy_count, 0, 16, st));
     tm_mark("memset");
 
-    LAUNCH(k_digits<FS>, ceil_div(n, 256), 256, 0, st, reinterpret_cast<const unsigned char *>(d_scalars), (uint32_t)n, p.c, p.W,
+    LAUNCH(k_digits<FS>, dim3(ceil_div(n, 256), p.count), 256, 0, st, reinterpret_cast<const unsigned char *>(d_scalars), (uint32_t)n, (uint64_t)p.stride, p.c, p.W,
            reinterpret_cast<int16_t *>(g.digits.p));
     tm_mark("digits");
-    LAUNCH_BARRIER_FLEX(k_hist, dim3(p.ntiles, p.W), 1024, (size_t)p.B * 4, st, reinterpret_cast<const int16_t *>(g.digits.p), (uint32_t)n,
+    LAUNCH_BARRIER_FLEX(k_hist, dim3(p.ntiles, p.Wt), 1024, (size_t)p.B * 4, st, reinterpret_cast<const int16_t *>(g.digits.p), (uint32_t)n,
                    p.B, p.tile, reinterpret_cast<uint32_t *>(g.counts.p));
     tm_mark("hist");
     LAUNCH_BARRIER(k_scan_a, scan_blocks, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.counts.p), p.NB,
@@ -52,7 +52,7 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size
                    reinterpret_cast<const uint32_t *>(g.block_sums.p), reinterpret_cast<uint32_t *>(g.offsets.p),
                    reinterpret_cast<uint32_t *>(g.cursor.p));
     tm_mark("scan");
-    LAUNCH_BARRIER_FLEX(k_scatter, dim3(p.ntiles, p.W), 1024, (size_t)p.B * 4, st, reinterpret_cast<const int16_t *>(g.digits.p),
+    LAUNCH_BARRIER_FLEX(k_scatter, dim3(p.ntiles, p.Wt), 1024, (size_t)p.B * 4, st, reinterpret_cast<const int16_t *>(g.digits.p),
                    (uint32_t)n, p.B, p.tile, reinterpret_cast<uint32_t *>(g.cursor.p), reinterpret_cast<U2 *>(g.sorted_idx.p));
     tm_mark("scatter");
     const uint32_t *total_ptr = reinterpret_cast<const uint32_t *>(g.offsets.p) + p.NB;
@@ -66,19 +66,20 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size
     tm_mark("accumulate");
     LAUNCH(k_fixup<F>, ceil_div(p.T, 128), 128, 0, st, (const uint32_t *)plan, reinterpret_cast<const uint32_t *>(g.offsets.p),
            reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
-           reinterpret_cast<const uint32_t *>(g.tail_key.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p), heavy_count, heavy_list);
+           reinterpret_cast<const uint32_t *>(g.tail_key.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p), heavy_count, heavy_list,
+           (uint32_t)(getenv("MIRA_FIXUP_DEBUG") ? atoi(getenv("MIRA_FIXUP_DEBUG")) : 0));
     LAUNCH_BARRIER(k_fixup_heavy<F>, 256, FIXUP_BLOCK, 0, st, heavy_count, heavy_list,
                    reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
                    reinterpret_cast<unsigned char *>(g.bucket_sums.p));
     tm_mark("fixup");
-    LAUNCH(k_reduce_chunks<F>, ceil_div((uint64_t)p.W * p.nchunks, 64), 64, 0, st,
-           reinterpret_cast<const unsigned char *>(g.bucket_sums.p), p.B, p.m, p.W, reinterpret_cast<unsigned char *>(g.chunks.p));
+    LAUNCH(k_reduce_chunks<F>, ceil_div((uint64_t)p.Wt * p.nchunks, 64), 64, 0, st,
+           reinterpret_cast<const unsigned char *>(g.bucket_sums.p), p.B, p.m, p.Wt, reinterpret_cast<unsigned char *>(g.chunks.p));
     tm_mark("reduce_chunks");
-    LAUNCH_BARRIER(k_window_sum<F>, p.W, FIXUP_BLOCK, 0, st, reinterpret_cast<const unsigned char *>(g.chunks.p), p.nchunks,
+    LAUNCH_BARRIER(k_window_sum<F>, p.Wt, FIXUP_BLOCK, 0, st, reinterpret_cast<const unsigned char *>(g.chunks.p), p.nchunks,
                    reinterpret_cast<unsigned char *>(g.window_sums.p));
     tm_mark("window_sum");
     RT_CHECK(rt_last());
-    RT_CHECK(rt_d2h(host_windows, g.window_sums.p, (size_t)p.W * 128, st));
+    RT_CHECK(rt_d2h(host_windows, g.window_sums.p, (size_t)p.Wt * 128, st));
     RT_CHECK(rt_sync(st));
     tm_end();
     return MIRA_OK;

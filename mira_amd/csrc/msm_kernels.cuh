@@ -20,15 +20,18 @@
 #include "curve29.cuh"
 
 static constexpr uint32_t KEY_NONE = 0xFFFFFFFFu;
-static constexpr int HEAVY_SPAN = 48;       // chains longer than this go to k_fixup_heavy
+static constexpr int HEAVY_SPAN = 6;        // chains longer than this go to k_fixup_heavy (a lane adds ~6.6 us per link)
 static constexpr int FIXUP_BLOCK = 256;
 
 // ------------------------------------------------------------------------------------------
 template <class FS>
-KERNEL void k_digits(const unsigned char *__restrict__ scalars, uint32_t n, uint32_t c, uint32_t W,
+KERNEL void k_digits(const unsigned char *__restrict__ scalars, uint32_t n, uint64_t stride, uint32_t c, uint32_t W,
                      int16_t *__restrict__ digits) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const uint32_t b = blockIdx.y;                       // MSM of the batch: its windows are b*W .. b*W + W-1
+    scalars += (size_t)b * stride * 32;
+    digits += (size_t)b * W * n;
     Fe<FS> s = fe_from_mont(fe_load<FS>(scalars + (size_t)i * 32));
     const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
     uint32_t carry = 0;
@@ -250,7 +253,7 @@ template <class F>
 KERNEL void __launch_bounds__(128) k_fixup(const uint32_t *__restrict__ plan, const uint32_t *__restrict__ offsets,
                     const unsigned char *__restrict__ head_part, const unsigned char *__restrict__ tail_part,
                     const uint32_t *__restrict__ tail_key, unsigned char *__restrict__ bucket_sums,
-                    uint32_t *__restrict__ heavy_count, uint32_t *__restrict__ heavy_list) {
+                    uint32_t *__restrict__ heavy_count, uint32_t *__restrict__ heavy_list, uint32_t dbg) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t L = plan[0], T = plan[1];
     if (t >= T) return;
@@ -264,8 +267,12 @@ KERNEL void __launch_bounds__(128) k_fixup(const uint32_t *__restrict__ plan, co
         return;
     }
     Xyzz29<F> acc = xyzz29_load<F>(tail_part + (size_t)t * XYZZ29_BYTES);
-    for (uint32_t q = 1; q <= span; q++) xyzz29_add(acc, xyzz29_load<F>(head_part + (size_t)(t + q) * XYZZ29_BYTES));
-    xyzz29_store(bucket_sums + (size_t)key * XYZZ29_BYTES, acc);
+    for (uint32_t q = 1; q <= span; q++) {
+        Xyzz29<F> hp = xyzz29_load<F>(head_part + (size_t)(t + q) * XYZZ29_BYTES);
+        if (dbg & 1u) { acc.x = f29_carry(f29_add(acc.x, hp.x)); F29_SET(acc.x, 9.0); }
+        else xyzz29_add(acc, hp);
+    }
+    if (!(dbg & 2u)) xyzz29_store(bucket_sums + (size_t)key * XYZZ29_BYTES, acc);
 }
 
 // Workgroup per heavy run (grid-stride over the list).  blockDim.x == FIXUP_BLOCK.

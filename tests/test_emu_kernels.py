@@ -96,3 +96,19 @@ def test_emu_omega(emu_lib):
     for k in (0, 3, 24, 28):
         for inv in (False, True):
             assert (F.get_omega_or_inv(k, inv, lib=emu_lib) == C.get_omega_or_inv(k, inv)).all()
+
+
+def test_emu_commit_batch(emu_lib):
+    """Batched cross-term commits (src/nifs/vanilla/mod.rs:124-127): each result equals its own commit."""
+    for cid in (0, 1):
+        n = 300
+        bs = C.synth_bases(cid, n + 20, seed=6)
+        key = cm.CommitmentKey(cid, bs, lib=emu_lib)
+        vs = [C.synth_scalars(cid, n, seed=20 + i, kind=i % 2) for i in range(4)]
+        got = key.commit_batch(vs)
+        for i, v in enumerate(vs):
+            assert (got[i] == C.commit(cid, bs, v)).all()
+            assert (got[i] == key.commit(v)).all()
+        assert key.commit_batch([]).shape == (0, 8)
+        with pytest.raises(cm.TooLongInput):
+            key.commit_batch([C.synth_scalars(cid, n + 21)])

@@ -152,3 +152,38 @@ def test_sharded_partials_equal_single(gpu_lib):
         assert (cm.combine_partials(cid, np.stack(parts), c, w) == whole).all()
     finally:
         gpu_lib.check(gpu_lib.c.mira_msm_set_window_bits(0))
+
+
+@pytest.mark.parametrize("cid,count", [(0, 6), (1, 5)])
+def test_commit_batch_fold_step_shape(gpu_lib, cid, count):
+    """The cross-term commits of one k = 17 fold step as one batched submission: every point equals
+    the oracle's and the one-at-a-time commit."""
+    n = 1 << 17
+    key = cm.CommitmentKey.synthetic(cid, n, seed=91)
+    bases = key.bases()
+    vs = [C.synth_scalars(cid, n, seed=100 + i) for i in range(count)]
+    got = key.commit_batch(vs)
+    for i, v in enumerate(vs):
+        assert (got[i] == C.commit(cid, bases, v)).all()
+    assert (got[0] == key.commit(vs[0])).all()
+    # device form with a stride larger than n
+    d = gpu_lib.alloc(count * (n + 64) * 32)
+    for i, v in enumerate(vs):
+        gpu_lib.upload(d + i * (n + 64) * 32, v)
+    assert (key.commit_batch_device(d, n, count, stride=n + 64) == got).all()
+    gpu_lib.free(d)
+
+
+def test_commit_batch_chunking(gpu_lib):
+    """More vectors than one launch takes at 16-bit windows (scan capacity): chunked internally."""
+    cid, n, count = 0, 1 << 14, 9
+    key = cm.CommitmentKey.synthetic(cid, n, seed=92)
+    bases = key.bases()
+    vs = [C.synth_scalars(cid, n, seed=200 + i, kind=i % 2) for i in range(count)]
+    gpu_lib.check(gpu_lib.c.mira_msm_set_window_bits(16))
+    try:
+        got = key.commit_batch(vs)
+    finally:
+        gpu_lib.check(gpu_lib.c.mira_msm_set_window_bits(0))
+    for i, v in enumerate(vs):
+        assert (got[i] == C.commit(cid, bases, v)).all()

@@ -108,6 +108,24 @@ template <class F, int LB> __global__ void __launch_bounds__(128, LB) mb_madd29(
     xyzz29_store(out + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * XYZZ29_BYTES, acc);
 }
 
+// one full XYZZ add per lane, executed `iters` times (iters = 1: the code runs once, cold)
+template <class F> __global__ void __launch_bounds__(128) mb_fulladd(unsigned char *buf, int iters) {
+    size_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    Xyzz29<F> a = xyzz29_load<F>(buf + (t % 4096) * XYZZ29_BYTES), b = xyzz29_load<F>(buf + ((t + 7) % 4096) * XYZZ29_BYTES);
+    for (int i = 0; i < iters; i++) xyzz29_add(a, b);
+    xyzz29_store(buf + (4096 + t) * XYZZ29_BYTES, a);
+}
+template <class F> __global__ void mb_init_points(unsigned char *buf, const unsigned char *pts) {
+    size_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    Aff29<F> p = aff29_load<F>(pts + (t & 7) * 64, false);
+    p.x.l[1] = (p.x.l[1] + (uint32_t)t * 977u) & M29;
+    Xyzz29<F> acc = xyzz29_identity<F>();
+    xyzz29_add_affine(acc, p);
+    p.x.l[2] = (p.x.l[2] + 5) & M29;
+    xyzz29_add_affine(acc, p);
+    xyzz29_store(buf + t * XYZZ29_BYTES, acc);
+}
+
 template <class F> float time_kernel(F launch, int reps = 5) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     launch();
@@ -178,6 +196,28 @@ int main() {
         printf("single wave: %.3f us per dependent f29_mul\n", t * 1e3 / (FE_ITERS * 2));
         t = time_kernel([&] { mb_madd29<Fq29, 2><<<1, 64>>>((unsigned char *)buf + 4096, (const unsigned char *)buf); });
         printf("single wave: %.3f us per dependent xyzz29 madd\n", t * 1e3 / FE_ITERS);
+    }
+    {
+        unsigned char *pb = (unsigned char *)buf + (1 << 20);
+        mb_init_points<Fq29><<<32, 128>>>(pb, (const unsigned char *)buf);
+        CK(hipDeviceSynchronize());
+        for (int waves : {1, 80, 640, 2560, 3072}) {
+            for (int iters : {1, 2, 8}) {
+                int blocks = (waves + 1) / 2;
+                hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+                float best = 1e9;
+                for (int rep = 0; rep < 3; rep++) {
+                    // a different kernel in between evicts the instruction cache, as in the real pipeline
+                    mb_f29mul<Fq29><<<CU * 8, 128>>>((unsigned char *)buf + 4096);
+                    hipEventRecord(e0);
+                    mb_fulladd<Fq29><<<blocks, 128>>>(pb, iters);
+                    hipEventRecord(e1); hipEventSynchronize(e1);
+                    float ms; hipEventElapsedTime(&ms, e0, e1);
+                    best = ms < best ? ms : best;
+                }
+                printf("full add x%d per lane, %4d waves: %8.1f us\n", iters, waves, best * 1e3);
+            }
+        }
     }
     // single-wave latency of one fe_mul chain
     {

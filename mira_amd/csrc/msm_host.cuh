@@ -16,7 +16,7 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size
     const uint32_t scan_blocks = ceil_div(p.NB, SCAN_TILE);
     if (scan_blocks > 1024) { set_error("window configuration exceeds the scan capacity"); return MIRA_E_UNSUPPORTED; }
     if ((rc = g.block_sums.ensure(1024 * 4))) return rc;
-    if ((rc = g.sorted_idx.ensure(entries * 8 + 8))) return rc;
+    if ((rc = g.sorted_idx.ensure(entries * 4 + 8))) return rc;
     if ((rc = g.bucket_sums.ensure((size_t)p.NB * XYZZ29_BYTES))) return rc;
     if ((rc = g.head_part.ensure((size_t)p.T * XYZZ29_BYTES))) return rc;
     if ((rc = g.tail_part.ensure((size_t)p.T * XYZZ29_BYTES))) return rc;
@@ -53,13 +53,13 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size
                    reinterpret_cast<uint32_t *>(g.cursor.p));
     tm_mark("scan");
     LAUNCH_BARRIER_FLEX(k_scatter, dim3(p.ntiles, p.Wt), 1024, (size_t)p.B * 4, st, reinterpret_cast<const int16_t *>(g.digits.p),
-                   (uint32_t)n, p.B, p.tile, reinterpret_cast<uint32_t *>(g.cursor.p), reinterpret_cast<U2 *>(g.sorted_idx.p));
+                   (uint32_t)n, p.B, p.tile, reinterpret_cast<uint32_t *>(g.cursor.p), reinterpret_cast<uint32_t *>(g.sorted_idx.p));
     tm_mark("scatter");
     const uint32_t *total_ptr = reinterpret_cast<const uint32_t *>(g.offsets.p) + p.NB;
     uint32_t *plan = heavy_count + 2;
     LAUNCH(k_plan, 1, 64, 0, st, total_ptr, p.lanes, p.L, plan);
-    LAUNCH(k_accumulate<F>, ceil_div(p.T, 128), 128, 0, st, reinterpret_cast<const U2 *>(g.sorted_idx.p),
-           total_ptr, bases, (const uint32_t *)plan,
+    LAUNCH(k_accumulate<F>, ceil_div(p.T, 128), 128, 0, st, reinterpret_cast<const uint32_t *>(g.sorted_idx.p),
+           reinterpret_cast<const uint32_t *>(g.offsets.p), p.NB, bases, (const uint32_t *)plan,
            reinterpret_cast<unsigned char *>(g.bucket_sums.p), reinterpret_cast<unsigned char *>(g.head_part.p),
            reinterpret_cast<uint32_t *>(g.head_key.p), reinterpret_cast<unsigned char *>(g.tail_part.p),
            reinterpret_cast<uint32_t *>(g.tail_key.p));

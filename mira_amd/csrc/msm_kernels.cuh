@@ -7,7 +7,10 @@
 //                 (2^(c-1) counters = 128 KiB at c = 16), flushed with coalesced atomics
 //   k_scan_*      exclusive scan of the W * 2^(c-1) counters
 //   k_scatter     same tiling; the workgroup claims a contiguous range per bucket (one global
-//                 atomic per non-empty LDS bin) and places (point index | sign) and bucket key
+//                 atomic per non-empty LDS bin) and places (point index | sign), 4 bytes per entry.
+//                 (A two-level coarse/fine sort was built and measured: 1.59 ms against 1.30 ms
+//                 for this single level at 2^22 -- it moves 3x the bytes and L2 write-combining
+//                 does not make up for it.)
 //   k_accumulate  (9 x 29-bit limb field, curve29.cuh) every lane owns exactly L consecutive sorted entries (perfect balance however
 //                 skewed the scalars are); complete bucket runs go straight to bucket_sums, runs
 //                 cut by a lane boundary leave a head/tail partial
@@ -128,7 +131,7 @@ KERNEL void k_scan_c(const uint32_t *__restrict__ counts, uint32_t NB, const uin
 // ------------------------------------------------------------------------------------------
 // grid = (ntiles, W), dynamic LDS = B * 4 bytes.  Same tiling as k_hist.
 KERNEL void k_scatter(const int16_t *__restrict__ digits, uint32_t n, uint32_t B, uint32_t tile,
-                      uint32_t *__restrict__ cursor, U2 *__restrict__ sorted) {
+                      uint32_t *__restrict__ cursor, uint32_t *__restrict__ sorted) {
     DYN_SHARED(uint32_t, bins);
     const uint32_t w = blockIdx.y;
     for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) bins[b] = 0;
@@ -150,7 +153,7 @@ KERNEL void k_scatter(const int16_t *__restrict__ digits, uint32_t n, uint32_t B
         if (d != 0) {
             uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1;
             uint32_t pos = atomicAdd(&bins[b], 1u);
-            sorted[pos] = U2{i | (d < 0 ? 0x80000000u : 0u), w * B + b};   // one 8-byte store per entry
+            sorted[pos] = i | (d < 0 ? 0x80000000u : 0u);   // 4 bytes per entry; the bucket is implied by the position
         }
     }
 }
@@ -201,48 +204,70 @@ KERNEL void k_plan(const uint32_t *__restrict__ total_ptr, uint32_t resident_lan
     plan[1] = (uint32_t)(((uint64_t)total + L - 1) / L);
 }
 
+// largest b in [lo, NB) with offsets[b] <= pos  (offsets non-decreasing, offsets[NB] = total > pos)
+DEV uint32_t bucket_of(const uint32_t *__restrict__ offsets, uint32_t lo, uint32_t NB, uint32_t pos) {
+    uint32_t hi = NB;           // invariant: offsets[lo] <= pos < offsets[hi]
+    while (hi - lo > 1) {
+        uint32_t mid = lo + ((hi - lo) >> 1);
+        if (offsets[mid] <= pos) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
 template <class F>
-KERNEL void __launch_bounds__(128) k_accumulate(const U2 *__restrict__ sorted,
-                         const uint32_t *__restrict__ total_ptr, const unsigned char *__restrict__ bases,
+KERNEL void __launch_bounds__(128) k_accumulate(const uint32_t *__restrict__ sorted, const uint32_t *__restrict__ offsets, uint32_t NB,
+                         const unsigned char *__restrict__ bases,
                          const uint32_t *__restrict__ plan, unsigned char *__restrict__ bucket_sums,
                          unsigned char *__restrict__ head_part, uint32_t *__restrict__ head_key,
                          unsigned char *__restrict__ tail_part, uint32_t *__restrict__ tail_key) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t total = *total_ptr;
+    const uint32_t total = offsets[NB];
     const uint32_t L = plan[0];
     const uint64_t start64 = (uint64_t)t * L;
     if (start64 >= total) return;
     const uint32_t start = (uint32_t)start64;
     const uint32_t end = (total - start > L) ? start + L : total;
-    // two-deep software pipeline: the entry two ahead and the base one ahead are in flight while
-    // the current mixed add (about 9k issue cycles per wave) runs
-    U2 ent0 = sorted[start];
-    U2 ent1 = (start + 1 < end) ? sorted[start + 1] : ent0;
-    uint32_t cur = ent0.y;
-    const bool cont_prev = start > 0 && sorted[start - 1].y == cur;
+    // The bucket of an entry is implied by its position: bucket b owns sorted[offsets[b] ..
+    // offsets[b+1]).  Find the bucket holding `start` once, then walk the boundaries; the boundary
+    // after next is always already loaded, so a run change costs no memory stall unless it skips
+    // empty buckets.
+    uint32_t cur = bucket_of(offsets, 0, NB, start);
+    uint32_t run_end = offsets[cur + 1];
+    uint32_t next_end = (cur + 2 <= NB) ? offsets[cur + 2] : total;
+    const bool cont_prev = offsets[cur] < start;
     bool first = true;
     Xyzz29<F> acc = xyzz29_identity<F>();
-    const U4 *bp = reinterpret_cast<const U4 *>(bases + (size_t)(ent0.x & 0x7FFFFFFFu) * 64);
+    // two-deep software pipeline: the entry two ahead and the base one ahead are in flight while
+    // the current mixed add (about 9k issue cycles per wave) runs
+    uint32_t ent0 = sorted[start];
+    uint32_t ent1 = (start + 1 < end) ? sorted[start + 1] : ent0;
+    const U4 *bp = reinterpret_cast<const U4 *>(bases + (size_t)(ent0 & 0x7FFFFFFFu) * 64);
     U4 r0 = bp[0], r1 = bp[1], r2 = bp[2], r3 = bp[3];
     for (uint32_t j = start; j < end; j++) {
-        const uint32_t k = ent0.y, e = ent0.x;
+        const uint32_t e = ent0;
         const U4 c0 = r0, c1 = r1, c2 = r2, c3 = r3;
         if (j + 1 < end) {
-            bp = reinterpret_cast<const U4 *>(bases + (size_t)(ent1.x & 0x7FFFFFFFu) * 64);
+            bp = reinterpret_cast<const U4 *>(bases + (size_t)(ent1 & 0x7FFFFFFFu) * 64);
             r0 = bp[0]; r1 = bp[1]; r2 = bp[2]; r3 = bp[3];
         }
         ent0 = ent1;
         if (j + 2 < end) ent1 = sorted[j + 2];
-        if (k != cur) {
+        if (j == run_end) {                                  // the run of `cur` is complete
             if (first && cont_prev) { xyzz29_store(head_part + (size_t)t * XYZZ29_BYTES, acc); head_key[t] = cur; }
             else xyzz29_store(bucket_sums + (size_t)cur * XYZZ29_BYTES, acc);
             first = false;
             acc = xyzz29_identity<F>();
-            cur = k;
+            cur++;
+            run_end = next_end;
+            if (run_end <= j) {                              // empty buckets in between: search
+                cur = bucket_of(offsets, cur, NB, j);
+                run_end = offsets[cur + 1];
+            }
+            next_end = (cur + 2 <= NB) ? offsets[cur + 2] : total;
         }
         xyzz29_add_affine(acc, aff29_from_raw<F>(c0, c1, c2, c3, (e >> 31) != 0));
     }
-    const bool cont_next = end < total && sorted[end].y == cur;
+    const bool cont_next = end < run_end;                    // the run continues in the next lane
     if (first && cont_prev) { xyzz29_store(head_part + (size_t)t * XYZZ29_BYTES, acc); head_key[t] = cur; }
     else if (cont_next) { xyzz29_store(tail_part + (size_t)t * XYZZ29_BYTES, acc); tail_key[t] = cur; }
     else xyzz29_store(bucket_sums + (size_t)cur * XYZZ29_BYTES, acc);

@@ -220,6 +220,38 @@ def extras(lib, cm, with_cpu):
     except Exception as e:   # extras never take the headline down
         ex["ntt_2p24"] = {"error": repr(e)}
 
+    # ---- witness folding W1 + r W2 (src/plonk/mod.rs:1099-1110): HBM-bound ----
+    try:
+        from mira_amd import fold as FD
+        n = 14 << 17                                           # the primary witness vector of a k = 17 step
+        d1 = cm.synth_scalars_device(cm.CURVE_BN256, n, seed=0x57, kind=1)
+        d2 = cm.synth_scalars_device(cm.CURVE_BN256, n, seed=0x58)
+        do = lib.alloc(n * 32)
+        r = lib.download(cm.synth_scalars_device(cm.CURVE_BN256, 1, seed=0x59), (1, 4))[0]
+        FD.fold_witness_device(FD.FIELD_FR, do, d1, d2, r, n)
+        lib.check(lib.c.mira_set_timing(1))
+        ms = 0.0
+        for _ in range(5):
+            FD.fold_witness_device(FD.FIELD_FR, do, d1, d2, r, n)
+            ms += dict(lib.timings())["fold_witness"] / 5
+        lib.check(lib.c.mira_set_timing(0))
+        gbs = 96 * n / (ms * 1e-3) / 1e9
+        ex["fold_witness_14x2p17"] = {"ms": round(ms, 4), "G_elements_per_s": round(n / ms / 1e6, 2),
+                                      "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                   "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes": 96 * n}}
+        if with_cpu:
+            from oracle import cref as C
+            m = 1 << 20
+            a, b2 = lib.download(d1, (m, 4)), lib.download(d2, (m, 4))
+            t0 = time.perf_counter(); want = C.fold_witness(1, a, b2, r); dtc = time.perf_counter() - t0
+            ex["fold_witness_14x2p17"]["cpu_baseline"] = {"value": round(m / dtc / 1e9, 4), "unit": "G elements/s", "cores": C.num_threads(), "kind": "port",
+                                                          "sample": f"first 2^20 elements, {dtc * 1e3:.1f} ms"}
+            ex["fold_witness_14x2p17"]["bit_exact_vs_oracle_2p20"] = bool((lib.download(do, (m, 4)) == want).all())
+        for p in (d1, d2, do):
+            lib.free(p)
+    except Exception as e:
+        ex["fold_witness_14x2p17"] = {"error": repr(e)}
+
     # ---- fold-step MSM schedule at k = 17 -----------------------------
     # per curve: one witness commit (witness-like scalars) + the cross-term commits (uniform), the
     # latter both one call at a time (as the reference issues them) and as one batched submission

@@ -92,6 +92,22 @@ int mira_msm_combine(int curve, const uint64_t *partials /* nparts * MIRA_PARTIA
  * sharded MSM must use the same c. */
 int mira_msm_set_window_bits(int32_t c);
 
+/* Read a range of the registered key back in the reference layout (cache file writing,
+ * save_to_file, src/commitment.rs:96-101). */
+int mira_msm_download_bases(uint64_t handle, size_t first, size_t n, uint64_t *bases_out /* n * 8 limbs */);
+
+/* ---- the step after the MSM in one fold: RelaxedPlonkWitness::fold (src/plonk/mod.rs:1097-1134)
+ * field: MIRA_FIELD_FQ / MIRA_FIELD_FR.  Vectors stay in HBM between the commits and the fold.
+ *   mira_fold_witness_device:  out[i] = w1[i] + r * w2[i]
+ *   mira_fold_error_device:    e[i]  += sum_k r^(k+1) * cross_terms[k][i],  k < num_terms <= 16
+ * mira_g1_mul_add: out = acc + scalar * point on affine points -- the single-scalar best_multiexp
+ * calls of RelaxedPlonkInstance::fold (src/plonk/mod.rs:986-999, 1049-1053); host, O(256).   */
+#define MIRA_FIELD_FQ 0
+#define MIRA_FIELD_FR 1
+int mira_fold_witness_device(int field, void *d_out, const void *d_w1, const void *d_w2, const uint64_t r[4], size_t n);
+int mira_fold_error_device(int field, void *d_e, const void *const *d_cross_terms, size_t num_terms, const uint64_t r[4], size_t n);
+int mira_g1_mul_add(int curve, const uint64_t acc[8], const uint64_t scalar[4], const uint64_t point[8], uint64_t out[8]);
+
 /* ---- NTT over bn256::Fr (src/fft.rs) -----------------------------------------------------
  * In place, natural order in and out.  `a` = 2^log_n elements.  log_n <= 24 in this build
  * (the field allows 28, src/fft.rs:13).                                                      */

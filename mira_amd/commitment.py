@@ -79,6 +79,59 @@ class CommitmentKey:
             raise ValueError("bases were registered from host memory; keep your own copy")
         return self.lib.download(ptr, (self._len, 8))
 
+    # ---- commitment-key cache (src/commitment.rs:96-167): raw dump of [C], 2^k x 64 bytes ----
+    def download(self, first=0, n=None):
+        """The registered key (or a range) back in the reference layout."""
+        n = self._len - first if n is None else n
+        out = np.empty((n, 8), dtype=np.uint64)
+        self.lib.check(self.lib.c.mira_msm_download_bases(self.handle, first, n, out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    def save_to_file(self, file_path, chunk=1 << 20):
+        """`save_to_file` (src/commitment.rs:96-101): the slice as raw bytes."""
+        with open(file_path, "wb") as f:
+            for first in range(0, self._len, chunk):
+                f.write(self.download(first, min(chunk, self._len - first)).tobytes())
+
+    @classmethod
+    def load_from_file(cls, curve, file_path, k, lib=None, chunk=1 << 20):
+        """`load_from_file` (src/commitment.rs:110-127): 2^k points straight from the file into
+        HBM in chunks (memory-mapped, never a second host copy of the whole key)."""
+        lib = lib or _lib.load()
+        n = 1 << k
+        mm = np.memmap(file_path, dtype=np.uint64, mode="r")
+        if mm.size < n * 8:
+            raise IOError(f"failed to fill whole buffer: {file_path} holds {mm.size // 8} points, need {n}")   # read_exact
+        ptr = lib.alloc(max(n, 1) * 64)
+        for first in range(0, n, chunk):
+            cnt = min(chunk, n - first)
+            lib.upload(ptr + first * 64, np.ascontiguousarray(mm[first * 8:(first + cnt) * 8]))
+        key = cls(curve, device_ptr=ptr, length=n, lib=lib)
+        lib.free(ptr)                                   # register keeps its own resident copy
+        return key
+
+    @classmethod
+    def load_or_setup_cache(cls, curve, cache_folder, label, k, lib=None):
+        """`load_or_setup_cache` (src/commitment.rs:134-166): `{cache_folder}/{label}/{k}.bin`;
+        a loaded key is validated point by point (is_on_curve) on the GPU and rejected with the
+        reference's message otherwise.  A missing file is generated and stored -- with the
+        synthetic generator here, because `setup`'s hash-to-curve lives in the absent halo2curves."""
+        import os
+        path = os.path.join(cache_folder, label, f"{k}.bin")
+        if os.path.exists(path):
+            key = cls.load_from_file(curve, path, k, lib=lib)
+            try:
+                key.check_on_curve()
+            except _lib.MiraError as e:
+                if e.code == _lib.MIRA_E_INVALID_POINT:
+                    raise IOError("Wrong file in cache, some ptr out of curve") from e
+                raise
+            return key
+        key = cls.synthetic(curve, 1 << k, lib=lib)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        key.save_to_file(path)
+        return key
+
     def check_on_curve(self):
         """load_or_setup_cache's validation (src/commitment.rs:145-154), on the GPU."""
         self.lib.check(self.lib.c.mira_msm_check_bases(self.handle))

@@ -131,7 +131,8 @@ static MsmPlan make_plan(size_t n, int32_t forced_c, uint32_t count = 1, uint64_
     p.lanes = 256u * 4u * 3u * 64u;
     p.L = 16;   // minimum segment length (small MSMs: more, shorter segments beat fewer fix-up links)
     p.T = (uint32_t)std::min<uint64_t>(p.lanes, ceil_div(entries, p.L));   // upper bound of segments
-    p.m = std::min<uint32_t>(16, p.B);
+    // reduction chunk: the chain is 2m running-sum adds, then ceil(B/m/512) + 9 in k_window_sum
+    p.m = std::min<uint32_t>(p.B, p.B <= 4096 ? 4 : 16);   // measured: m = 8 at B = 32768 is slower (65k lanes of scalar-mul work)
     p.nchunks = p.B / p.m;
     return p;
 }
@@ -248,6 +249,30 @@ static int ntt_kind_host_locked(uint64_t *a, uint32_t log_n, NttKind kind, const
     RT_CHECK(rt_d2h(a, g.ntt_stage.p, bytes, g.stream));
     RT_CHECK(rt_sync(g.stream));
     return MIRA_OK;
+}
+
+// acc + scalar * point on affine points: the single-scalar best_multiexp calls of
+// RelaxedPlonkInstance::fold (src/plonk/mod.rs:986-999, 1049-1053).  O(256) host work.
+template <class FB, class FS> static void g1_mul_add_t(const uint64_t acc[8], const uint64_t scalar[4], const uint64_t point[8], uint64_t out[8]) {
+    using namespace hostf;
+    HFe<FS> s;
+    memcpy(s.l, scalar, 32);
+    HFe<FS> one_plain = {{1, 0, 0, 0}};
+    s = mul(s, one_plain);                                  // leave Montgomery form: canonical integer
+    auto lift = [](const uint64_t p[8]) {
+        HXyzz<FB> r = identity<FB>();
+        bool zero = true;
+        for (int i = 0; i < 8; i++) zero &= (p[i] == 0);
+        if (!zero) { memcpy(r.x.l, p, 32); memcpy(r.y.l, p + 4, 32); r.zz = one<FB>(); r.zzz = one<FB>(); }
+        return r;
+    };
+    HXyzz<FB> P = lift(point), R = identity<FB>();
+    for (int bit = 255; bit >= 0; bit--) {
+        R = dbl_pt(R);
+        if ((s.l[bit / 64] >> (bit % 64)) & 1) R = add_pt(R, P);
+    }
+    R = add_pt(R, lift(acc));
+    to_affine(R, out);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -436,6 +461,46 @@ int mira_coset_ifft_bn256_fr(uint64_t *a, uint32_t log_n) { std::lock_guard<std:
 int mira_get_omega_or_inv(uint32_t k, int is_inverse, uint64_t out[4]) {
     if (!out || k > 28) { set_error("k=" + std::to_string(k) + " should no larger than F::S=28"); return MIRA_E_BAD_ARG; }
     return ntt_get_omega_or_inv(k, is_inverse != 0, out);
+}
+
+int mira_fold_witness_device(int field, void *d_out, const void *d_w1, const void *d_w2, const uint64_t r[4], size_t n) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    if ((field != 0 && field != 1) || !r || (n && (!d_out || !d_w1 || !d_w2))) { set_error("bad fold arguments"); return MIRA_E_BAD_ARG; }
+    if (!n) return MIRA_OK;
+    return fold_witness_device(field, d_out, d_w1, d_w2, r, n);
+}
+int mira_fold_error_device(int field, void *d_e, const void *const *d_cross_terms, size_t num_terms, const uint64_t r[4], size_t n) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    if ((field != 0 && field != 1) || !r || num_terms > 16 || (num_terms && !d_cross_terms) || (n && !d_e)) { set_error("bad fold arguments"); return MIRA_E_BAD_ARG; }
+    for (size_t k = 0; k < num_terms; k++)
+        if (n && !d_cross_terms[k]) { set_error("null cross term"); return MIRA_E_BAD_ARG; }
+    if (!n || !num_terms) return MIRA_OK;
+    return fold_error_device(field, d_e, d_cross_terms, num_terms, r, n);
+}
+int mira_g1_mul_add(int curve, const uint64_t acc[8], const uint64_t scalar[4], const uint64_t point[8], uint64_t out[8]) {
+    if ((curve != MIRA_CURVE_BN256 && curve != MIRA_CURVE_GRUMPKIN) || !acc || !scalar || !point || !out) { set_error("bad arguments"); return MIRA_E_BAD_ARG; }
+    if (curve == MIRA_CURVE_BN256) g1_mul_add_t<FqP, FrP>(acc, scalar, point, out);
+    else g1_mul_add_t<FrP, FqP>(acc, scalar, point, out);
+    return MIRA_OK;
+}
+int mira_msm_download_bases(uint64_t handle, size_t first, size_t n, uint64_t *bases_out) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    auto it = g_bases.find(handle);
+    if (it == g_bases.end()) { set_error("unknown bases handle"); return MIRA_E_BAD_ARG; }
+    const Bases &bs = it->second;
+    if (first > bs.n || n > bs.n - first || (n && !bases_out)) { set_error("range outside the registered key"); return MIRA_E_BAD_ARG; }
+    if (!n) return MIRA_OK;
+    if ((rc = g.scalars_stage.ensure(n * 64))) return rc;
+    if ((rc = bs.curve == MIRA_CURVE_BN256 ? export_bases_bn256(bs, first, n, g.scalars_stage.p) : export_bases_grumpkin(bs, first, n, g.scalars_stage.p))) return rc;
+    RT_CHECK(rt_d2h(bases_out, g.scalars_stage.p, n * 64, g.stream));
+    RT_CHECK(rt_sync(g.stream));
+    return MIRA_OK;
 }
 
 int mira_synth_scalars_device(int curve, size_t n, uint64_t index0, uint64_t seed, int kind, void *d_out) {

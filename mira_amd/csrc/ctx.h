@@ -80,6 +80,7 @@ struct Ctx {
     DevBuf head_part, tail_part, head_key, tail_key, heavy, chunks, window_sums, scalars_stage, consts;
     // NTT workspace
     DevBuf ntt_tmp, ntt_stage, ntt_tables, ntt_consts;
+    DevBuf fold_consts;
     std::string ntt_tables_key;
     uint64_t next_handle = 1;
 };
@@ -119,6 +120,12 @@ int synth_bases_bn256(size_t n, uint64_t index0, uint64_t seed, void *d_out);
 int synth_bases_grumpkin(size_t n, uint64_t index0, uint64_t seed, void *d_out);
 int check_bases_bn256(const Bases &bs, uint32_t *d_bad);
 int check_bases_grumpkin(const Bases &bs, uint32_t *d_bad);
+
+// fold.hip
+int fold_witness_device(int field, void *d_out, const void *d_w1, const void *d_w2, const uint64_t r[4], size_t n);
+int fold_error_device(int field, void *d_e, const void *const *d_terms, size_t K, const uint64_t r[4], size_t n);
+int export_bases_bn256(const Bases &bs, size_t first, size_t n, void *d_out);
+int export_bases_grumpkin(const Bases &bs, size_t first, size_t n, void *d_out);
 
 // ntt.hip
 enum NttKind { NTT_BEST, NTT_FFT, NTT_IFFT, NTT_COSET_FFT, NTT_COSET_IFFT };

@@ -1,0 +1,51 @@
+// The step right after the MSM in one NIFS fold: witness / error-vector
+// folding, reference src/plonk/mod.rs:1097-1134 (RelaxedPlonkWitness::fold)
+//     W[i] = W1[i] + r * W2[i]                      (par_iter axpy)
+//     E[i] = E[i] + sum_k r^(k+1) * T_k[i]          (K cross-term vectors)
+// Element-wise over vectors that already live in HBM, one multiplication per 96 bytes moved:
+// HBM-bound.  Each lane handles one element with two 16-byte loads per operand; results are
+// canonical, so they equal the reference's bit for bit.
+#pragma once
+#include "field29.cuh"
+
+static constexpr int FOLD_MAX_TERMS = 16;
+struct FoldTerms {
+    const unsigned char *t[FOLD_MAX_TERMS];
+};
+
+// multiplier-form constants (9 limbs padded to 48 B, value * 2^261): see ntt_kernels.cuh tw_load
+template <class F> DEV Fe29<F> fold_const_load(const unsigned char *p) {
+    const U4 *q = reinterpret_cast<const U4 *>(p);
+    U4 a = q[0], b = q[1], c = q[2];
+    Fe29<F> r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w; r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w; r.l[8] = c.x;
+    F29_SET(r, 1.0);
+    return r;
+}
+template <class F> DEV Fe<typename F::Sat> fold_canonical(const Fe29<F> &v) { return reduce_once(f29_pack(v)); }
+
+// out[i] = a[i] + r * b[i]
+template <class F>
+KERNEL void k_fold_axpy(const unsigned char *__restrict__ a, const unsigned char *__restrict__ b, const unsigned char *__restrict__ r_mult,
+                        uint64_t n, unsigned char *__restrict__ out) {
+    using S = typename F::Sat;
+    const Fe29<F> r = fold_const_load<F>(r_mult);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        Fe<S> x = fe_load<S>(a + i * 32), y = fe_load<S>(b + i * 32);
+        Fe<S> t = fold_canonical(f29_mul(f29_unpack_canonical<F>(y), r));
+        fe_store(out + i * 32, fe_add(x, t));
+    }
+}
+// e[i] += sum_k powers[k] * T_k[i],  powers[k] = r^(k+1) in multiplier form (48 B each)
+template <class F>
+KERNEL void k_fold_error(unsigned char *__restrict__ e, FoldTerms terms, uint32_t K, const unsigned char *__restrict__ powers, uint64_t n) {
+    using S = typename F::Sat;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        Fe<S> acc = fe_load<S>(e + i * 32);
+        for (uint32_t k = 0; k < K; k++) {
+            Fe<S> t = fe_load<S>(terms.t[k] + i * 32);
+            acc = fe_add(acc, fold_canonical(f29_mul(f29_unpack_canonical<F>(t), fold_const_load<F>(powers + (size_t)k * 48))));
+        }
+        fe_store(e + i * 32, acc);
+    }
+}

@@ -13,3 +13,4 @@ int synth_bases_bn256(size_t n, uint64_t index0, uint64_t seed, void *d_out) {
 int check_bases_bn256(const Bases &bs, uint32_t *d_bad) {
     return check_bases<Fq29>(bs, reinterpret_cast<const unsigned char *>(g.consts.p) + 128, d_bad);
 }
+int export_bases_bn256(const Bases &bs, size_t first, size_t n, void *d_out) { return export_bases<Fq29>(bs, first, n, d_out); }

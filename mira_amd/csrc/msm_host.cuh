@@ -75,7 +75,7 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size
     LAUNCH(k_reduce_chunks<F>, ceil_div((uint64_t)p.Wt * p.nchunks, 64), 64, 0, st,
            reinterpret_cast<const unsigned char *>(g.bucket_sums.p), p.B, p.m, p.Wt, reinterpret_cast<unsigned char *>(g.chunks.p));
     tm_mark("reduce_chunks");
-    LAUNCH_BARRIER(k_window_sum<F>, p.Wt, FIXUP_BLOCK, 0, st, reinterpret_cast<const unsigned char *>(g.chunks.p), p.nchunks,
+    LAUNCH_BARRIER(k_window_sum<F>, p.Wt, WSUM_BLOCK, (size_t)WSUM_BLOCK * XYZZ29_BYTES, st, reinterpret_cast<const unsigned char *>(g.chunks.p), p.nchunks,
                    reinterpret_cast<unsigned char *>(g.window_sums.p));
     tm_mark("window_sum");
     RT_CHECK(rt_last());
@@ -88,6 +88,7 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size
 
 template <class F, class FS> static int curve_init() {
 #ifndef MIRA_CPU_EMU
+    RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_sum<F>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     // the LDS-staged histogram needs more than the 64 KiB default (128 KiB at c = 16)
     RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -115,6 +116,14 @@ template <class F> static int convert_bases(const void *d_src, void *d_dst, size
     if (!n) return MIRA_OK;
     LAUNCH(k_convert_bases<F>, ceil_div(n, 256), 256, 0, g.stream, reinterpret_cast<const unsigned char *>(d_src),
            reinterpret_cast<unsigned char *>(d_dst), (uint64_t)n);
+    RT_CHECK(rt_last());
+    RT_CHECK(rt_sync(g.stream));
+    return MIRA_OK;
+}
+template <class F> static int export_bases(const Bases &bs, size_t first, size_t n, void *d_out) {
+    if (!n) return MIRA_OK;
+    LAUNCH(k_export_bases<F>, ceil_div(n, 256), 256, 0, g.stream, reinterpret_cast<const unsigned char *>(bs.d) + first * 64,
+           reinterpret_cast<unsigned char *>(d_out), (uint64_t)n);
     RT_CHECK(rt_last());
     RT_CHECK(rt_sync(g.stream));
     return MIRA_OK;

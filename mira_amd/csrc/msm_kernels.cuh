@@ -25,6 +25,7 @@
 static constexpr uint32_t KEY_NONE = 0xFFFFFFFFu;
 static constexpr int HEAVY_SPAN = 6;        // chains longer than this go to k_fixup_heavy (a lane adds ~6.6 us per link)
 static constexpr int FIXUP_BLOCK = 256;
+static constexpr int WSUM_BLOCK = 512;       // k_window_sum: 512 lanes x 144 B = 72 KiB of LDS (1024 lanes would cap VGPRs at 128 and spill)
 
 // ------------------------------------------------------------------------------------------
 template <class FS>
@@ -171,6 +172,21 @@ KERNEL void k_convert_bases(const unsigned char *__restrict__ src, unsigned char
     if (!(fe_is_zero(x) && fe_is_zero(y))) {
         x = reduce_once(f29_pack(f29_from_r256<F>(x)));
         y = reduce_once(f29_pack(f29_from_r256<F>(y)));
+    }
+    fe_store(dst + i * 64, x);
+    fe_store(dst + i * 64 + 32, y);
+}
+
+// The inverse of k_convert_bases: resident layout -> reference layout (key export / cache file).
+template <class F>
+KERNEL void k_export_bases(const unsigned char *__restrict__ src, unsigned char *__restrict__ dst, uint64_t n) {
+    using S = typename F::Sat;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fe<S> x = fe_load<S>(src + i * 64), y = fe_load<S>(src + i * 64 + 32);
+    if (!(fe_is_zero(x) && fe_is_zero(y))) {
+        x = f29_to_r256(f29_unpack_canonical<F>(x));
+        y = f29_to_r256(f29_unpack_canonical<F>(y));
     }
     fe_store(dst + i * 64, x);
     fe_store(dst + i * 64 + 32, y);
@@ -359,18 +375,18 @@ KERNEL void __launch_bounds__(64) k_reduce_chunks(const unsigned char *__restric
 }
 
 // Workgroup per window: window_sums[w] = sum_j R[w][j], exported as X, Y, ZZ, ZZZ in the
-// reference's canonical R = 2^256 form (128 B) for the host epilogue.  blockDim.x == FIXUP_BLOCK.
+// reference's canonical R = 2^256 form (128 B) for the host epilogue.  blockDim.x == WSUM_BLOCK.
 template <class F>
-KERNEL void __launch_bounds__(256) k_window_sum(const unsigned char *__restrict__ R, uint32_t nchunks, unsigned char *__restrict__ window_sums) {
-    __shared__ __attribute__((aligned(16))) unsigned char red[FIXUP_BLOCK * XYZZ29_BYTES];
+KERNEL void __launch_bounds__(512) k_window_sum(const unsigned char *__restrict__ R, uint32_t nchunks, unsigned char *__restrict__ window_sums) {
+    DYN_SHARED(unsigned char, red);
     const uint32_t w = blockIdx.x;
     Xyzz29<F> acc = xyzz29_identity<F>();
     for (uint32_t q = threadIdx.x; q < nchunks; q += blockDim.x)
         xyzz29_add(acc, xyzz29_load<F>(R + ((size_t)w * nchunks + q) * XYZZ29_BYTES));
     xyzz29_store(red + threadIdx.x * XYZZ29_BYTES, acc);
     __syncthreads();
-    for (uint32_t st = FIXUP_BLOCK / 2; st > 0; st >>= 1) {
-        if (threadIdx.x < st) {
+    for (uint32_t st = WSUM_BLOCK / 2; st > 0; st >>= 1) {
+        if (threadIdx.x < st && threadIdx.x + st < nchunks) {      // lanes beyond nchunks hold the identity
             xyzz29_add(acc, xyzz29_load<F>(red + (threadIdx.x + st) * XYZZ29_BYTES));
             xyzz29_store(red + threadIdx.x * XYZZ29_BYTES, acc);
         }

@@ -143,3 +143,18 @@ def synth_scalars(curve, n, seed=0x4D495241, kind=0):
 def synth_bases(curve, n, seed=0x42415345):
     out = np.empty((n, 8), dtype=np.uint64)
     lib().oracle_synth_bases(curve, ctypes.c_size_t(n), ctypes.c_uint64(seed), _p(out)); return out
+
+
+def fold_witness(field, w1, w2, r):
+    """RelaxedPlonkWitness::fold, W part (src/plonk/mod.rs:1099-1110)"""
+    w1, w2 = _u64(w1).reshape(-1, 4), _u64(w2).reshape(-1, 4)
+    out = np.empty_like(w1)
+    lib().oracle_fold_witness(field, _p(w1), _p(w2), _p(_u64(r)), ctypes.c_size_t(len(w1)), _p(out)); return out
+
+
+def fold_error(field, e, cross_terms, r):
+    """RelaxedPlonkWitness::fold, E part (src/plonk/mod.rs:1118-1131)"""
+    e = _u64(e).reshape(-1, 4).copy()
+    terms = [_u64(t).reshape(-1, 4) for t in cross_terms]
+    ptrs = (ctypes.c_void_p * len(terms))(*[t.ctypes.data for t in terms])
+    lib().oracle_fold_error(field, _p(e), ptrs, ctypes.c_size_t(len(terms)), _p(_u64(r)), ctypes.c_size_t(len(e))); return e

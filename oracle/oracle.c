@@ -412,6 +412,28 @@ int oracle_commit(int curve, const u64 *ck, size_t ck_len, const u64 *v, size_t 
     return 1;
 }
 
+/* ------------------------------------------------------------------ witness folding
+ * RelaxedPlonkWitness::fold, src/plonk/mod.rs:1097-1134.  field: 0 = Fq, 1 = Fr.             */
+void oracle_fold_witness(int f, const u64 *w1, const u64 *w2, const u64 *r4, size_t n, u64 *out) {
+    const field_t *F = fld(f);
+#pragma omp parallel for
+    for (long i = 0; i < (long)n; i++) {                       /* *w1 + *r * *w2, :1107 */
+        fe t; f_mul(&t, (const fe *)r4, (const fe *)(w2 + 4 * i), F);
+        f_add((fe *)(out + 4 * i), (const fe *)(w1 + 4 * i), &t, F);
+    }
+}
+void oracle_fold_error(int f, u64 *e, const u64 *const *terms, size_t K, const u64 *r4, size_t n) {
+    const field_t *F = fld(f);
+    fe pw[16], cur = *(const fe *)r4;                          /* r^1, r^2, ...  :1119-1121 */
+    for (size_t k = 0; k < K && k < 16; k++) { pw[k] = cur; f_mul(&cur, &cur, (const fe *)r4, F); }
+#pragma omp parallel for
+    for (long i = 0; i < (long)n; i++) {                       /* fold(*ei, acc + power_of_r * tk[i]) :1126-1130 */
+        fe acc = *(fe *)(e + 4 * i);
+        for (size_t k = 0; k < K; k++) { fe t; f_mul(&t, &pw[k], (const fe *)(terms[k] + 4 * i), F); f_add(&acc, &acc, &t, F); }
+        *(fe *)(e + 4 * i) = acc;
+    }
+}
+
 /* ------------------------------------------------------------------ NTT (src/fft.rs) */
 static fe fr_pow_u64(const fe *a, u64 e) {
     fe ee = {{e, 0, 0, 0}}, r; f_pow(&r, a, &ee, &FR); return r;

@@ -154,6 +154,25 @@ def concatenate_with_padding(vs, pad_size):
     return out
 
 
+# ----------------------------------------------------------------------------- witness folding
+def fold_witness(w1, w2, r, mod):
+    """src/plonk/mod.rs:1099-1110: w1 + r * w2, element-wise"""
+    assert len(w1) == len(w2)
+    return [(a + r * b) % mod for a, b in zip(w1, w2)]
+
+
+def fold_error(e, cross_terms, r, mod):
+    """src/plonk/mod.rs:1118-1131: e_i + sum_k r^(k+1) * T_k[i]"""
+    out = []
+    for i, ei in enumerate(e):
+        acc, pw = ei, r
+        for t in cross_terms:
+            acc = (acc + pw * t[i]) % mod
+            pw = pw * r % mod
+        out.append(acc)
+    return out
+
+
 # ----------------------------------------------------------------------------- NTT
 def get_omega_or_inv(k, is_inverse):
     """src/fft.rs:12-23"""

@@ -1,0 +1,92 @@
+"""SURVEY.md 8(f) rows N2 (witness / error folding) and N3 (commitment-key cache) -- oracle
+cross-checks on CPU and the kernel logic under the test-only emulation."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import arr_to_point, ints_to_mont, mont_to_ints, point_to_arr
+from mira_amd import commitment as cm
+from mira_amd import fold as FD
+from oracle import cref as C
+from oracle import pyref as P
+
+MODS = {0: P.P_MOD, 1: P.R_MOD}          # field id -> modulus
+CURVE_OF_FIELD = {1: 0, 0: 1}            # scalars of bn256 live in Fr (1), of grumpkin in Fq (0)
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_oracle_fold_c_vs_python(field):
+    mod, cid, n = MODS[field], CURVE_OF_FIELD[field], 257
+    w1, w2 = C.synth_scalars(cid, n, seed=1, kind=1), C.synth_scalars(cid, n, seed=2)
+    r = C.synth_scalars(cid, 1, seed=3)[0]
+    ri = mont_to_ints(r, mod)[0]
+    want = P.fold_witness(mont_to_ints(w1, mod), mont_to_ints(w2, mod), ri, mod)
+    assert mont_to_ints(C.fold_witness(field, w1, w2, r), mod) == want
+    terms = [C.synth_scalars(cid, n, seed=10 + k) for k in range(5)]
+    want_e = P.fold_error(mont_to_ints(w1, mod), [mont_to_ints(t, mod) for t in terms], ri, mod)
+    assert mont_to_ints(C.fold_error(field, w1, terms, r), mod) == want_e
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_emu_fold(emu_lib, field):
+    cid, n = CURVE_OF_FIELD[field], 1000
+    w1, w2 = C.synth_scalars(cid, n, seed=4, kind=1), C.synth_scalars(cid, n, seed=5)
+    r = C.synth_scalars(cid, 1, seed=6)[0]
+    assert (FD.fold_witness(field, w1, w2, r, lib=emu_lib) == C.fold_witness(field, w1, w2, r)).all()
+    terms = [C.synth_scalars(cid, n, seed=20 + k) for k in range(6)]
+    assert (FD.fold_error(field, w1, terms, r, lib=emu_lib) == C.fold_error(field, w1, terms, r)).all()
+    assert (FD.fold_error(field, w1, [], r, lib=emu_lib) == w1).all()
+    with pytest.raises(AssertionError):
+        FD.fold_witness(field, w1, w2[:-1], r, lib=emu_lib)        # zip_eq
+
+
+def test_emu_commit_is_homomorphic_over_fold(emu_lib):
+    """is_sat_relaxed's check (src/plonk/mod.rs:547-557): the commitment of the folded witness
+    equals the folded commitment -- with every piece coming from this library."""
+    for cid, field in ((0, 1), (1, 0)):
+        n = 200
+        bases = C.synth_bases(cid, n, seed=3)
+        key = cm.CommitmentKey(cid, bases, lib=emu_lib)
+        w1, w2 = C.synth_scalars(cid, n, seed=7, kind=1), C.synth_scalars(cid, n, seed=8)
+        r = C.synth_scalars(cid, 1, seed=9)[0]
+        folded = FD.fold_witness(field, w1, w2, r, lib=emu_lib)
+        lhs = key.commit(folded)
+        rhs = FD.g1_mul_add(cid, key.commit(w1), r, key.commit(w2), lib=emu_lib)
+        assert (lhs == rhs).all()
+
+
+def test_emu_g1_mul_add_matches_oracle(emu_lib):
+    for cid in (0, 1):
+        cv = P.CURVES[cid]
+        pts = C.synth_bases(cid, 2, seed=12)
+        s = C.synth_scalars(cid, 1, seed=13)[0]
+        want = P.ec_add(arr_to_point(pts[0], cid), P.ec_mul(mont_to_ints(s, cv.r)[0], arr_to_point(pts[1], cid), cv), cv)
+        assert arr_to_point(FD.g1_mul_add(cid, pts[0], s, pts[1], lib=emu_lib), cid) == want
+        zero = np.zeros(8, dtype=np.uint64)
+        assert (FD.g1_mul_add(cid, zero, np.zeros(4, dtype=np.uint64), pts[1], lib=emu_lib) == zero).all()
+
+
+def test_emu_key_cache_roundtrip(emu_lib, tmp_path):
+    """src/commitment.rs:96-167 and its test `consistency` (:178-194): save, load, compare."""
+    cid, k = 0, 6
+    key = cm.CommitmentKey.synthetic(cid, 1 << k, lib=emu_lib)
+    original = key.bases()
+    assert (key.download() == original).all()               # export inverts the resident conversion
+    path = tmp_path / "my-temporary-note.txt"
+    key.save_to_file(path)
+    assert os.path.getsize(path) == (1 << k) * 64
+    assert open(path, "rb").read() == original.tobytes()     # raw dump of the slice
+    loaded = cm.CommitmentKey.load_from_file(cid, path, k, lib=emu_lib)
+    assert (loaded.download() == original).all()
+    with pytest.raises(IOError):
+        cm.CommitmentKey.load_from_file(cid, path, k + 1, lib=emu_lib)     # read_exact fails
+    # load_or_setup_cache: creates {folder}/{label}/{k}.bin, reloads and validates it
+    k1 = cm.CommitmentKey.load_or_setup_cache(cid, str(tmp_path / "cache"), "bn256", k, lib=emu_lib)
+    p = tmp_path / "cache" / "bn256" / f"{k}.bin"
+    assert p.exists()
+    k2 = cm.CommitmentKey.load_or_setup_cache(cid, str(tmp_path / "cache"), "bn256", k, lib=emu_lib)
+    assert (k1.download() == k2.download()).all()
+    raw = bytearray(p.read_bytes()); raw[70] ^= 1; p.write_bytes(bytes(raw))
+    with pytest.raises(IOError, match="Wrong file in cache, some ptr out of curve"):
+        cm.CommitmentKey.load_or_setup_cache(cid, str(tmp_path / "cache"), "bn256", k, lib=emu_lib)

@@ -1,0 +1,26 @@
+"""Copy the judged summaries out of gpurun_out/ (scratch) into profiles/ (tracked).
+usage: python tools/collect_profiles.py <tag> <bench_json> <kernel_stats_dir> <pmc_fetch_dir> <pmc_write_dir>"""
+import collections, csv, glob, json, shutil, sys
+tag, bench, stats_dir, fdir, wdir = sys.argv[1:6]
+shutil.copy(bench, f"profiles/{tag}_bench.json")
+shutil.copy(glob.glob(f"{stats_dir}/*/*kernel_stats.csv")[0], f"profiles/{tag}_msm2p22_kernel_stats.csv")
+out = {}
+lines = ["kernel,counter,launches,avg_value_KB"]
+for c, d in (("FETCH_SIZE", fdir), ("WRITE_SIZE", wdir)):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(glob.glob(f"{d}/*/*counter_collection.csv")[0])):
+        agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        lines.append(f"\"{k}\",{c},{len(v)},{sum(v) / len(v):.1f}")
+        out[(k, c)] = sum(v) / len(v)
+open(f"profiles/{tag}_msm2p22_pmc_fetch_write.csv", "w").write("\n".join(lines) + "\n")
+f = [v for (k, c), v in out.items() if "k_accumulate" in k and c == "FETCH_SIZE"][0]
+w = [v for (k, c), v in out.items() if "k_accumulate" in k and c == "WRITE_SIZE"][0]
+dg = [v for (k, c), v in out.items() if "k_digits" in k and c == "FETCH_SIZE"][0]
+json.dump({"k_accumulate_2p22": int((2 * f + w) * 1024),
+           "_how": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (profiles/{tag}_msm2p22_pmc_fetch_write.csv); "
+                   "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE tallies 128-B requests at 64 B), "
+                   f"confirmed on this run's own streaming kernel k_digits (128 MiB of scalars read, {dg / 1024:.1f} MiB reported); "
+                   "the 64-B gather pattern of k_accumulate itself is uncalibrated",
+           "_raw_KB": {"FETCH_SIZE": f, "WRITE_SIZE": w}}, open("profiles/pmc_traffic.json", "w"), indent=1)
+print("k_accumulate traffic GB:", (2 * f + w) * 1024 / 1e9)

@@ -63,6 +63,12 @@ int mira_msm_register_bases(int curve, const uint64_t *bases /* n * 8 limbs */, 
  * in the engine's layout, so the caller's buffer is free again when the call returns. */
 int mira_msm_register_bases_device(int curve, const void *d_bases, size_t n, uint64_t *handle_out);
 int mira_msm_unregister(uint64_t handle);
+/* Optional, once per key: build the fixed-base window tables 2^(20 w) * P_i, w < 13, in HBM
+ * (13 x the key size: 3.3 GiB at 2^22 points).  Later MSMs of >= 2^18 pairs on this handle then use
+ * one shared set of 2^19 buckets and 13 instead of 16 additions per pair.  Results are unchanged
+ * (bit-identical); mira_msm_partial_device then reports window_bits = 0, num_windows = 64 (64
+ * partial sums to be added).  MIRA_E_ALLOC if the tables do not fit. */
+int mira_msm_precompute(uint64_t handle);
 /* Validate every registered base against the curve equation on the GPU, as
  * load_or_setup_cache does with is_on_curve (src/commitment.rs:145-154). */
 int mira_msm_check_bases(uint64_t handle);

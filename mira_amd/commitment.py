@@ -132,6 +132,12 @@ class CommitmentKey:
         key.save_to_file(path)
         return key
 
+    def precompute(self):
+        """Build the fixed-base window tables in HBM (13 x the key size); large commits on this key
+        then take 13 instead of 16 bucket additions per pair.  Results are bit-identical."""
+        self.lib.check(self.lib.c.mira_msm_precompute(self.handle))
+        return self
+
     def check_on_curve(self):
         """load_or_setup_cache's validation (src/commitment.rs:145-154), on the GPU."""
         self.lib.check(self.lib.c.mira_msm_check_bases(self.handle))

@@ -17,6 +17,7 @@ void set_error(const std::string &s) { g_err = s; }
 static std::mutex g_lock;
 Ctx g;
 static std::map<uint64_t, Bases> g_bases;
+static constexpr size_t TABLE_MIN_N = (size_t)1 << 18;   // below this an MSM is latency-bound and the per-window path is as fast
 
 // constants block on device: [0] gen bn256 (64 B, R form) [64] gen grumpkin (64 B, R form)
 // [128] b bn256 (32 B, R' form) [160] b grumpkin (32 B, R' form)
@@ -182,13 +183,20 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
     memset(out_partial, 0, MIRA_PARTIAL_U64 * 8);
     if (n == 0) return MIRA_OK;
     if (!d_scalars) { set_error("null scalars"); return MIRA_E_BAD_ARG; }
+    // fixed-base mode: window tables present, MSM large enough to be throughput-bound, no forced width
+    const size_t table_min_n = getenv("MIRA_TABLE_MIN_N") ? (size_t)atoll(getenv("MIRA_TABLE_MIN_N")) : TABLE_MIN_N;   // tests lower it
+    if (bs.tables && n >= table_min_n && g.forced_c == 0) {
+        *c_out = 0; *W_out = 64;                            // 64 partial sums, combined by a plain sum
+        return bs.curve == MIRA_CURVE_BN256 ? msm_launch_table_bn256(bs, first, d_scalars, n, out_partial)
+                                             : msm_launch_table_grumpkin(bs, first, d_scalars, n, out_partial);
+    }
     if (bs.curve == MIRA_CURVE_BN256) return msm_launch_bn256(bs, first, d_scalars, n, p, out_partial);
     return msm_launch_grumpkin(bs, first, d_scalars, n, p, out_partial);
 }
 
 static int combine_locked(int curve, const uint64_t *partials, size_t nparts, uint32_t c, uint32_t W, uint64_t out[8]) {
     if (curve != MIRA_CURVE_BN256 && curve != MIRA_CURVE_GRUMPKIN) { set_error("unknown curve"); return MIRA_E_BAD_ARG; }
-    if (!partials || !out || nparts == 0 || c < 1 || c > 16 || W < 1 || W > MIRA_MAX_WINDOWS) { set_error("bad combine arguments"); return MIRA_E_BAD_ARG; }
+    if (!partials || !out || nparts == 0 || c > 16 || W < 1 || W > MIRA_MAX_WINDOWS) { set_error("bad combine arguments"); return MIRA_E_BAD_ARG; }
     std::vector<uint64_t> win((size_t)W * 16);
     if (curve == MIRA_CURVE_BN256) { sum_partials<FqP>(partials, nparts, W, win.data()); horner_affine<FqP>(win.data(), c, W, out); }
     else { sum_partials<FrP>(partials, nparts, W, win.data()); horner_affine<FrP>(win.data(), c, W, out); }
@@ -347,8 +355,19 @@ int mira_msm_unregister(uint64_t handle) {
     auto it = g_bases.find(handle);
     if (it == g_bases.end()) { set_error("unknown bases handle"); return MIRA_E_BAD_ARG; }
     if (it->second.owned && it->second.d) rt_free(it->second.d);
+    if (it->second.tables) rt_free(it->second.tables);
     g_bases.erase(it);
     return MIRA_OK;
+}
+int mira_msm_precompute(uint64_t handle) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    auto it = g_bases.find(handle);
+    if (it == g_bases.end()) { set_error("unknown bases handle"); return MIRA_E_BAD_ARG; }
+    Bases &bs = it->second;
+    if ((uint64_t)bs.n * 13 >= (1ull << 31)) { set_error("key too long for 31-bit table indices"); return MIRA_E_UNSUPPORTED; }
+    return bs.curve == MIRA_CURVE_BN256 ? build_tables_bn256(bs) : build_tables_grumpkin(bs);
 }
 int mira_msm_check_bases(uint64_t handle) {
     std::lock_guard<std::mutex> lk(g_lock);

@@ -28,6 +28,7 @@ static inline hipError_t rt_free(void *p) { return hipFree(p); }
 static inline hipError_t rt_memset(void *p, int v, size_t n, hipStream_t s) { return hipMemsetAsync(p, v, n, s); }
 static inline hipError_t rt_h2d(void *d, const void *h, size_t n, hipStream_t s) { return hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s); }
 static inline hipError_t rt_d2h(void *h, const void *d, size_t n, hipStream_t s) { return hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s); }
+static inline hipError_t rt_d2d(void *d, const void *s_, size_t n, hipStream_t s) { return hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, s); }
 static inline hipError_t rt_sync(hipStream_t s) { return hipStreamSynchronize(s); }
 static inline hipError_t rt_last() { return hipGetLastError(); }
 #else
@@ -37,6 +38,7 @@ static inline int rt_free(void *p) { free(p); return 0; }
 static inline int rt_memset(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
 static inline int rt_h2d(void *d, const void *h, size_t n, hipStream_t) { memcpy(d, h, n); return 0; }
 static inline int rt_d2h(void *h, const void *d, size_t n, hipStream_t) { memcpy(h, d, n); return 0; }
+static inline int rt_d2d(void *d, const void *s_, size_t n, hipStream_t) { memcpy(d, s_, n); return 0; }
 static inline int rt_sync(hipStream_t) { return 0; }
 static inline int rt_last() { return 0; }
 #endif
@@ -76,7 +78,7 @@ struct Ctx {
     int32_t forced_c = 0;
     Timing tm;
     // MSM workspace (grow-only, shared by all handles: calls are serialised by the ABI lock)
-    DevBuf digits, counts, offsets, cursor, block_sums, sorted_idx, sorted_key, bucket_sums;
+    DevBuf digits, counts, offsets, cursor, block_sums, sorted_idx, sorted_key, bucket_sums, part, coarse_offsets;
     DevBuf head_part, tail_part, head_key, tail_key, heavy, chunks, window_sums, scalars_stage, consts;
     // NTT workspace
     DevBuf ntt_tmp, ntt_stage, ntt_tables, ntt_consts;
@@ -91,6 +93,7 @@ struct Bases {
     size_t n;
     void *d = nullptr;
     bool owned = false;
+    void *tables = nullptr;   // fixed-base window tables (table_kernels.cuh), TABLE_W * n points, or null
 };
 
 void tm_begin();
@@ -110,6 +113,10 @@ struct MsmPlan {
 // per-curve translation units (msm_bn256.hip / msm_grumpkin.hip)
 int msm_launch_bn256(const Bases &bs, size_t first, const void *d_scalars, size_t n, const MsmPlan &p, uint64_t *host_windows);
 int msm_launch_grumpkin(const Bases &bs, size_t first, const void *d_scalars, size_t n, const MsmPlan &p, uint64_t *host_windows);
+int msm_launch_table_bn256(const Bases &bs, size_t first, const void *d_scalars, size_t n, uint64_t *host_sums);
+int msm_launch_table_grumpkin(const Bases &bs, size_t first, const void *d_scalars, size_t n, uint64_t *host_sums);
+int build_tables_bn256(Bases &bs);
+int build_tables_grumpkin(Bases &bs);
 int curve_init_bn256();
 int convert_bases_bn256(const void *d_src, void *d_dst, size_t n);
 int convert_bases_grumpkin(const void *d_src, void *d_dst, size_t n);

@@ -14,3 +14,7 @@ int check_bases_bn256(const Bases &bs, uint32_t *d_bad) {
     return check_bases<Fq29>(bs, reinterpret_cast<const unsigned char *>(g.consts.p) + 128, d_bad);
 }
 int export_bases_bn256(const Bases &bs, size_t first, size_t n, void *d_out) { return export_bases<Fq29>(bs, first, n, d_out); }
+int msm_launch_table_bn256(const Bases &bs, size_t first, const void *d_scalars, size_t n, uint64_t *host_sums) {
+    return msm_launch_table<Fq29, FrP>(bs, first, d_scalars, n, host_sums);
+}
+int build_tables_bn256(Bases &bs) { return build_tables<Fq29>(bs); }

@@ -14,3 +14,7 @@ int check_bases_grumpkin(const Bases &bs, uint32_t *d_bad) {
     return check_bases<Fr29>(bs, reinterpret_cast<const unsigned char *>(g.consts.p) + 160, d_bad);
 }
 int export_bases_grumpkin(const Bases &bs, size_t first, size_t n, void *d_out) { return export_bases<Fr29>(bs, first, n, d_out); }
+int msm_launch_table_grumpkin(const Bases &bs, size_t first, const void *d_scalars, size_t n, uint64_t *host_sums) {
+    return msm_launch_table<Fr29, FqP>(bs, first, d_scalars, n, host_sums);
+}
+int build_tables_grumpkin(Bases &bs) { return build_tables<Fr29>(bs); }

@@ -3,6 +3,13 @@
 #pragma once
 #include "ctx.h"
 #include "msm_kernels.cuh"
+#include "table_kernels.cuh"
+
+#ifdef MIRA_CPU_EMU
+static constexpr uint32_t FIXUP_HEAVY_GRID = 4;     // emulated lanes are OS threads: keep the idle grid small
+#else
+static constexpr uint32_t FIXUP_HEAVY_GRID = 256;
+#endif
 
 template <class F, class FS>
 static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size_t n, const MsmPlan &p,
@@ -68,7 +75,7 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size
            reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
            reinterpret_cast<const uint32_t *>(g.tail_key.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p), heavy_count, heavy_list,
            (uint32_t)(getenv("MIRA_FIXUP_DEBUG") ? atoi(getenv("MIRA_FIXUP_DEBUG")) : 0));
-    LAUNCH_BARRIER(k_fixup_heavy<F>, 256, FIXUP_BLOCK, 0, st, heavy_count, heavy_list,
+    LAUNCH_BARRIER(k_fixup_heavy<F>, FIXUP_HEAVY_GRID, FIXUP_BLOCK, 0, st, heavy_count, heavy_list,
                    reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
                    reinterpret_cast<unsigned char *>(g.bucket_sums.p));
     tm_mark("fixup");
@@ -126,5 +133,110 @@ template <class F> static int export_bases(const Bases &bs, size_t first, size_t
            reinterpret_cast<unsigned char *>(d_out), (uint64_t)n);
     RT_CHECK(rt_last());
     RT_CHECK(rt_sync(g.stream));
+    return MIRA_OK;
+}
+
+// ---- fixed-base window tables (table_kernels.cuh) -------------------------------------------------
+template <class F> static int build_tables(Bases &bs) {
+    if (bs.tables || bs.n == 0) return MIRA_OK;
+    const size_t bytes = (size_t)TABLE_W * bs.n * 64;
+    void *t = nullptr;
+    if (rt_malloc(&t, bytes) != hipSuccess || !t) {
+        set_error("device allocation of " + std::to_string(bytes) + " bytes for the window tables failed");
+        return MIRA_E_ALLOC;
+    }
+    unsigned char *tb = reinterpret_cast<unsigned char *>(t);
+    RT_CHECK(rt_d2d(tb, bs.d, bs.n * 64, g.stream));                        // T_0 = the key itself
+    for (uint32_t w = 1; w < TABLE_W; w++)
+        LAUNCH(k_table_step<F>, ceil_div(bs.n, 64), 64, 0, g.stream, (const unsigned char *)(tb + (size_t)(w - 1) * bs.n * 64),
+               tb + (size_t)w * bs.n * 64, (uint64_t)bs.n, TABLE_C);
+    RT_CHECK(rt_last());
+    RT_CHECK(rt_sync(g.stream));
+    bs.tables = t;
+    return MIRA_OK;
+}
+
+// One MSM over the tables: 13 signed 20-bit digits per scalar, one set of 2^19 buckets.  Returns
+// TABLE_SUMS partial sums (XYZZ, canonical, reference form) whose plain sum is the result.
+template <class F, class FS>
+static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars, size_t n, uint64_t *host_sums) {
+    int rc;
+    const size_t entries = (size_t)n * TABLE_W;
+    const uint32_t lanes = 256u * 4u * 3u * 64u, Lmin = 16;
+    const uint32_t T = (uint32_t)std::min<uint64_t>(lanes, ceil_div(entries, Lmin));
+    const uint32_t m = 16, nchunks = TABLE_B / m;
+    if ((rc = g.digits.ensure(entries * 4))) return rc;
+    if ((rc = g.counts.ensure(((size_t)TABLE_CB + 1) * 4))) return rc;
+    if ((rc = g.coarse_offsets.ensure(((size_t)TABLE_CB + 1) * 4))) return rc;
+    if ((rc = g.cursor.ensure(((size_t)TABLE_CB + 1) * 4))) return rc;
+    if ((rc = g.block_sums.ensure(1024 * 4))) return rc;
+    if ((rc = g.part.ensure(entries * 8 + 8))) return rc;
+    if ((rc = g.sorted_idx.ensure(entries * 4 + 8))) return rc;
+    if ((rc = g.offsets.ensure(((size_t)TABLE_B + 1) * 4))) return rc;
+    if ((rc = g.bucket_sums.ensure((size_t)TABLE_B * XYZZ29_BYTES))) return rc;
+    if ((rc = g.head_part.ensure((size_t)T * XYZZ29_BYTES))) return rc;
+    if ((rc = g.tail_part.ensure((size_t)T * XYZZ29_BYTES))) return rc;
+    if ((rc = g.head_key.ensure((size_t)T * 4))) return rc;
+    if ((rc = g.tail_key.ensure((size_t)T * 4))) return rc;
+    if ((rc = g.heavy.ensure(((size_t)T * 3 + 4) * 4))) return rc;
+    if ((rc = g.chunks.ensure((size_t)nchunks * XYZZ29_BYTES))) return rc;
+    if ((rc = g.window_sums.ensure((size_t)TABLE_SUMS * 128))) return rc;
+
+    hipStream_t st = g.stream;
+    uint32_t *heavy_count = reinterpret_cast<uint32_t *>(g.heavy.p);
+    uint32_t *heavy_list = heavy_count + 4, *plan = heavy_count + 2;
+    // level-1 tiles of 32k points: runs of ~64 entries per (workgroup, coarse bin)
+    const uint32_t tile = 32768, ntiles = ceil_div(n, tile);
+    tm_begin();
+    RT_CHECK(rt_memset(g.counts.p, 0, ((size_t)TABLE_CB + 1) * 4, st));
+    RT_CHECK(rt_memset(g.bucket_sums.p, 0, (size_t)TABLE_B * XYZZ29_BYTES, st));
+    RT_CHECK(rt_memset(g.head_key.p, 0xFF, (size_t)T * 4, st));
+    RT_CHECK(rt_memset(g.tail_key.p, 0xFF, (size_t)T * 4, st));
+    RT_CHECK(rt_memset(heavy_count, 0, 16, st));
+    tm_mark("memset");
+    LAUNCH(k_digits32<FS>, ceil_div(n, 256), 256, 0, st, reinterpret_cast<const unsigned char *>(d_scalars), (uint32_t)n,
+           reinterpret_cast<int32_t *>(g.digits.p));
+    tm_mark("digits");
+    LAUNCH_BARRIER_FLEX(k_thist_coarse, dim3(ntiles, TABLE_W), 512, 0, st, reinterpret_cast<const int32_t *>(g.digits.p), (uint32_t)n, tile,
+                        reinterpret_cast<uint32_t *>(g.counts.p));
+    tm_mark("hist");
+    LAUNCH_BARRIER(k_scan_a, 1, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.counts.p), TABLE_CB, reinterpret_cast<uint32_t *>(g.block_sums.p));
+    LAUNCH_BARRIER(k_scan_b, 1, 1024, 0, st, reinterpret_cast<uint32_t *>(g.block_sums.p), 1u);
+    LAUNCH_BARRIER(k_scan_c, 1, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.counts.p), TABLE_CB,
+                   reinterpret_cast<const uint32_t *>(g.block_sums.p), reinterpret_cast<uint32_t *>(g.coarse_offsets.p),
+                   reinterpret_cast<uint32_t *>(g.cursor.p));
+    tm_mark("scan");
+    LAUNCH_BARRIER_FLEX(k_tpartition, dim3(ntiles, TABLE_W), 512, 0, st, reinterpret_cast<const int32_t *>(g.digits.p), (uint32_t)n,
+                        (uint32_t)bs.n, (uint32_t)first, tile, reinterpret_cast<uint32_t *>(g.cursor.p), reinterpret_cast<U2 *>(g.part.p));
+    tm_mark("partition");
+    LAUNCH_BARRIER_FLEX(k_tsort_fine, TABLE_CB, 1024, 0, st, reinterpret_cast<const U2 *>(g.part.p),
+                        reinterpret_cast<const uint32_t *>(g.coarse_offsets.p), reinterpret_cast<uint32_t *>(g.sorted_idx.p),
+                        reinterpret_cast<uint32_t *>(g.offsets.p));
+    tm_mark("sort_fine");
+    const uint32_t *total_ptr = reinterpret_cast<const uint32_t *>(g.offsets.p) + TABLE_B;
+    LAUNCH(k_plan, 1, 64, 0, st, total_ptr, lanes, Lmin, plan);
+    LAUNCH(k_accumulate<F>, ceil_div(T, 128), 128, 0, st, reinterpret_cast<const uint32_t *>(g.sorted_idx.p),
+           reinterpret_cast<const uint32_t *>(g.offsets.p), TABLE_B, reinterpret_cast<const unsigned char *>(bs.tables), (const uint32_t *)plan,
+           reinterpret_cast<unsigned char *>(g.bucket_sums.p), reinterpret_cast<unsigned char *>(g.head_part.p),
+           reinterpret_cast<uint32_t *>(g.head_key.p), reinterpret_cast<unsigned char *>(g.tail_part.p),
+           reinterpret_cast<uint32_t *>(g.tail_key.p));
+    tm_mark("accumulate");
+    LAUNCH(k_fixup<F>, ceil_div(T, 128), 128, 0, st, (const uint32_t *)plan, reinterpret_cast<const uint32_t *>(g.offsets.p),
+           reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
+           reinterpret_cast<const uint32_t *>(g.tail_key.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p), heavy_count, heavy_list, 0u);
+    LAUNCH_BARRIER(k_fixup_heavy<F>, FIXUP_HEAVY_GRID, FIXUP_BLOCK, 0, st, heavy_count, heavy_list,
+                   reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
+                   reinterpret_cast<unsigned char *>(g.bucket_sums.p));
+    tm_mark("fixup");
+    LAUNCH(k_reduce_chunks<F>, ceil_div(nchunks, 64), 64, 0, st, reinterpret_cast<const unsigned char *>(g.bucket_sums.p), TABLE_B, m, 1u,
+           reinterpret_cast<unsigned char *>(g.chunks.p));
+    tm_mark("reduce_chunks");
+    LAUNCH_BARRIER(k_window_sum<F>, TABLE_SUMS, WSUM_BLOCK, (size_t)WSUM_BLOCK * XYZZ29_BYTES, st,
+                   reinterpret_cast<const unsigned char *>(g.chunks.p), nchunks / TABLE_SUMS, reinterpret_cast<unsigned char *>(g.window_sums.p));
+    tm_mark("window_sum");
+    RT_CHECK(rt_last());
+    RT_CHECK(rt_d2h(host_sums, g.window_sums.p, (size_t)TABLE_SUMS * 128, st));
+    RT_CHECK(rt_sync(st));
+    tm_end();
     return MIRA_OK;
 }

@@ -1,0 +1,175 @@
+// Fixed-base ("window table") mode of the MSM, sized for 288 GB of HBM3E.
+//
+// The commitment key is immutable and reused by every fold step (reference
+// src/ivc/public_params.rs:50), so the engine may spend memory on it once: for a window width c it
+// keeps W = ceil(256 / c) tables T_w[i] = 2^(c w) * P_i (affine, 64 B, resident layout).  Then
+//     sum_i k_i P_i = sum_i sum_w d_{i,w} T_w[i]
+// needs ONE set of 2^(c-1) buckets instead of one per window.  With a single set the bucket
+// reduction stops growing with W, so c can rise from 16 to 20: 13 mixed additions per pair
+// instead of 16 (k_accumulate is 72 % of the step and ALU-bound), no host Horner, and the window
+// sums come back as 64 plain partial sums.  Cost: W x the key size in HBM (13 x 64 B per point:
+// 3.3 GiB at 2^22, 52 GiB at 2^26) and 12 x 20 doublings per point at registration.
+//
+// With 2^19 buckets the LDS histogram of the single-level sort no longer fits; the sort is
+// two-level: 512 coarse bins of 1024 buckets (tiles of 32k points give 64-entry runs per bin that
+// combine in L2), then each coarse bin's ~100k entries by fine key, which also emits the offsets.
+#pragma once
+#include "curve29.cuh"
+
+static constexpr uint32_t TABLE_C = 20;                  // window width of table mode
+static constexpr uint32_t TABLE_W = 13;                  // ceil(256 / 20)
+static constexpr uint32_t TABLE_B = 1u << (TABLE_C - 1); // buckets (signed digits)
+static constexpr uint32_t TABLE_FINE_BITS = 10;
+static constexpr uint32_t TABLE_CB = TABLE_B >> TABLE_FINE_BITS;   // 512 coarse bins of 1024 buckets
+static constexpr uint32_t TABLE_SUMS = 64;               // partial sums returned to the host
+
+// a^(P-2) on loose values (any input bound <= 12: every intermediate is a product < 2 P)
+template <class F> HD Fe29<F> f29_inv(const Fe29<F> &a) {
+    Fe29<F> acc = f29_one<F>(), base = f29_mul(a, f29_one<F>());   // bring the bound down to < 2
+    // exponent P - 2, little-endian 29-bit limbs of P (P[0] is odd and > 2: no borrow)
+#pragma unroll 1
+    for (int i = 0; i < 9; i++) {
+        uint32_t e = F::P[i] - (i == 0 ? 2u : 0u);
+        const int bits = (i < 8) ? 29 : 22;              // P < 2^254 = 2^(8*29 + 22)
+#pragma unroll 1
+        for (int k = 0; k < bits; k++) {
+            if ((e >> k) & 1) acc = f29_mul(acc, base);
+            base = f29_sqr(base);
+        }
+    }
+    return acc;
+}
+
+// dst[i] = 2^c * src[i]  (affine resident layout in and out; identity stays identity)
+template <class F>
+KERNEL void __launch_bounds__(64) k_table_step(const unsigned char *__restrict__ src, unsigned char *__restrict__ dst, uint64_t n, uint32_t c) {
+    using S = typename F::Sat;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Aff29<F> p = aff29_load<F>(src + i * 64, false);
+    if (aff29_is_identity(p)) {
+        fe_store(dst + i * 64, fe_zero<S>()); fe_store(dst + i * 64 + 32, fe_zero<S>());
+        return;
+    }
+    Xyzz29<F> q = xyzz29_double_affine(p);
+    for (uint32_t k = 1; k < c; k++) q = xyzz29_double(q);
+    Fe<S> x = fe_zero<S>(), y = fe_zero<S>();
+    if (!xyzz29_is_identity(q)) {
+        Fe29<F> zi = f29_inv(q.zzz);                      // 1 / ZZZ
+        Fe29<F> zzi = f29_sqr(f29_mul(zi, q.zz));         // (ZZ / ZZZ)^2 = 1 / ZZ
+        x = reduce_once(f29_pack(f29_mul(q.x, zzi)));
+        y = reduce_once(f29_pack(f29_mul(q.y, zi)));
+    }
+    fe_store(dst + i * 64, x);
+    fe_store(dst + i * 64 + 32, y);
+}
+
+// scalar -> 13 signed 20-bit digits, window-major int32
+template <class FS>
+KERNEL void k_digits32(const unsigned char *__restrict__ scalars, uint32_t n, int32_t *__restrict__ digits) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fe<FS> s = fe_from_mont(fe_load<FS>(scalars + (size_t)i * 32));
+    const uint32_t mask = (1u << TABLE_C) - 1u, half = 1u << (TABLE_C - 1);
+    uint32_t carry = 0;
+    for (uint32_t w = 0; w < TABLE_W; w++) {
+        uint32_t raw = (s.l[0] & mask) + carry;
+#pragma unroll
+        for (int k = 0; k < 7; k++) s.l[k] = (s.l[k] >> TABLE_C) | (s.l[k + 1] << (32 - TABLE_C));
+        s.l[7] >>= TABLE_C;
+        int32_t d;
+        if (raw >= half) { d = (int32_t)raw - (int32_t)(1u << TABLE_C); carry = 1; }
+        else { d = (int32_t)raw; carry = 0; }
+        digits[(size_t)w * n + i] = d;
+    }
+}
+
+// level 1: grid = (ntiles, TABLE_W); LDS = TABLE_CB counters
+KERNEL void k_thist_coarse(const int32_t *__restrict__ digits, uint32_t n, uint32_t tile, uint32_t *__restrict__ counts) {
+    __shared__ uint32_t bins[TABLE_CB];
+    const uint32_t w = blockIdx.y;
+    for (uint32_t b = threadIdx.x; b < TABLE_CB; b += blockDim.x) bins[b] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * tile, end = (base + tile < n) ? base + tile : n;
+    const int32_t *dw = digits + (size_t)w * n;
+    for (uint32_t i = base + threadIdx.x; i < end; i += blockDim.x) {
+        int32_t d = dw[i];
+        if (d != 0) atomicAdd(&bins[((uint32_t)(d < 0 ? -d : d) - 1) >> TABLE_FINE_BITS], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < TABLE_CB; b += blockDim.x) {
+        uint32_t cnt = bins[b];
+        if (cnt) atomicAdd(&counts[b], cnt);
+    }
+}
+// entries: x = table index (w * N + first + i) | sign << 31, y = bucket.  N = registered key length,
+// first = offset of this MSM's bases inside the key (point-chunk sharding).
+KERNEL void k_tpartition(const int32_t *__restrict__ digits, uint32_t n, uint32_t N, uint32_t first, uint32_t tile,
+                         uint32_t *__restrict__ cursor, U2 *__restrict__ part) {
+    __shared__ uint32_t bins[TABLE_CB];
+    const uint32_t w = blockIdx.y;
+    for (uint32_t b = threadIdx.x; b < TABLE_CB; b += blockDim.x) bins[b] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * tile, end = (base + tile < n) ? base + tile : n;
+    const int32_t *dw = digits + (size_t)w * n;
+    for (uint32_t i = base + threadIdx.x; i < end; i += blockDim.x) {
+        int32_t d = dw[i];
+        if (d != 0) atomicAdd(&bins[((uint32_t)(d < 0 ? -d : d) - 1) >> TABLE_FINE_BITS], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < TABLE_CB; b += blockDim.x) {
+        uint32_t cnt = bins[b];
+        if (cnt) bins[b] = atomicAdd(&cursor[b], cnt);
+    }
+    __syncthreads();
+    for (uint32_t i = base + threadIdx.x; i < end; i += blockDim.x) {
+        int32_t d = dw[i];
+        if (d != 0) {
+            uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1;
+            uint32_t pos = atomicAdd(&bins[b >> TABLE_FINE_BITS], 1u);
+            part[pos] = U2{(w * N + first + i) | (d < 0 ? 0x80000000u : 0u), b};
+        }
+    }
+}
+// level 2: workgroups walk the coarse bins; bucket id of fine key f in bin g is g * 1024 + f.
+// blockDim.x <= 1024.
+KERNEL void __launch_bounds__(1024) k_tsort_fine(const U2 *__restrict__ part, const uint32_t *__restrict__ coarse_offsets,
+                         uint32_t *__restrict__ sorted, uint32_t *__restrict__ offsets) {
+    constexpr uint32_t F = 1u << TABLE_FINE_BITS;
+    __shared__ uint32_t cnt[F];
+    __shared__ uint32_t cur[F];
+    for (uint32_t g = blockIdx.x; g < TABLE_CB; g += gridDim.x) {
+        const uint32_t base = coarse_offsets[g], endp = coarse_offsets[g + 1];
+        for (uint32_t f = threadIdx.x; f < F; f += blockDim.x) cnt[f] = 0;
+        __syncthreads();
+        for (uint32_t p = base + threadIdx.x; p < endp; p += blockDim.x) atomicAdd(&cnt[part[p].y & (F - 1)], 1u);
+        __syncthreads();
+        // exclusive scan of the F counters: per-lane chunk sums, one serial pass over the (<= 1024)
+        // chunk sums, then each lane rewrites its chunk as running cursors.  Any blockDim works.
+        const uint32_t per = (F + blockDim.x - 1) / blockDim.x;
+        const uint32_t lo = (threadIdx.x * per < F) ? threadIdx.x * per : F, hi = (lo + per < F) ? lo + per : F;
+        uint32_t s = 0;
+        for (uint32_t f = lo; f < hi; f++) s += cnt[f];
+        cur[threadIdx.x] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t run = 0;
+            for (uint32_t t = 0; t < blockDim.x; t++) { uint32_t v = cur[t]; cur[t] = run; run += v; }
+        }
+        __syncthreads();
+        uint32_t run = base + cur[threadIdx.x];
+        for (uint32_t f = lo; f < hi; f++) {
+            uint32_t c = cnt[f];
+            offsets[(size_t)g * F + f] = run;
+            cnt[f] = run;                                  // cnt[] now holds the running cursors
+            run += c;
+        }
+        if (g == TABLE_CB - 1 && threadIdx.x == 0) offsets[TABLE_B] = endp;
+        __syncthreads();
+        for (uint32_t p = base + threadIdx.x; p < endp; p += blockDim.x) {
+            U2 e = part[p];
+            sorted[atomicAdd(&cnt[e.y & (F - 1)], 1u)] = e.x;
+        }
+        __syncthreads();
+    }
+}

@@ -51,34 +51,39 @@ template <class F> void emu_launch(bool barrier, dim3 grid, dim3 block, size_t s
     gridDim = grid; blockDim = block;
     std::vector<unsigned char> sh(shmem + 16);
     emu_dyn_shared = sh.data();
-    unsigned nthreads = block.x * block.y * block.z;
-    for (unsigned bz = 0; bz < grid.z; bz++)
-        for (unsigned by = 0; by < grid.y; by++)
-            for (unsigned bx = 0; bx < grid.x; bx++) {
-                if (!barrier) {
-                    emu_barrier = nullptr;
+    const unsigned nthreads = block.x * block.y * block.z;
+    auto tid3 = [&](unsigned t) { return dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y)); };
+    if (!barrier) {
+        emu_barrier = nullptr;
+        for (unsigned bz = 0; bz < grid.z; bz++)
+            for (unsigned by = 0; by < grid.y; by++)
+                for (unsigned bx = 0; bx < grid.x; bx++) {
                     blockIdx = dim3(bx, by, bz);
-                    for (unsigned t = 0; t < nthreads; t++) {
-                        threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
-                        body();
-                    }
-                } else {
-                    pthread_barrier_t bar;
-                    pthread_barrier_init(&bar, nullptr, nthreads);
-                    emu_barrier = &bar;
-                    std::vector<std::thread> th;
-                    th.reserve(nthreads);
-                    for (unsigned t = 0; t < nthreads; t++)
-                        th.emplace_back([&, t] {
-                            blockIdx = dim3(bx, by, bz);
-                            threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
-                            body();
-                        });
-                    for (auto &x : th) x.join();
-                    pthread_barrier_destroy(&bar);
-                    emu_barrier = nullptr;
+                    for (unsigned t = 0; t < nthreads; t++) { threadIdx = tid3(t); body(); }
                 }
-            }
+        return;
+    }
+    // barrier kernels: one OS thread per lane, created once per launch; the lanes walk the blocks
+    // together (a block is finished by every lane before the next one starts, as LDS is reused)
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, nullptr, nthreads);
+    emu_barrier = &bar;
+    std::vector<std::thread> th;
+    th.reserve(nthreads);
+    for (unsigned t = 0; t < nthreads; t++)
+        th.emplace_back([&, t] {
+            threadIdx = tid3(t);
+            for (unsigned bz = 0; bz < grid.z; bz++)
+                for (unsigned by = 0; by < grid.y; by++)
+                    for (unsigned bx = 0; bx < grid.x; bx++) {
+                        blockIdx = dim3(bx, by, bz);
+                        body();
+                        pthread_barrier_wait(&bar);
+                    }
+        });
+    for (auto &x : th) x.join();
+    pthread_barrier_destroy(&bar);
+    emu_barrier = nullptr;
 }
 #define LAUNCH(kern, grid, block, shmem, stream, ...) \
     emu_launch(false, dim3(grid), dim3(block), (shmem), [&] { kern(__VA_ARGS__); })

@@ -45,7 +45,7 @@ def test_emu_commit_is_homomorphic_over_fold(emu_lib):
     """is_sat_relaxed's check (src/plonk/mod.rs:547-557): the commitment of the folded witness
     equals the folded commitment -- with every piece coming from this library."""
     for cid, field in ((0, 1), (1, 0)):
-        n = 200
+        n = 64
         bases = C.synth_bases(cid, n, seed=3)
         key = cm.CommitmentKey(cid, bases, lib=emu_lib)
         w1, w2 = C.synth_scalars(cid, n, seed=7, kind=1), C.synth_scalars(cid, n, seed=8)

@@ -187,3 +187,25 @@ def test_commit_batch_chunking(gpu_lib):
         gpu_lib.check(gpu_lib.c.mira_msm_set_window_bits(0))
     for i, v in enumerate(vs):
         assert (got[i] == C.commit(cid, bases, v)).all()
+
+
+@pytest.mark.parametrize("cid,log_n", [(0, 20), (1, 18)])
+def test_fixed_base_tables(gpu_lib, cid, log_n):
+    """mira_msm_precompute (window tables in HBM, 2^19 shared buckets): bit-identical to the
+    per-window path and the oracle; partials over the tables combine to the whole."""
+    n = 1 << log_n
+    key = cm.CommitmentKey.synthetic(cid, n, seed=93)
+    d = cm.synth_scalars_device(cid, n, seed=94)
+    dw = cm.synth_scalars_device(cid, n, seed=95, kind=1)
+    before, before_w = key.commit_device(d, n), key.commit_device(dw, n)
+    key.precompute()
+    assert (key.commit_device(d, n) == before).all()
+    assert (key.commit_device(dw, n) == before_w).all()
+    assert (before == C.commit(cid, key.bases(), gpu_lib.download(d, (n, 4)))).all()
+    h = n // 2 + 12345
+    pa, ca, wa = key.commit_partial_device(0, d, h)
+    pb, cb, wb = key.commit_partial_device(h, d + h * 32, n - h)
+    assert (ca, wa) == (0, 64) == (cb, wb)
+    assert (cm.combine_partials(cid, np.stack([pa, pb]), ca, wa) == before).all()
+    m = (1 << 18) + 777                                  # a prefix of the key, still table mode
+    assert (key.commit_device(d, m) == C.commit(cid, key.bases()[:m], gpu_lib.download(d, (m, 4)))).all()

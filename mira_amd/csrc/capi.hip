@@ -165,8 +165,11 @@ static void sum_partials(const uint64_t *partials, size_t nparts, uint32_t W, ui
     }
 }
 
+// sharded: the caller is one rank of a point-chunk sharded MSM.  All ranks must produce the same
+// kind of partial, so the choice between table and per-window mode then depends only on whether
+// the handle has tables (and on the forced width), never on this rank's chunk length.
 static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scalars, size_t n, uint64_t *out_partial,
-                              uint32_t *c_out, uint32_t *W_out) {
+                              uint32_t *c_out, uint32_t *W_out, bool sharded = false) {
     int rc = ensure_ctx();
     if (rc) return rc;
     auto it = g_bases.find(handle);
@@ -185,7 +188,7 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
     if (!d_scalars) { set_error("null scalars"); return MIRA_E_BAD_ARG; }
     // fixed-base mode: window tables present, MSM large enough to be throughput-bound, no forced width
     const size_t table_min_n = getenv("MIRA_TABLE_MIN_N") ? (size_t)atoll(getenv("MIRA_TABLE_MIN_N")) : TABLE_MIN_N;   // tests lower it
-    if (bs.tables && n >= table_min_n && g.forced_c == 0) {
+    if (bs.tables && (sharded || n >= table_min_n) && g.forced_c == 0) {
         *c_out = 0; *W_out = 64;                            // 64 partial sums, combined by a plain sum
         return bs.curve == MIRA_CURVE_BN256 ? msm_launch_table_bn256(bs, first, d_scalars, n, out_partial)
                                              : msm_launch_table_grumpkin(bs, first, d_scalars, n, out_partial);
@@ -446,7 +449,7 @@ int mira_msm_partial_device(uint64_t handle, size_t first, const void *d_scalars
     std::lock_guard<std::mutex> lk(g_lock);
     if (!out_partial || !window_bits || !num_windows) { set_error("null output"); return MIRA_E_BAD_ARG; }
     uint32_t c, W;
-    int rc = msm_partial_locked(handle, first, d_scalars, n, out_partial, &c, &W);
+    int rc = msm_partial_locked(handle, first, d_scalars, n, out_partial, &c, &W, true);
     if (rc) return rc;
     *window_bits = (int32_t)c; *num_windows = (int32_t)W;
     return MIRA_OK;

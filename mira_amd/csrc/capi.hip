@@ -17,6 +17,7 @@ void set_error(const std::string &s) { g_err = s; }
 static std::mutex g_lock;
 Ctx g;
 static std::map<uint64_t, Bases> g_bases;
+static constexpr size_t PLAN_HIST_MIN_N = (size_t)1 << 15;  // below this the pre-pass (one extra sync) costs more than it can save
 static constexpr size_t TABLE_MIN_N = (size_t)1 << 18;   // below this an MSM is latency-bound and the per-window path is as fast
 
 // constants block on device: [0] gen bn256 (64 B, R form) [64] gen grumpkin (64 B, R form)
@@ -107,13 +108,21 @@ static int upload_consts() {
 // ------------------------------------------------------------------------------------------
 // MSM plan
 
-static MsmPlan make_plan(size_t n, int32_t forced_c, uint32_t count = 1, uint64_t stride = 0) {
+static MsmPlan make_plan(size_t n, int32_t forced_c, uint32_t count = 1, uint64_t stride = 0, const uint32_t *bitlen_hist = nullptr) {
     MsmPlan p;
     uint32_t best_c = 4;
     double best = 1e300;
     for (uint32_t c = 4; c <= 16; c++) {
         double W = std::ceil(256.0 / c);
-        double cost = (double)n * W + 6.0 * W * (double)(1u << (c - 1));
+        // bucket additions: one per non-zero digit.  Dense estimate n * W, or, with the bit-length
+        // histogram of the actual scalars (summed over the batch), ceil(len / c) digits each.
+        double adds = (double)n * W;
+        if (bitlen_hist) {
+            adds = 0;
+            for (uint32_t len = 1; len < 256; len++) adds += (double)bitlen_hist[len] * std::ceil((double)len / c);
+            adds /= count;
+        }
+        double cost = adds + 6.0 * W * (double)(1u << (c - 1));
         if (cost < best) { best = cost; best_c = c; }
     }
     p.c = forced_c ? (uint32_t)forced_c : best_c;
@@ -179,7 +188,18 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
         set_error("Can't commit too long input: input len: " + std::to_string(first + n) + ", but limit is " + std::to_string(bs.n));
         return MIRA_E_TOO_LONG;
     }
-    MsmPlan p = make_plan(n, g.forced_c);
+    const size_t table_min_n = getenv("MIRA_TABLE_MIN_N") ? (size_t)atoll(getenv("MIRA_TABLE_MIN_N")) : TABLE_MIN_N;   // tests lower it
+    const bool table_mode = bs.tables && (sharded || n >= table_min_n) && g.forced_c == 0;
+    // data-dependent planning for single (unsharded) commits: ranks of a sharded MSM must agree on
+    // the window width, so they keep the dense estimate
+    uint32_t hist[256];
+    const size_t hist_min_n = getenv("MIRA_PLAN_HIST_MIN_N") ? (size_t)atoll(getenv("MIRA_PLAN_HIST_MIN_N")) : PLAN_HIST_MIN_N;   // tests lower it
+    const bool use_hist = !table_mode && !sharded && g.forced_c == 0 && n >= hist_min_n && d_scalars;
+    if (use_hist) {
+        int rc2 = bs.curve == MIRA_CURVE_BN256 ? scalar_bitlen_hist_bn256(d_scalars, n, 1, n, hist) : scalar_bitlen_hist_grumpkin(d_scalars, n, 1, n, hist);
+        if (rc2) return rc2;
+    }
+    MsmPlan p = make_plan(n, g.forced_c, 1, 0, use_hist ? hist : nullptr);
     if (n >= (1ull << 31) || (uint64_t)n * p.W >= (1ull << 32)) { set_error("n too large for 32-bit entry offsets"); return MIRA_E_UNSUPPORTED; }
     if (p.W > MIRA_MAX_WINDOWS) { set_error("window configuration exceeds MIRA_MAX_WINDOWS"); return MIRA_E_UNSUPPORTED; }
     *c_out = p.c; *W_out = p.W;
@@ -187,8 +207,7 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
     if (n == 0) return MIRA_OK;
     if (!d_scalars) { set_error("null scalars"); return MIRA_E_BAD_ARG; }
     // fixed-base mode: window tables present, MSM large enough to be throughput-bound, no forced width
-    const size_t table_min_n = getenv("MIRA_TABLE_MIN_N") ? (size_t)atoll(getenv("MIRA_TABLE_MIN_N")) : TABLE_MIN_N;   // tests lower it
-    if (bs.tables && (sharded || n >= table_min_n) && g.forced_c == 0) {
+    if (table_mode) {
         *c_out = 0; *W_out = 64;                            // 64 partial sums, combined by a plain sum
         return bs.curve == MIRA_CURVE_BN256 ? msm_launch_table_bn256(bs, first, d_scalars, n, out_partial)
                                              : msm_launch_table_grumpkin(bs, first, d_scalars, n, out_partial);

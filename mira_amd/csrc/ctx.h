@@ -79,7 +79,7 @@ struct Ctx {
     Timing tm;
     // MSM workspace (grow-only, shared by all handles: calls are serialised by the ABI lock)
     DevBuf digits, counts, offsets, cursor, block_sums, sorted_idx, sorted_key, bucket_sums, part, coarse_offsets;
-    DevBuf head_part, tail_part, head_key, tail_key, heavy, chunks, window_sums, scalars_stage, consts;
+    DevBuf head_part, tail_part, head_key, tail_key, heavy, heavy_out, chunks, window_sums, scalars_stage, consts;
     // NTT workspace
     DevBuf ntt_tmp, ntt_stage, ntt_tables, ntt_consts;
     DevBuf fold_consts;
@@ -117,6 +117,8 @@ int msm_launch_table_bn256(const Bases &bs, size_t first, const void *d_scalars,
 int msm_launch_table_grumpkin(const Bases &bs, size_t first, const void *d_scalars, size_t n, uint64_t *host_sums);
 int build_tables_bn256(Bases &bs);
 int build_tables_grumpkin(Bases &bs);
+int scalar_bitlen_hist_bn256(const void *d_scalars, size_t n, size_t count, size_t stride, uint32_t host_hist[256]);
+int scalar_bitlen_hist_grumpkin(const void *d_scalars, size_t n, size_t count, size_t stride, uint32_t host_hist[256]);
 int curve_init_bn256();
 int convert_bases_bn256(const void *d_src, void *d_dst, size_t n);
 int convert_bases_grumpkin(const void *d_src, void *d_dst, size_t n);

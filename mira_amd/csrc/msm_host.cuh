@@ -8,7 +8,7 @@
 #ifdef MIRA_CPU_EMU
 static constexpr uint32_t FIXUP_HEAVY_GRID = 4;     // emulated lanes are OS threads: keep the idle grid small
 #else
-static constexpr uint32_t FIXUP_HEAVY_GRID = 256;
+static constexpr uint32_t FIXUP_HEAVY_GRID = 4096;   // waves; idle ones leave at once
 #endif
 
 template <class F, class FS>
@@ -29,21 +29,23 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size
     if ((rc = g.tail_part.ensure((size_t)p.T * XYZZ29_BYTES))) return rc;
     if ((rc = g.head_key.ensure((size_t)p.T * 4))) return rc;
     if ((rc = g.tail_key.ensure((size_t)p.T * 4))) return rc;
-    if ((rc = g.heavy.ensure(((size_t)p.T * 3 + 4) * 4))) return rc;
+    if ((rc = g.heavy.ensure(64 + ((size_t)p.T / 2 + 8) * 32))) return rc;            // counters, runs, sub-job descriptors
+    if ((rc = g.heavy_out.ensure(((size_t)p.T / 2 + 8) * XYZZ29_BYTES))) return rc;
     if ((rc = g.chunks.ensure((size_t)p.Wt * p.nchunks * XYZZ29_BYTES))) return rc;
     if ((rc = g.window_sums.ensure((size_t)p.Wt * 128))) return rc;
 
     hipStream_t st = g.stream;
     const unsigned char *bases = reinterpret_cast<const unsigned char *>(bs.d) + first * 64;
-    uint32_t *heavy_count = reinterpret_cast<uint32_t *>(g.heavy.p);
-    uint32_t *heavy_list = heavy_count + 4;
+    uint32_t *heavy_count = reinterpret_cast<uint32_t *>(g.heavy.p);          // [0] runs, [1] sub-jobs, [2..3] plan
+    U4 *heavy_runs = reinterpret_cast<U4 *>(heavy_count + 16);
+    U4 *heavy_subs = heavy_runs + ((size_t)p.T / 4 + 4);
 
     tm_begin();
     RT_CHECK(rt_memset(g.counts.p, 0, ((size_t)p.NB + 1) * 4, st));
     RT_CHECK(rt_memset(g.bucket_sums.p, 0, (size_t)p.NB * XYZZ29_BYTES, st));
     RT_CHECK(rt_memset(g.head_key.p, 0xFF, (size_t)p.T * 4, st));
     RT_CHECK(rt_memset(g.tail_key.p, 0xFF, (size_t)p.T * 4, st));
-    RT_CHECK(rt_memset(heavy_count, 0, 16, st));
+    RT_CHECK(rt_memset(heavy_count, 0, 64, st));
     tm_mark("memset");
 
     LAUNCH(k_digits<FS>, dim3(ceil_div(n, 256), p.count), 256, 0, st, reinterpret_cast<const unsigned char *>(d_scalars), (uint32_t)n, (uint64_t)p.stride, p.c, p.W,
@@ -73,10 +75,11 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size
     tm_mark("accumulate");
     LAUNCH(k_fixup<F>, ceil_div(p.T, 128), 128, 0, st, (const uint32_t *)plan, reinterpret_cast<const uint32_t *>(g.offsets.p),
            reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
-           reinterpret_cast<const uint32_t *>(g.tail_key.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p), heavy_count, heavy_list,
-           (uint32_t)(getenv("MIRA_FIXUP_DEBUG") ? atoi(getenv("MIRA_FIXUP_DEBUG")) : 0));
-    LAUNCH_BARRIER(k_fixup_heavy<F>, FIXUP_HEAVY_GRID, FIXUP_BLOCK, 0, st, heavy_count, heavy_list,
-                   reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
+           reinterpret_cast<const uint32_t *>(g.tail_key.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p), heavy_count, heavy_runs, heavy_subs);
+    LAUNCH_BARRIER(k_fixup_heavy_a<F>, FIXUP_HEAVY_GRID, HEAVY_BLOCK, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_subs,
+                   reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<unsigned char *>(g.heavy_out.p));
+    LAUNCH_BARRIER(k_fixup_heavy_b<F>, FIXUP_HEAVY_GRID, HEAVY_BLOCK, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_runs,
+                   reinterpret_cast<const unsigned char *>(g.heavy_out.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
                    reinterpret_cast<unsigned char *>(g.bucket_sums.p));
     tm_mark("fixup");
     LAUNCH(k_reduce_chunks<F>, ceil_div((uint64_t)p.Wt * p.nchunks, 64), 64, 0, st,
@@ -178,13 +181,16 @@ static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars
     if ((rc = g.tail_part.ensure((size_t)T * XYZZ29_BYTES))) return rc;
     if ((rc = g.head_key.ensure((size_t)T * 4))) return rc;
     if ((rc = g.tail_key.ensure((size_t)T * 4))) return rc;
-    if ((rc = g.heavy.ensure(((size_t)T * 3 + 4) * 4))) return rc;
+    if ((rc = g.heavy.ensure(64 + ((size_t)T / 2 + 8) * 32))) return rc;
+    if ((rc = g.heavy_out.ensure(((size_t)T / 2 + 8) * XYZZ29_BYTES))) return rc;
     if ((rc = g.chunks.ensure((size_t)nchunks * XYZZ29_BYTES))) return rc;
     if ((rc = g.window_sums.ensure((size_t)TABLE_SUMS * 128))) return rc;
 
     hipStream_t st = g.stream;
     uint32_t *heavy_count = reinterpret_cast<uint32_t *>(g.heavy.p);
-    uint32_t *heavy_list = heavy_count + 4, *plan = heavy_count + 2;
+    uint32_t *plan = heavy_count + 2;
+    U4 *heavy_runs = reinterpret_cast<U4 *>(heavy_count + 16);
+    U4 *heavy_subs = heavy_runs + ((size_t)T / 4 + 4);
     // level-1 tiles of 32k points: runs of ~64 entries per (workgroup, coarse bin)
     const uint32_t tile = 32768, ntiles = ceil_div(n, tile);
     tm_begin();
@@ -192,7 +198,7 @@ static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars
     RT_CHECK(rt_memset(g.bucket_sums.p, 0, (size_t)TABLE_B * XYZZ29_BYTES, st));
     RT_CHECK(rt_memset(g.head_key.p, 0xFF, (size_t)T * 4, st));
     RT_CHECK(rt_memset(g.tail_key.p, 0xFF, (size_t)T * 4, st));
-    RT_CHECK(rt_memset(heavy_count, 0, 16, st));
+    RT_CHECK(rt_memset(heavy_count, 0, 64, st));
     tm_mark("memset");
     LAUNCH(k_digits32<FS>, ceil_div(n, 256), 256, 0, st, reinterpret_cast<const unsigned char *>(d_scalars), (uint32_t)n,
            reinterpret_cast<int32_t *>(g.digits.p));
@@ -223,9 +229,11 @@ static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars
     tm_mark("accumulate");
     LAUNCH(k_fixup<F>, ceil_div(T, 128), 128, 0, st, (const uint32_t *)plan, reinterpret_cast<const uint32_t *>(g.offsets.p),
            reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
-           reinterpret_cast<const uint32_t *>(g.tail_key.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p), heavy_count, heavy_list, 0u);
-    LAUNCH_BARRIER(k_fixup_heavy<F>, FIXUP_HEAVY_GRID, FIXUP_BLOCK, 0, st, heavy_count, heavy_list,
-                   reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
+           reinterpret_cast<const uint32_t *>(g.tail_key.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p), heavy_count, heavy_runs, heavy_subs);
+    LAUNCH_BARRIER(k_fixup_heavy_a<F>, FIXUP_HEAVY_GRID, HEAVY_BLOCK, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_subs,
+                   reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<unsigned char *>(g.heavy_out.p));
+    LAUNCH_BARRIER(k_fixup_heavy_b<F>, FIXUP_HEAVY_GRID, HEAVY_BLOCK, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_runs,
+                   reinterpret_cast<const unsigned char *>(g.heavy_out.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
                    reinterpret_cast<unsigned char *>(g.bucket_sums.p));
     tm_mark("fixup");
     LAUNCH(k_reduce_chunks<F>, ceil_div(nchunks, 64), 64, 0, st, reinterpret_cast<const unsigned char *>(g.bucket_sums.p), TABLE_B, m, 1u,
@@ -238,5 +246,19 @@ static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars
     RT_CHECK(rt_d2h(host_sums, g.window_sums.p, (size_t)TABLE_SUMS * 128, st));
     RT_CHECK(rt_sync(st));
     tm_end();
+    return MIRA_OK;
+}
+
+// bit-length histogram of `count` scalar vectors (planning pre-pass; one small D2H + sync)
+template <class FS> static int scalar_bitlen_hist(const void *d_scalars, size_t n, size_t count, size_t stride, uint32_t host_hist[256]) {
+    int rc;
+    if ((rc = g.block_sums.ensure(1024 * 4))) return rc;
+    RT_CHECK(rt_memset(g.block_sums.p, 0, 1024, g.stream));
+    const uint32_t blocks = std::min<uint32_t>(1024, ceil_div(n, 256));
+    LAUNCH_BARRIER_FLEX(k_bitlen_hist<FS>, dim3(blocks, (uint32_t)count), 256, 0, g.stream, reinterpret_cast<const unsigned char *>(d_scalars),
+                        (uint32_t)n, (uint64_t)stride, reinterpret_cast<uint32_t *>(g.block_sums.p));
+    RT_CHECK(rt_last());
+    RT_CHECK(rt_d2h(host_hist, g.block_sums.p, 1024, g.stream));
+    RT_CHECK(rt_sync(g.stream));
     return MIRA_OK;
 }

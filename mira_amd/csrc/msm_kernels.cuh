@@ -15,7 +15,7 @@
 //                 skewed the scalars are); complete bucket runs go straight to bucket_sums, runs
 //                 cut by a lane boundary leave a head/tail partial
 //   k_fixup*      joins the partials: short chains by one lane, long chains (heavy buckets such as
-//                 "all witness cells equal 1") by a workgroup-wide strided sum + LDS tree
+//                 "all witness cells equal 1") by two levels of workgroup LDS trees
 //   k_reduce_chunks / k_window_sum   sum_b (b+1) * S_b per window by chunked running sums
 // Host: Horner over the W window sums and the single inversion of to_affine().
 #pragma once
@@ -26,6 +26,30 @@ static constexpr uint32_t KEY_NONE = 0xFFFFFFFFu;
 static constexpr int HEAVY_SPAN = 6;        // chains longer than this go to k_fixup_heavy (a lane adds ~6.6 us per link)
 static constexpr int FIXUP_BLOCK = 256;
 static constexpr int WSUM_BLOCK = 512;       // k_window_sum: 512 lanes x 144 B = 72 KiB of LDS (1024 lanes would cap VGPRs at 128 and spill)
+
+// ------------------------------------------------------------------------------------------
+// Planning pre-pass: histogram of the bit lengths of the canonical scalars (hist[0] = zeros,
+// hist[b] = scalars with top set bit b-1).  Witness vectors are mostly zeros and small values
+// (SURVEY.md 7 "bucket contention"; src/util.rs:189-193 zero-pads every column), so the number
+// of non-zero digits -- and with it the best window width -- depends on the data.
+template <class FS>
+KERNEL void k_bitlen_hist(const unsigned char *__restrict__ scalars, uint32_t n, uint64_t stride, uint32_t *__restrict__ hist) {
+    __shared__ uint32_t bins[256];
+    for (uint32_t b = threadIdx.x; b < 256; b += blockDim.x) bins[b] = 0;
+    __syncthreads();
+    scalars += (size_t)blockIdx.y * stride * 32;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        Fe<FS> s = fe_from_mont(fe_load<FS>(scalars + (size_t)i * 32));
+        uint32_t len = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (s.l[k]) len = 32u * k + (32u - (uint32_t)__builtin_clz(s.l[k]));
+        atomicAdd(&bins[len > 255 ? 255 : len], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < 256; b += blockDim.x)
+        if (bins[b]) atomicAdd(&hist[b], bins[b]);
+}
 
 // ------------------------------------------------------------------------------------------
 template <class FS>
@@ -289,12 +313,18 @@ KERNEL void __launch_bounds__(128) k_accumulate(const uint32_t *__restrict__ sor
     else xyzz29_store(bucket_sums + (size_t)cur * XYZZ29_BYTES, acc);
 }
 
-// One lane per k_accumulate lane that owns the start of a cut run.
+// One lane per k_accumulate lane that owns the start of a cut run.  Short chains are summed here;
+// a chain longer than HEAVY_SPAN partials (a heavy bucket: the carry bucket of small witness
+// values, a column of ones, the sparse top window) is cut into sub-jobs of HEAVY_SUB partials for
+// the two workgroup-parallel kernels below, so its cost is two LDS trees whatever its length.
+// heavy_ctr = {runs, sub-jobs}; runs[h] = {lane, span, bucket, first sub-job}; subs[s] = {first
+// partial, count, run, -}.
+static constexpr uint32_t HEAVY_SUB = 256;
 template <class F>
 KERNEL void __launch_bounds__(128) k_fixup(const uint32_t *__restrict__ plan, const uint32_t *__restrict__ offsets,
                     const unsigned char *__restrict__ head_part, const unsigned char *__restrict__ tail_part,
                     const uint32_t *__restrict__ tail_key, unsigned char *__restrict__ bucket_sums,
-                    uint32_t *__restrict__ heavy_count, uint32_t *__restrict__ heavy_list, uint32_t dbg) {
+                    uint32_t *__restrict__ heavy_ctr, U4 *__restrict__ runs, U4 *__restrict__ subs) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t L = plan[0], T = plan[1];
     if (t >= T) return;
@@ -303,44 +333,70 @@ KERNEL void __launch_bounds__(128) k_fixup(const uint32_t *__restrict__ plan, co
     const uint32_t run_end = offsets[key + 1];
     const uint32_t span = (run_end - 1) / L - t;   // lanes t+1 .. t+span hold head partials of this run
     if (span > (uint32_t)HEAVY_SPAN) {
-        uint32_t h = atomicAdd(heavy_count, 1u);
-        heavy_list[3 * h] = t; heavy_list[3 * h + 1] = span; heavy_list[3 * h + 2] = key;
+        const uint32_t nsub = (span + HEAVY_SUB - 1) / HEAVY_SUB;
+        const uint32_t h = atomicAdd(&heavy_ctr[0], 1u);
+        const uint32_t base = atomicAdd(&heavy_ctr[1], nsub);
+        runs[h] = U4{t, span, key, base};
+        for (uint32_t s = 0; s < nsub; s++) {
+            const uint32_t first = t + 1 + s * HEAVY_SUB;
+            const uint32_t cnt = (span - s * HEAVY_SUB < HEAVY_SUB) ? span - s * HEAVY_SUB : HEAVY_SUB;
+            subs[base + s] = U4{first, cnt, h, 0};
+        }
         return;
     }
     Xyzz29<F> acc = xyzz29_load<F>(tail_part + (size_t)t * XYZZ29_BYTES);
-    for (uint32_t q = 1; q <= span; q++) {
-        Xyzz29<F> hp = xyzz29_load<F>(head_part + (size_t)(t + q) * XYZZ29_BYTES);
-        if (dbg & 1u) { acc.x = f29_carry(f29_add(acc.x, hp.x)); F29_SET(acc.x, 9.0); }
-        else xyzz29_add(acc, hp);
-    }
-    if (!(dbg & 2u)) xyzz29_store(bucket_sums + (size_t)key * XYZZ29_BYTES, acc);
+    for (uint32_t q = 1; q <= span; q++) xyzz29_add(acc, xyzz29_load<F>(head_part + (size_t)(t + q) * XYZZ29_BYTES));
+    xyzz29_store(bucket_sums + (size_t)key * XYZZ29_BYTES, acc);
 }
 
-// Workgroup per heavy run (grid-stride over the list).  blockDim.x == FIXUP_BLOCK.
-template <class F>
-KERNEL void __launch_bounds__(256) k_fixup_heavy(const uint32_t *__restrict__ heavy_count, const uint32_t *__restrict__ heavy_list,
-                          const unsigned char *__restrict__ head_part, const unsigned char *__restrict__ tail_part,
-                          unsigned char *__restrict__ bucket_sums) {
-    __shared__ __attribute__((aligned(16))) unsigned char red[FIXUP_BLOCK * XYZZ29_BYTES];
-    const uint32_t nheavy = *heavy_count;
-    for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
-        const uint32_t t = heavy_list[3 * h], span = heavy_list[3 * h + 1], key = heavy_list[3 * h + 2];
-        Xyzz29<F> acc = xyzz29_identity<F>();
-        for (uint32_t q = threadIdx.x; q < span; q += blockDim.x)
-            xyzz29_add(acc, xyzz29_load<F>(head_part + (size_t)(t + 1 + q) * XYZZ29_BYTES));
-        xyzz29_store(red + threadIdx.x * XYZZ29_BYTES, acc);
+// LDS tree over the first `cnt` lanes' values (cnt <= blockDim.x = HEAVY_BLOCK); result in lane 0
+static constexpr uint32_t HEAVY_BLOCK = 64;      // one wave per sub-job: most heavy chains are 7..64 partials long
+template <class F> DEV void block_tree_sum(Xyzz29<F> &acc, unsigned char *red, uint32_t cnt) {
+    xyzz29_store(red + threadIdx.x * XYZZ29_BYTES, acc);
+    __syncthreads();
+    uint32_t width = 1;
+    while (width < cnt) width <<= 1;
+    for (uint32_t st = width >> 1; st > 0; st >>= 1) {
+        if (threadIdx.x < st && threadIdx.x + st < cnt) {
+            xyzz29_add(acc, xyzz29_load<F>(red + (threadIdx.x + st) * XYZZ29_BYTES));
+            xyzz29_store(red + threadIdx.x * XYZZ29_BYTES, acc);
+        }
         __syncthreads();
-        for (uint32_t st = FIXUP_BLOCK / 2; st > 0; st >>= 1) {
-            if (threadIdx.x < st) {
-                xyzz29_add(acc, xyzz29_load<F>(red + (threadIdx.x + st) * XYZZ29_BYTES));
-                xyzz29_store(red + threadIdx.x * XYZZ29_BYTES, acc);
-            }
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) {
-            xyzz29_add(acc, xyzz29_load<F>(tail_part + (size_t)t * XYZZ29_BYTES));
-            xyzz29_store(bucket_sums + (size_t)key * XYZZ29_BYTES, acc);
-        }
+    }
+}
+// stage A: one wave per sub-job (grid-stride): sub_out[s] = sum of its <= 256 head partials
+// (each lane first adds up to 4 of them, then a 6-level LDS tree)
+template <class F>
+KERNEL void __launch_bounds__(64) k_fixup_heavy_a(const uint32_t *__restrict__ heavy_ctr, const U4 *__restrict__ subs,
+                          const unsigned char *__restrict__ head_part, unsigned char *__restrict__ sub_out) {
+    __shared__ __attribute__((aligned(16))) unsigned char red[HEAVY_BLOCK * XYZZ29_BYTES];
+    const uint32_t nsubs = heavy_ctr[1];
+    for (uint32_t s = blockIdx.x; s < nsubs; s += gridDim.x) {
+        const U4 d = subs[s];
+        Xyzz29<F> acc = xyzz29_identity<F>();
+        for (uint32_t q = threadIdx.x; q < d.y; q += blockDim.x)
+            xyzz29_add(acc, xyzz29_load<F>(head_part + (size_t)(d.x + q) * XYZZ29_BYTES));
+        block_tree_sum(acc, red, d.y < blockDim.x ? d.y : blockDim.x);
+        if (threadIdx.x == 0) xyzz29_store(sub_out + (size_t)s * XYZZ29_BYTES, acc);
+        __syncthreads();
+    }
+}
+// stage B: one wave per heavy run: bucket = tail partial + sum of its sub-job results
+template <class F>
+KERNEL void __launch_bounds__(64) k_fixup_heavy_b(const uint32_t *__restrict__ heavy_ctr, const U4 *__restrict__ runs,
+                          const unsigned char *__restrict__ sub_out, const unsigned char *__restrict__ tail_part,
+                          unsigned char *__restrict__ bucket_sums) {
+    __shared__ __attribute__((aligned(16))) unsigned char red[HEAVY_BLOCK * XYZZ29_BYTES];
+    const uint32_t nruns = heavy_ctr[0];
+    for (uint32_t h = blockIdx.x; h < nruns; h += gridDim.x) {
+        const U4 r = runs[h];                                      // {lane, span, bucket, first sub-job}
+        const uint32_t nsub = (r.y + HEAVY_SUB - 1) / HEAVY_SUB;
+        Xyzz29<F> acc = xyzz29_identity<F>();
+        for (uint32_t q = threadIdx.x; q < nsub; q += blockDim.x)
+            xyzz29_add(acc, xyzz29_load<F>(sub_out + (size_t)(r.w + q) * XYZZ29_BYTES));
+        if (threadIdx.x == 0) xyzz29_add(acc, xyzz29_load<F>(tail_part + (size_t)r.x * XYZZ29_BYTES));
+        block_tree_sum(acc, red, nsub < blockDim.x ? nsub : blockDim.x);
+        if (threadIdx.x == 0) xyzz29_store(bucket_sums + (size_t)r.z * XYZZ29_BYTES, acc);
         __syncthreads();
     }
 }

@@ -136,3 +136,16 @@ def test_emu_fixed_base_tables(emu_lib, monkeypatch):
         pb, cb, wb = key.commit_partial_device(100, d + 100 * 32, n - 100)
         assert (ca, wa) == (0, 64) == (cb, wb)
         assert (cm.combine_partials(cid, np.stack([pa, pb]), ca, wa, lib=emu_lib) == before).all()
+
+
+def test_emu_data_dependent_planning(emu_lib, monkeypatch):
+    """The bit-length pre-pass changes only the window width, never the result."""
+    monkeypatch.setenv("MIRA_PLAN_HIST_MIN_N", "1")
+    for cid in (0, 1):
+        n = 400
+        bs = C.synth_bases(cid, n, seed=50)
+        key = cm.CommitmentKey(cid, bs, lib=emu_lib)
+        for kind in (0, 1):
+            sc = C.synth_scalars(cid, n, seed=51 + kind, kind=kind)
+            assert (key.commit(sc) == C.commit(cid, bs, sc)).all()
+        assert not key.commit(np.zeros((n, 4), dtype=np.uint64)).any()

@@ -134,7 +134,12 @@ def main():
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 5),
                      "traffic": load_traffic(args.log_n), "algorithmic_bytes_per_launch": MSM_BYTES_PER_PAIR * n,
                      "avg_launch_ms": round(t_acc, 4),
-                     "note": "integer-ALU bound (about 160 modular multiplications per pair); see DESIGN.md"},
+                     "alu": None if t_acc <= 0 else {
+                         "achieved_G_modmul_per_s": round(160 * n / (t_acc * 1e-3) / 1e9, 1), "microbench_peak_G_modmul_per_s": 171.0,
+                         "frac": round(160 * n / (t_acc * 1e-3) / 1e9 / 171.0, 3),
+                         "note": "16 mixed XYZZ additions x 10 field multiplications per pair; peak = f29_mul microbenchmark "
+                                 "(profiles/r01_b_microbench_f29.txt); PMC: ~82 % of the VALU issue bound at the 2.05 GHz held under load"},
+                     "note": "integer-ALU bound (about 160 modular multiplications per pair); see DESIGN.md section 4"},
         "stages_ms": {k: round(v, 4) for k, v in stages.items()},
     }
 

@@ -4,6 +4,7 @@
 #include "ctx.h"
 #include "msm_kernels.cuh"
 #include "table_kernels.cuh"
+#include "sort_kernels.cuh"
 
 #ifdef MIRA_CPU_EMU
 static constexpr uint32_t FIXUP_HEAVY_GRID = 4;     // emulated lanes are OS threads: keep the idle grid small
@@ -24,6 +25,12 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size
     if (scan_blocks > 1024) { set_error("window configuration exceeds the scan capacity"); return MIRA_E_UNSUPPORTED; }
     if ((rc = g.block_sums.ensure(1024 * 4))) return rc;
     if ((rc = g.sorted_idx.ensure(entries * 4 + 8))) return rc;
+    const size_t staged_min_n = getenv("MIRA_STAGED_MIN_N") ? (size_t)atoll(getenv("MIRA_STAGED_MIN_N")) : (size_t)1 << 19;   // tests lower it
+    const bool staged = n >= staged_min_n && p.c >= 9 && getenv("MIRA_NO_STAGED_SORT") == nullptr;
+    if (staged) {
+        if ((rc = g.part.ensure(entries * 8 + 8))) return rc;
+        if ((rc = g.coarse_offsets.ensure(((size_t)p.Wt * 512 + 1) * 4))) return rc;
+    }
     if ((rc = g.bucket_sums.ensure((size_t)p.NB * XYZZ29_BYTES))) return rc;
     if ((rc = g.head_part.ensure((size_t)p.T * XYZZ29_BYTES))) return rc;
     if ((rc = g.tail_part.ensure((size_t)p.T * XYZZ29_BYTES))) return rc;
@@ -61,7 +68,22 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size
                    reinterpret_cast<const uint32_t *>(g.block_sums.p), reinterpret_cast<uint32_t *>(g.offsets.p),
                    reinterpret_cast<uint32_t *>(g.cursor.p));
     tm_mark("scan");
-    LAUNCH_BARRIER_FLEX(k_scatter, dim3(p.ntiles, p.Wt), 1024, (size_t)p.B * 4, st, reinterpret_cast<const int16_t *>(g.digits.p),
+    // sort: LDS-staged two-level partition for large inputs (bursts of consecutive entries), the
+    // single-level scatter otherwise (small inputs: the tile structure buys nothing there)
+    if (staged) {
+        const uint32_t coarse_bits = getenv("MIRA_STAGED_COARSE_BITS") ? (uint32_t)atoi(getenv("MIRA_STAGED_COARSE_BITS")) : 8;   // development knob
+        const uint32_t fine_bits = (p.c - 1) - std::min<uint32_t>(p.c - 1, coarse_bits);      // coarse bin = top bits of the bucket id
+        const uint32_t CB = p.B >> fine_bits;                                       // <= 256 coarse bins per window
+        LAUNCH(k_stage_cursors, ceil_div((uint64_t)p.Wt * CB, 256), 256, 0, st, reinterpret_cast<const uint32_t *>(g.offsets.p), p.Wt * CB, fine_bits,
+               reinterpret_cast<uint32_t *>(g.coarse_offsets.p));
+        LAUNCH_BARRIER_FLEX(k_stage1, dim3(ceil_div(n, STAGE_TILE), p.Wt), 1024, (size_t)STAGE_TILE * 8, st, reinterpret_cast<const int16_t *>(g.digits.p),
+                            (uint32_t)n, p.B, fine_bits, CB, reinterpret_cast<uint32_t *>(g.coarse_offsets.p), reinterpret_cast<U2 *>(g.part.p));
+        tm_mark("sort_level1");
+        LAUNCH_BARRIER_FLEX(k_stage2, ceil_div(entries, STAGE_TILE), 1024, (size_t)STAGE_TILE * 6, st, reinterpret_cast<const U2 *>(g.part.p),
+                            reinterpret_cast<const uint32_t *>(g.offsets.p) + p.NB, fine_bits, reinterpret_cast<uint32_t *>(g.cursor.p),
+                            reinterpret_cast<uint32_t *>(g.sorted_idx.p));
+    } else
+        LAUNCH_BARRIER_FLEX(k_scatter, dim3(p.ntiles, p.Wt), 1024, (size_t)p.B * 4, st, reinterpret_cast<const int16_t *>(g.digits.p),
                    (uint32_t)n, p.B, p.tile, reinterpret_cast<uint32_t *>(g.cursor.p), reinterpret_cast<uint32_t *>(g.sorted_idx.p));
     tm_mark("scatter");
     const uint32_t *total_ptr = reinterpret_cast<const uint32_t *>(g.offsets.p) + p.NB;
@@ -102,6 +124,8 @@ template <class F, class FS> static int curve_init() {
     // the LDS-staged histogram needs more than the 64 KiB default (128 KiB at c = 16)
     RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stage1), hipFuncAttributeMaxDynamicSharedMemorySize, STAGE_TILE * 8));   // + 10 KiB static
+    RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stage2), hipFuncAttributeMaxDynamicSharedMemorySize, STAGE_TILE * 6));   // + 52 KiB static
 #endif
     return MIRA_OK;
 }

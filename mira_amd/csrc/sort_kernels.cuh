@@ -1,0 +1,194 @@
+// LDS-staged two-level bucket sort (replaces the single-level k_scatter for large MSMs).
+//
+// k_scatter places every entry with its own 4-byte store at a random address: 67 M partial-line
+// writes per 2^22 MSM reach HBM one by one (measured 58 G stores/s, 1.15 ms).  Here every global
+// write is a burst of consecutive entries:
+//   level 1 (k_stage1)  a workgroup takes a tile of 16384 points of one window, ranks them by
+//                       coarse bin (bucket >> fine_bits) with LDS atomics, stages them in LDS in
+//                       bin order and copies each bin's run (tile / bins ~ 128 entries) to the
+//                       range it claimed with ONE global atomic per bin;
+//   level 2 (k_stage2)  a workgroup takes 16384 consecutive level-1 entries (one or two coarse
+//                       bins), ranks them by bucket, stages, and copies each bucket's run to the
+//                       range claimed in the final array.
+// The bucket histogram (k_hist) and its scan already give every cursor: fine cursors are the bucket
+// offsets, coarse cursors the offsets at coarse-bin boundaries.
+#pragma once
+#include "field.cuh"
+
+static constexpr uint32_t STAGE_TILE = 16384;      // entries per workgroup tile
+static constexpr uint32_t STAGE_MAX_BINS1 = 512;   // coarse bins per window handled in LDS
+static constexpr uint32_t STAGE_MAX_KEYS2 = 4096;  // bucket range one level-2 tile may span in LDS
+
+// exclusive scan of cnt[0..nb) into ofs[0..nb) by the whole workgroup (any blockDim); returns total in *total
+DEV void block_excl_scan(const uint32_t *cnt, uint32_t *ofs, uint32_t *tmp /* blockDim entries */, uint32_t nb, uint32_t *total) {
+    const uint32_t per = (nb + blockDim.x - 1) / blockDim.x;
+    const uint32_t lo = (threadIdx.x * per < nb) ? threadIdx.x * per : nb, hi = (lo + per < nb) ? lo + per : nb;
+    uint32_t s = 0;
+    for (uint32_t b = lo; b < hi; b++) s += cnt[b];
+    tmp[threadIdx.x] = s;
+    __syncthreads();
+    // Hillis-Steele over the per-lane sums
+    for (uint32_t off = 1; off < blockDim.x; off <<= 1) {
+        uint32_t add = (threadIdx.x >= off) ? tmp[threadIdx.x - off] : 0;
+        __syncthreads();
+        tmp[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = tmp[threadIdx.x] - s;
+    for (uint32_t b = lo; b < hi; b++) { ofs[b] = run; run += cnt[b]; }
+    if (threadIdx.x == blockDim.x - 1) *total = tmp[threadIdx.x];
+    __syncthreads();
+}
+
+// init coarse cursors from the bucket offsets: cursor1[g] = offsets[g << fine_bits]
+KERNEL void k_stage_cursors(const uint32_t *__restrict__ offsets, uint32_t ncoarse, uint32_t fine_bits, uint32_t *__restrict__ cursor1) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < ncoarse) cursor1[g] = offsets[(size_t)g << fine_bits];
+}
+
+// level 1.  grid = (ntiles, W_total); digits int16 window-major; B buckets per window, CB = B >> fine_bits
+// coarse bins per window (<= STAGE_MAX_BINS1).  part entries: x = index | sign << 31, y = w * B + bucket.
+// dynamic LDS: STAGE_TILE * 8 bytes staging.
+KERNEL void __launch_bounds__(1024) k_stage1(const int16_t *__restrict__ digits, uint32_t n, uint32_t B, uint32_t fine_bits, uint32_t CB,
+                                              uint32_t *__restrict__ cursor1, U2 *__restrict__ part) {
+    DYN_SHARED(U2, stage);
+    __shared__ uint32_t cnt[STAGE_MAX_BINS1], lofs[STAGE_MAX_BINS1], gbase[STAGE_MAX_BINS1], tmp[1024], total_s;
+    const uint32_t w = blockIdx.y;
+    const uint32_t base = blockIdx.x * STAGE_TILE, end = (base + STAGE_TILE < n) ? base + STAGE_TILE : n;
+    const int16_t *dw = digits + (size_t)w * n;
+    for (uint32_t b = threadIdx.x; b < CB; b += blockDim.x) cnt[b] = 0;
+    __syncthreads();
+    constexpr int PER = STAGE_TILE / 1024;               // 16 points per lane at blockDim 1024
+#ifndef MIRA_CPU_EMU
+    int16_t dreg[PER];                                   // the tile's digits stay in registers between the two passes
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        uint32_t i = base + k * 1024 + threadIdx.x;
+        dreg[k] = (i < end) ? dw[i] : (int16_t)0;
+    }
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        int32_t d = dreg[k];
+        if (d != 0) atomicAdd(&cnt[((uint32_t)(d < 0 ? -d : d) - 1) >> fine_bits], 1u);
+    }
+#else
+    for (uint32_t i = base + threadIdx.x; i < end; i += blockDim.x) {
+        int32_t d = dw[i];
+        if (d != 0) atomicAdd(&cnt[((uint32_t)(d < 0 ? -d : d) - 1) >> fine_bits], 1u);
+    }
+#endif
+    __syncthreads();
+    block_excl_scan(cnt, lofs, tmp, CB, &total_s);
+    for (uint32_t b = threadIdx.x; b < CB; b += blockDim.x) {
+        uint32_t c = cnt[b];
+        gbase[b] = c ? atomicAdd(&cursor1[(size_t)w * CB + b], c) : 0;
+        cnt[b] = lofs[b];                                // cnt[] becomes the running LDS cursor
+    }
+    __syncthreads();
+#ifndef MIRA_CPU_EMU
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        int32_t d = dreg[k];
+        if (d != 0) {
+            uint32_t i = base + k * 1024 + threadIdx.x;
+            uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1;
+            uint32_t p = atomicAdd(&cnt[b >> fine_bits], 1u);
+            stage[p] = U2{i | (d < 0 ? 0x80000000u : 0u), w * B + b};
+        }
+    }
+#else
+    for (uint32_t i = base + threadIdx.x; i < end; i += blockDim.x) {
+        int32_t d = dw[i];
+        if (d != 0) {
+            uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1;
+            uint32_t p = atomicAdd(&cnt[b >> fine_bits], 1u);
+            stage[p] = U2{i | (d < 0 ? 0x80000000u : 0u), w * B + b};
+        }
+    }
+#endif
+    __syncthreads();
+    const uint32_t total = total_s;
+    for (uint32_t p = threadIdx.x; p < total; p += blockDim.x) {     // consecutive p: consecutive addresses within a bin's run
+        U2 e = stage[p];
+        uint32_t cb = (e.y - w * B) >> fine_bits;
+        part[gbase[cb] + (p - lofs[cb])] = e;
+    }
+}
+
+// level 2.  grid = ceil(total / STAGE_TILE) upper bound (tiles beyond `total` exit).  Tile entries
+// have bucket ids in [key_lo, key_lo + STAGE_MAX_KEYS2) in the common case; entries outside that
+// range (sparse inputs spanning many coarse bins) are placed directly.
+// dynamic LDS: STAGE_TILE * 4 (staged x) + STAGE_TILE * 2 (staged local key).
+KERNEL void __launch_bounds__(1024) k_stage2(const U2 *__restrict__ part, const uint32_t *__restrict__ total_ptr, uint32_t fine_bits,
+                                              uint32_t *__restrict__ cursor2, uint32_t *__restrict__ sorted) {
+    DYN_SHARED(uint32_t, stage_x);
+    uint16_t *stage_k = reinterpret_cast<uint16_t *>(stage_x + STAGE_TILE);
+    __shared__ uint32_t cnt[STAGE_MAX_KEYS2], lofs[STAGE_MAX_KEYS2], gbase[STAGE_MAX_KEYS2], tmp[1024], total_s;
+    const uint32_t total = *total_ptr;
+    const uint32_t base = blockIdx.x * STAGE_TILE;
+    if (base >= total) return;
+    const uint32_t end = (total - base > STAGE_TILE) ? base + STAGE_TILE : total;
+    const uint32_t key_lo = (part[base].y >> fine_bits) << fine_bits;
+    for (uint32_t b = threadIdx.x; b < STAGE_MAX_KEYS2; b += blockDim.x) cnt[b] = 0;
+    __syncthreads();
+#ifndef MIRA_CPU_EMU
+    constexpr int PER = STAGE_TILE / 1024;
+    U2 ereg[PER];                                        // the tile's entries stay in registers between the two passes
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        uint32_t p = base + j * 1024 + threadIdx.x;
+        ereg[j] = (p < end) ? part[p] : U2{0, 0xFFFFFFFFu};
+    }
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        uint32_t k = ereg[j].y - key_lo;
+        if (ereg[j].y != 0xFFFFFFFFu && k < STAGE_MAX_KEYS2) atomicAdd(&cnt[k], 1u);
+    }
+#else
+    for (uint32_t p = base + threadIdx.x; p < end; p += blockDim.x) {
+        uint32_t k = part[p].y - key_lo;
+        if (k < STAGE_MAX_KEYS2) atomicAdd(&cnt[k], 1u);
+    }
+#endif
+    __syncthreads();
+    block_excl_scan(cnt, lofs, tmp, STAGE_MAX_KEYS2, &total_s);
+    for (uint32_t b = threadIdx.x; b < STAGE_MAX_KEYS2; b += blockDim.x) {
+        uint32_t c = cnt[b];
+        gbase[b] = c ? atomicAdd(&cursor2[(size_t)key_lo + b], c) : 0;
+        cnt[b] = lofs[b];
+    }
+    __syncthreads();
+#ifndef MIRA_CPU_EMU
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        U2 e = ereg[j];
+        if (e.y == 0xFFFFFFFFu) continue;
+        uint32_t k = e.y - key_lo;
+        if (k < STAGE_MAX_KEYS2) {
+            uint32_t q = atomicAdd(&cnt[k], 1u);
+            stage_x[q] = e.x;
+            stage_k[q] = (uint16_t)k;
+        } else {
+            sorted[atomicAdd(&cursor2[e.y], 1u)] = e.x;             // out-of-range key: direct placement
+        }
+    }
+#else
+    for (uint32_t p = base + threadIdx.x; p < end; p += blockDim.x) {
+        U2 e = part[p];
+        uint32_t k = e.y - key_lo;
+        if (k < STAGE_MAX_KEYS2) {
+            uint32_t q = atomicAdd(&cnt[k], 1u);
+            stage_x[q] = e.x;
+            stage_k[q] = (uint16_t)k;
+        } else {
+            sorted[atomicAdd(&cursor2[e.y], 1u)] = e.x;             // out-of-range key: direct placement
+        }
+    }
+#endif
+    __syncthreads();
+    const uint32_t staged = total_s;
+    for (uint32_t q = threadIdx.x; q < staged; q += blockDim.x) {
+        uint32_t k = stage_k[q];
+        sorted[gbase[k] + (q - lofs[k])] = stage_x[q];
+    }
+}

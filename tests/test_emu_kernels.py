@@ -149,3 +149,21 @@ def test_emu_data_dependent_planning(emu_lib, monkeypatch):
             sc = C.synth_scalars(cid, n, seed=51 + kind, kind=kind)
             assert (key.commit(sc) == C.commit(cid, bs, sc)).all()
         assert not key.commit(np.zeros((n, 4), dtype=np.uint64)).any()
+
+
+def test_emu_staged_sort(emu_lib, monkeypatch):
+    """LDS-staged two-level sort (sort_kernels.cuh), forced on at a small size: same commitments."""
+    monkeypatch.setenv("MIRA_STAGED_MIN_N", "1")
+    for cid, c in ((0, 10), (1, 13)):
+        n = 700
+        bs = C.synth_bases(cid, n, seed=60)
+        key = cm.CommitmentKey(cid, bs, lib=emu_lib)
+        emu_lib.check(emu_lib.c.mira_msm_set_window_bits(c))
+        try:
+            for kind in (0, 1):
+                sc = C.synth_scalars(cid, n, seed=61 + kind, kind=kind)
+                assert (key.commit(sc) == C.commit(cid, bs, sc)).all()
+            one = np.tile(C.to_mont(C.FIELD_FR if cid == 0 else C.FIELD_FQ, np.array([1, 0, 0, 0], dtype=np.uint64)), (n, 1))
+            assert (key.commit(one) == C.msm_pippenger(cid, one, bs)).all()
+        finally:
+            emu_lib.check(emu_lib.c.mira_msm_set_window_bits(0))

@@ -225,6 +225,32 @@ def extras(lib, cm, with_cpu):
     except Exception as e:   # extras never take the headline down
         ex["ntt_2p24"] = {"error": repr(e)}
 
+    # ---- the same 2^22 MSM over fixed-base window tables (opt-in mode) ----
+    try:
+        n = 1 << 22
+        key = cm.CommitmentKey.synthetic(cm.CURVE_BN256, n)
+        d = cm.synth_scalars_device(cm.CURVE_BN256, n)
+        ref = key.commit_device(d, n)
+        t0 = time.perf_counter(); key.precompute(); pre_s = time.perf_counter() - t0
+        key.commit_device(d, n)
+        lib.check(lib.c.mira_set_timing(1))
+        reps, acc = 5, {}
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out = key.commit_device(d, n)
+            for name, ms in lib.timings():
+                acc[name] = acc.get(name, 0.0) + ms / reps
+        dt = (time.perf_counter() - t0) / reps
+        lib.check(lib.c.mira_set_timing(0))
+        ex["msm_2p22_fixed_base"] = {"M_pairs_per_s": round(n / dt / 1e6, 1), "ms": round(dt * 1e3, 3), "stages_ms": {a: round(b, 4) for a, b in acc.items()},
+                                     "same_point_as_per_window_path": bool((out == ref).all()),
+                                     "precompute_s": round(pre_s, 3), "table_bytes": 13 * n * 64,
+                                     "note": "mira_msm_precompute: 13 window tables 2^(20w) P_i in HBM, one set of 2^19 buckets, 13 additions "
+                                             "per pair; the tables depend on the key only and are built once per key, outside this timing"}
+        key.close(); lib.free(d)
+    except Exception as e:
+        ex["msm_2p22_fixed_base"] = {"error": repr(e)}
+
     # ---- witness folding W1 + r W2 (src/plonk/mod.rs:1099-1110): HBM-bound ----
     try:
         from mira_amd import fold as FD

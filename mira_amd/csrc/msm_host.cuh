@@ -76,8 +76,8 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size
         const uint32_t CB = p.B >> fine_bits;                                       // <= 256 coarse bins per window
         LAUNCH(k_stage_cursors, ceil_div((uint64_t)p.Wt * CB, 256), 256, 0, st, reinterpret_cast<const uint32_t *>(g.offsets.p), p.Wt * CB, fine_bits,
                reinterpret_cast<uint32_t *>(g.coarse_offsets.p));
-        LAUNCH_BARRIER_FLEX(k_stage1, dim3(ceil_div(n, STAGE_TILE), p.Wt), 1024, (size_t)STAGE_TILE * 8, st, reinterpret_cast<const int16_t *>(g.digits.p),
-                            (uint32_t)n, p.B, fine_bits, CB, reinterpret_cast<uint32_t *>(g.coarse_offsets.p), reinterpret_cast<U2 *>(g.part.p));
+        LAUNCH_BARRIER_FLEX((k_stage1<int16_t, false>), dim3(ceil_div(n, STAGE_TILE), p.Wt), 1024, (size_t)STAGE_TILE * 8, st, reinterpret_cast<const int16_t *>(g.digits.p),
+                            (uint32_t)n, p.B, fine_bits, CB, 0u, 0u, reinterpret_cast<uint32_t *>(g.coarse_offsets.p), reinterpret_cast<U2 *>(g.part.p));
         tm_mark("sort_level1");
         LAUNCH_BARRIER_FLEX(k_stage2, ceil_div(entries, STAGE_TILE), 1024, (size_t)STAGE_TILE * 6, st, reinterpret_cast<const U2 *>(g.part.p),
                             reinterpret_cast<const uint32_t *>(g.offsets.p) + p.NB, fine_bits, reinterpret_cast<uint32_t *>(g.cursor.p),
@@ -124,7 +124,8 @@ template <class F, class FS> static int curve_init() {
     // the LDS-staged histogram needs more than the 64 KiB default (128 KiB at c = 16)
     RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stage1), hipFuncAttributeMaxDynamicSharedMemorySize, STAGE_TILE * 8));   // + 10 KiB static
+    RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stage1<int16_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, STAGE_TILE * 8));   // + 10 KiB static
+    RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stage1<int32_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, STAGE_TILE * 8));
     RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stage2), hipFuncAttributeMaxDynamicSharedMemorySize, STAGE_TILE * 6));   // + 52 KiB static
 #endif
     return MIRA_OK;
@@ -200,6 +201,8 @@ static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars
     if ((rc = g.part.ensure(entries * 8 + 8))) return rc;
     if ((rc = g.sorted_idx.ensure(entries * 4 + 8))) return rc;
     if ((rc = g.offsets.ensure(((size_t)TABLE_B + 1) * 4))) return rc;
+    if ((rc = g.fine_counts.ensure(((size_t)TABLE_B + 1) * 4))) return rc;
+    if ((rc = g.fine_cursor.ensure(((size_t)TABLE_B + 1) * 4))) return rc;
     if ((rc = g.bucket_sums.ensure((size_t)TABLE_B * XYZZ29_BYTES))) return rc;
     if ((rc = g.head_part.ensure((size_t)T * XYZZ29_BYTES))) return rc;
     if ((rc = g.tail_part.ensure((size_t)T * XYZZ29_BYTES))) return rc;
@@ -236,13 +239,24 @@ static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars
                    reinterpret_cast<const uint32_t *>(g.block_sums.p), reinterpret_cast<uint32_t *>(g.coarse_offsets.p),
                    reinterpret_cast<uint32_t *>(g.cursor.p));
     tm_mark("scan");
-    LAUNCH_BARRIER_FLEX(k_tpartition, dim3(ntiles, TABLE_W), 512, 0, st, reinterpret_cast<const int32_t *>(g.digits.p), (uint32_t)n,
-                        (uint32_t)bs.n, (uint32_t)first, tile, reinterpret_cast<uint32_t *>(g.cursor.p), reinterpret_cast<U2 *>(g.part.p));
-    tm_mark("partition");
-    LAUNCH_BARRIER_FLEX(k_tsort_fine, TABLE_CB, 1024, 0, st, reinterpret_cast<const U2 *>(g.part.p),
-                        reinterpret_cast<const uint32_t *>(g.coarse_offsets.p), reinterpret_cast<uint32_t *>(g.sorted_idx.p),
-                        reinterpret_cast<uint32_t *>(g.offsets.p));
-    tm_mark("sort_fine");
+    // level 1 by coarse bin (top 9 bits), bucket counts from its output, scan, level 2 by bucket
+    const uint32_t *coarse_total = reinterpret_cast<const uint32_t *>(g.coarse_offsets.p) + TABLE_CB;
+    LAUNCH_BARRIER_FLEX((k_stage1<int32_t, true>), dim3(ceil_div(n, STAGE_TILE), TABLE_W), 1024, (size_t)STAGE_TILE * 8, st,
+                        reinterpret_cast<const int32_t *>(g.digits.p), (uint32_t)n, TABLE_B, TABLE_FINE_BITS, TABLE_CB, (uint32_t)bs.n, (uint32_t)first,
+                        reinterpret_cast<uint32_t *>(g.cursor.p), reinterpret_cast<U2 *>(g.part.p));
+    tm_mark("sort_level1");
+    RT_CHECK(rt_memset(g.fine_counts.p, 0, ((size_t)TABLE_B + 1) * 4, st));
+    LAUNCH_BARRIER_FLEX(k_stage2_count, ceil_div(entries, STAGE_TILE), 1024, 0, st, reinterpret_cast<const U2 *>(g.part.p), coarse_total, TABLE_FINE_BITS,
+                        reinterpret_cast<uint32_t *>(g.fine_counts.p));
+    const uint32_t fscan = ceil_div(TABLE_B, SCAN_TILE);
+    LAUNCH_BARRIER(k_scan_a, fscan, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.fine_counts.p), TABLE_B, reinterpret_cast<uint32_t *>(g.block_sums.p));
+    LAUNCH_BARRIER(k_scan_b, 1, 1024, 0, st, reinterpret_cast<uint32_t *>(g.block_sums.p), fscan);
+    LAUNCH_BARRIER(k_scan_c, fscan, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.fine_counts.p), TABLE_B,
+                   reinterpret_cast<const uint32_t *>(g.block_sums.p), reinterpret_cast<uint32_t *>(g.offsets.p), reinterpret_cast<uint32_t *>(g.fine_cursor.p));
+    tm_mark("bucket_count_scan");
+    LAUNCH_BARRIER_FLEX(k_stage2, ceil_div(entries, STAGE_TILE), 1024, (size_t)STAGE_TILE * 6, st, reinterpret_cast<const U2 *>(g.part.p), coarse_total,
+                        TABLE_FINE_BITS, reinterpret_cast<uint32_t *>(g.fine_cursor.p), reinterpret_cast<uint32_t *>(g.sorted_idx.p));
+    tm_mark("sort_level2");
     const uint32_t *total_ptr = reinterpret_cast<const uint32_t *>(g.offsets.p) + TABLE_B;
     LAUNCH(k_plan, 1, 64, 0, st, total_ptr, lanes, Lmin, plan);
     LAUNCH(k_accumulate<F>, ceil_div(T, 128), 128, 0, st, reinterpret_cast<const uint32_t *>(g.sorted_idx.p),

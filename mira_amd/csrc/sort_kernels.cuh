@@ -49,22 +49,27 @@ KERNEL void k_stage_cursors(const uint32_t *__restrict__ offsets, uint32_t ncoar
 // level 1.  grid = (ntiles, W_total); digits int16 window-major; B buckets per window, CB = B >> fine_bits
 // coarse bins per window (<= STAGE_MAX_BINS1).  part entries: x = index | sign << 31, y = w * B + bucket.
 // dynamic LDS: STAGE_TILE * 8 bytes staging.
-KERNEL void __launch_bounds__(1024) k_stage1(const int16_t *__restrict__ digits, uint32_t n, uint32_t B, uint32_t fine_bits, uint32_t CB,
-                                              uint32_t *__restrict__ cursor1, U2 *__restrict__ part) {
+// TABLE = true (fixed-base mode, table_kernels.cuh): int32 digits, ONE bucket set shared by all
+// windows (y = bucket, cursors indexed by the coarse bin alone) and x = w * N + first + i, the index
+// into the window tables (N = registered key length).
+template <class DIGIT, bool TABLE>
+KERNEL void __launch_bounds__(1024) k_stage1(const DIGIT *__restrict__ digits, uint32_t n, uint32_t B, uint32_t fine_bits, uint32_t CB,
+                                              uint32_t N, uint32_t first, uint32_t *__restrict__ cursor1, U2 *__restrict__ part) {
     DYN_SHARED(U2, stage);
     __shared__ uint32_t cnt[STAGE_MAX_BINS1], lofs[STAGE_MAX_BINS1], gbase[STAGE_MAX_BINS1], tmp[1024], total_s;
     const uint32_t w = blockIdx.y;
     const uint32_t base = blockIdx.x * STAGE_TILE, end = (base + STAGE_TILE < n) ? base + STAGE_TILE : n;
-    const int16_t *dw = digits + (size_t)w * n;
+    const DIGIT *dw = digits + (size_t)w * n;
+    const uint32_t key_base = TABLE ? 0u : w * B, cur_base = TABLE ? 0u : w * CB, idx_base = TABLE ? w * N + first : 0u;
     for (uint32_t b = threadIdx.x; b < CB; b += blockDim.x) cnt[b] = 0;
     __syncthreads();
     constexpr int PER = STAGE_TILE / 1024;               // 16 points per lane at blockDim 1024
 #ifndef MIRA_CPU_EMU
-    int16_t dreg[PER];                                   // the tile's digits stay in registers between the two passes
+    DIGIT dreg[PER];                                     // the tile's digits stay in registers between the two passes
 #pragma unroll
     for (int k = 0; k < PER; k++) {
         uint32_t i = base + k * 1024 + threadIdx.x;
-        dreg[k] = (i < end) ? dw[i] : (int16_t)0;
+        dreg[k] = (i < end) ? dw[i] : (DIGIT)0;
     }
 #pragma unroll
     for (int k = 0; k < PER; k++) {
@@ -81,7 +86,7 @@ KERNEL void __launch_bounds__(1024) k_stage1(const int16_t *__restrict__ digits,
     block_excl_scan(cnt, lofs, tmp, CB, &total_s);
     for (uint32_t b = threadIdx.x; b < CB; b += blockDim.x) {
         uint32_t c = cnt[b];
-        gbase[b] = c ? atomicAdd(&cursor1[(size_t)w * CB + b], c) : 0;
+        gbase[b] = c ? atomicAdd(&cursor1[(size_t)cur_base + b], c) : 0;
         cnt[b] = lofs[b];                                // cnt[] becomes the running LDS cursor
     }
     __syncthreads();
@@ -93,7 +98,7 @@ KERNEL void __launch_bounds__(1024) k_stage1(const int16_t *__restrict__ digits,
             uint32_t i = base + k * 1024 + threadIdx.x;
             uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1;
             uint32_t p = atomicAdd(&cnt[b >> fine_bits], 1u);
-            stage[p] = U2{i | (d < 0 ? 0x80000000u : 0u), w * B + b};
+            stage[p] = U2{(idx_base + i) | (d < 0 ? 0x80000000u : 0u), key_base + b};
         }
     }
 #else
@@ -102,7 +107,7 @@ KERNEL void __launch_bounds__(1024) k_stage1(const int16_t *__restrict__ digits,
         if (d != 0) {
             uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1;
             uint32_t p = atomicAdd(&cnt[b >> fine_bits], 1u);
-            stage[p] = U2{i | (d < 0 ? 0x80000000u : 0u), w * B + b};
+            stage[p] = U2{(idx_base + i) | (d < 0 ? 0x80000000u : 0u), key_base + b};
         }
     }
 #endif
@@ -110,8 +115,32 @@ KERNEL void __launch_bounds__(1024) k_stage1(const int16_t *__restrict__ digits,
     const uint32_t total = total_s;
     for (uint32_t p = threadIdx.x; p < total; p += blockDim.x) {     // consecutive p: consecutive addresses within a bin's run
         U2 e = stage[p];
-        uint32_t cb = (e.y - w * B) >> fine_bits;
+        uint32_t cb = (e.y - key_base) >> fine_bits;
         part[gbase[cb] + (p - lofs[cb])] = e;
+    }
+}
+
+// Bucket counts from the level-1 output (table mode: 2^19 buckets do not fit an LDS histogram over
+// the raw digits, but a tile of coarse-sorted entries spans only ~2000 of them).  Same tiling as k_stage2.
+KERNEL void __launch_bounds__(1024) k_stage2_count(const U2 *__restrict__ part, const uint32_t *__restrict__ total_ptr, uint32_t fine_bits,
+                                                    uint32_t *__restrict__ counts) {
+    __shared__ uint32_t cnt[STAGE_MAX_KEYS2];
+    const uint32_t total = *total_ptr;
+    const uint32_t base = blockIdx.x * STAGE_TILE;
+    if (base >= total) return;
+    const uint32_t end = (total - base > STAGE_TILE) ? base + STAGE_TILE : total;
+    const uint32_t key_lo = (part[base].y >> fine_bits) << fine_bits;
+    for (uint32_t b = threadIdx.x; b < STAGE_MAX_KEYS2; b += blockDim.x) cnt[b] = 0;
+    __syncthreads();
+    for (uint32_t p = base + threadIdx.x; p < end; p += blockDim.x) {
+        uint32_t y = part[p].y, k = y - key_lo;
+        if (k < STAGE_MAX_KEYS2) atomicAdd(&cnt[k], 1u);
+        else atomicAdd(&counts[y], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < STAGE_MAX_KEYS2; b += blockDim.x) {
+        uint32_t c = cnt[b];
+        if (c) atomicAdd(&counts[(size_t)key_lo + b], c);
     }
 }
 

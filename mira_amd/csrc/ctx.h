@@ -78,7 +78,7 @@ struct Ctx {
     int32_t forced_c = 0;
     Timing tm;
     // MSM workspace (grow-only, shared by all handles: calls are serialised by the ABI lock)
-    DevBuf digits, counts, offsets, cursor, block_sums, sorted_idx, sorted_key, bucket_sums, part, coarse_offsets, fine_counts, fine_cursor;
+    DevBuf digits, counts, offsets, cursor, block_sums, sorted_idx, bucket_sums, part, coarse_offsets, fine_counts, fine_cursor;
     DevBuf head_part, tail_part, head_key, tail_key, heavy, heavy_out, chunks, window_sums, scalars_stage, consts;
     // NTT workspace
     DevBuf ntt_tmp, ntt_stage, ntt_tables, ntt_consts;

@@ -12,14 +12,6 @@
 #pragma once
 #include "field29.cuh"
 
-// Multiplier policy hook (every kernel currently inlines).  Calling one shared non-inlined copy
-// from the latency-bound tail kernels was measured and is slower: their cost is the dependent
-// chain, not instruction fetch (reduce_chunks 0.32 -> 0.53 ms at 131072 pairs).
-struct MulInline {
-    template <class F> static HD Fe29<F> mul(const Fe29<F> &a, const Fe29<F> &b) { return f29_mul(a, b); }
-    template <class F> static HD Fe29<F> sqr(const Fe29<F> &a) { return f29_sqr(a); }
-};
-
 template <class F> struct Aff29 {
     Fe29<F> x, y;   // identity: both literal zero
 };
@@ -38,82 +30,82 @@ template <class F> HD Xyzz29<F> xyzz29_identity() {
 template <class F> HD bool aff29_is_identity(const Aff29<F> &p) { return f29_is_literal_zero(p.x) && f29_is_literal_zero(p.y); }
 
 // 2 * (affine, not identity): mdbl-2008-s-1
-template <class M = MulInline, class F> HD Xyzz29<F> xyzz29_double_affine(const Aff29<F> &p) {
+template <class F> HD Xyzz29<F> xyzz29_double_affine(const Aff29<F> &p) {
     Xyzz29<F> r;
     Fe29<F> u = f29_dbl(p.y);                                   // < 2.1
-    Fe29<F> v = M::sqr(u);                                     // < 2
-    Fe29<F> w = M::mul(u, v);
-    Fe29<F> s = M::mul(p.x, v);
-    Fe29<F> m = f29_triple(M::sqr(p.x));                       // < 6
-    r.x = f29_sub<5>(M::sqr(m), f29_dbl(s));                   // 2S < 4  -> X < 7
-    r.y = f29_sub<3>(M::mul(m, f29_sub<8>(s, r.x)), M::mul(w, p.y));   // (S - X) < 10, * 6 = 60 -> Y < 5
+    Fe29<F> v = f29_sqr(u);                                     // < 2
+    Fe29<F> w = f29_mul(u, v);
+    Fe29<F> s = f29_mul(p.x, v);
+    Fe29<F> m = f29_triple(f29_sqr(p.x));                       // < 6
+    r.x = f29_sub<5>(f29_sqr(m), f29_dbl(s));                   // 2S < 4  -> X < 7
+    r.y = f29_sub<3>(f29_mul(m, f29_sub<8>(s, r.x)), f29_mul(w, p.y));   // (S - X) < 10, * 6 = 60 -> Y < 5
     r.zz = v; r.zzz = w;
     return r;
 }
 // 2 * XYZZ: dbl-2008-s-1
-template <class M = MulInline, class F> HD Xyzz29<F> xyzz29_double(const Xyzz29<F> &p) {
+template <class F> HD Xyzz29<F> xyzz29_double(const Xyzz29<F> &p) {
     if (xyzz29_is_identity(p)) return p;
     Xyzz29<F> r;
     Fe29<F> u = f29_dbl(p.y);                                   // < 10
-    Fe29<F> v = M::sqr(u);                                     // 100 <= 168
-    Fe29<F> w = M::mul(u, v);                                  // 20
-    Fe29<F> s = M::mul(p.x, v);                                // 18
-    Fe29<F> m = f29_triple(M::sqr(p.x));                       // 81 <= 168 ; m < 6
-    r.x = f29_sub<5>(M::sqr(m), f29_dbl(s));                   // < 7
-    r.y = f29_sub<3>(M::mul(m, f29_sub<8>(s, r.x)), M::mul(w, p.y));   // 6 * 10 ; 2 * 5 -> < 5
-    r.zz = M::mul(v, p.zz); r.zzz = M::mul(w, p.zzz);
+    Fe29<F> v = f29_sqr(u);                                     // 100 <= 168
+    Fe29<F> w = f29_mul(u, v);                                  // 20
+    Fe29<F> s = f29_mul(p.x, v);                                // 18
+    Fe29<F> m = f29_triple(f29_sqr(p.x));                       // 81 <= 168 ; m < 6
+    r.x = f29_sub<5>(f29_sqr(m), f29_dbl(s));                   // < 7
+    r.y = f29_sub<3>(f29_mul(m, f29_sub<8>(s, r.x)), f29_mul(w, p.y));   // 6 * 10 ; 2 * 5 -> < 5
+    r.zz = f29_mul(v, p.zz); r.zzz = f29_mul(w, p.zzz);
     return r;
 }
 
 // acc += q (q affine, canonical): madd-2008-s, 8M + 2S on the common path
-template <class M = MulInline, class F> HD void xyzz29_add_affine(Xyzz29<F> &acc, const Aff29<F> &q) {
+template <class F> HD void xyzz29_add_affine(Xyzz29<F> &acc, const Aff29<F> &q) {
     if (aff29_is_identity(q)) return;
     if (xyzz29_is_identity(acc)) {
         acc.x = q.x; acc.y = q.y; acc.zz = f29_one<F>(); acc.zzz = f29_one<F>();
         return;
     }
-    Fe29<F> u2 = M::mul(q.x, acc.zz);                          // < 2
-    Fe29<F> s2 = M::mul(q.y, acc.zzz);                         // < 2
+    Fe29<F> u2 = f29_mul(q.x, acc.zz);                          // < 2
+    Fe29<F> s2 = f29_mul(q.y, acc.zzz);                         // < 2
     Fe29<F> p = f29_sub<10>(u2, acc.x);                         // X1 < 9  -> P < 12
     Fe29<F> r = f29_sub<6>(s2, acc.y);                          // Y1 < 5  -> R < 8
     if (f29_is_zero_mod_p<12>(p)) {
-        if (f29_is_zero_mod_p<8>(r)) acc = xyzz29_double_affine<M>(q);   // same point
+        if (f29_is_zero_mod_p<8>(r)) acc = xyzz29_double_affine(q);   // same point
         else acc = xyzz29_identity<F>();                            // opposite points
         return;
     }
-    Fe29<F> pp = M::sqr(p);                                    // 144 <= 168
-    Fe29<F> ppp = M::mul(p, pp);                               // 24
-    Fe29<F> qq = M::mul(acc.x, pp);                            // 18
-    Fe29<F> x3 = f29_sub<7>(M::sqr(r), f29_add(ppp, f29_dbl(qq)));        // 64 ; PPP + 2Q < 6 -> X3 < 9
-    Fe29<F> y3 = f29_sub<3>(M::mul(r, f29_sub<10>(qq, x3)), M::mul(acc.y, ppp));   // 8 * 12 = 96 ; 5 * 2 -> Y3 < 5
+    Fe29<F> pp = f29_sqr(p);                                    // 144 <= 168
+    Fe29<F> ppp = f29_mul(p, pp);                               // 24
+    Fe29<F> qq = f29_mul(acc.x, pp);                            // 18
+    Fe29<F> x3 = f29_sub<7>(f29_sqr(r), f29_add(ppp, f29_dbl(qq)));        // 64 ; PPP + 2Q < 6 -> X3 < 9
+    Fe29<F> y3 = f29_sub<3>(f29_mul(r, f29_sub<10>(qq, x3)), f29_mul(acc.y, ppp));   // 8 * 12 = 96 ; 5 * 2 -> Y3 < 5
     acc.x = x3; acc.y = y3;
-    acc.zz = M::mul(acc.zz, pp);
-    acc.zzz = M::mul(acc.zzz, ppp);
+    acc.zz = f29_mul(acc.zz, pp);
+    acc.zzz = f29_mul(acc.zzz, ppp);
 }
 
 // acc += q (both XYZZ): add-2008-s, 12M + 2S
-template <class M = MulInline, class F> HD void xyzz29_add(Xyzz29<F> &acc, const Xyzz29<F> &q) {
+template <class F> HD void xyzz29_add(Xyzz29<F> &acc, const Xyzz29<F> &q) {
     if (xyzz29_is_identity(q)) return;
     if (xyzz29_is_identity(acc)) { acc = q; return; }
-    Fe29<F> u1 = M::mul(acc.x, q.zz);                          // 18
-    Fe29<F> u2 = M::mul(q.x, acc.zz);
-    Fe29<F> s1 = M::mul(acc.y, q.zzz);                         // 10
-    Fe29<F> s2 = M::mul(q.y, acc.zzz);
+    Fe29<F> u1 = f29_mul(acc.x, q.zz);                          // 18
+    Fe29<F> u2 = f29_mul(q.x, acc.zz);
+    Fe29<F> s1 = f29_mul(acc.y, q.zzz);                         // 10
+    Fe29<F> s2 = f29_mul(q.y, acc.zzz);
     Fe29<F> p = f29_sub<3>(u2, u1);                             // < 5
     Fe29<F> r = f29_sub<3>(s2, s1);                             // < 5
     if (f29_is_zero_mod_p<5>(p)) {
-        if (f29_is_zero_mod_p<5>(r)) acc = xyzz29_double<M>(acc);
+        if (f29_is_zero_mod_p<5>(r)) acc = xyzz29_double(acc);
         else acc = xyzz29_identity<F>();
         return;
     }
-    Fe29<F> pp = M::sqr(p);
-    Fe29<F> ppp = M::mul(p, pp);
-    Fe29<F> qq = M::mul(u1, pp);
-    Fe29<F> x3 = f29_sub<7>(M::sqr(r), f29_add(ppp, f29_dbl(qq)));        // < 9
-    Fe29<F> y3 = f29_sub<3>(M::mul(r, f29_sub<10>(qq, x3)), M::mul(s1, ppp));   // 5 * 12 -> < 5
+    Fe29<F> pp = f29_sqr(p);
+    Fe29<F> ppp = f29_mul(p, pp);
+    Fe29<F> qq = f29_mul(u1, pp);
+    Fe29<F> x3 = f29_sub<7>(f29_sqr(r), f29_add(ppp, f29_dbl(qq)));        // < 9
+    Fe29<F> y3 = f29_sub<3>(f29_mul(r, f29_sub<10>(qq, x3)), f29_mul(s1, ppp));   // 5 * 12 -> < 5
     acc.x = x3; acc.y = y3;
-    acc.zz = M::mul(M::mul(acc.zz, q.zz), pp);
-    acc.zzz = M::mul(M::mul(acc.zzz, q.zzz), ppp);
+    acc.zz = f29_mul(f29_mul(acc.zz, q.zz), pp);
+    acc.zzz = f29_mul(f29_mul(acc.zzz, q.zzz), ppp);
 }
 
 // ---- memory formats -------------------------------------------------------------------------------

@@ -26,7 +26,7 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size
     if ((rc = g.block_sums.ensure(1024 * 4))) return rc;
     if ((rc = g.sorted_idx.ensure(entries * 4 + 8))) return rc;
     const size_t staged_min_n = getenv("MIRA_STAGED_MIN_N") ? (size_t)atoll(getenv("MIRA_STAGED_MIN_N")) : (size_t)1 << 19;   // tests lower it
-    const bool staged = n >= staged_min_n && p.c >= 9 && getenv("MIRA_NO_STAGED_SORT") == nullptr;
+    const bool staged = n >= staged_min_n && p.c >= 9;
     if (staged) {
         if ((rc = g.part.ensure(entries * 8 + 8))) return rc;
         if ((rc = g.coarse_offsets.ensure(((size_t)p.Wt * 512 + 1) * 4))) return rc;
@@ -71,8 +71,7 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size
     // sort: LDS-staged two-level partition for large inputs (bursts of consecutive entries), the
     // single-level scatter otherwise (small inputs: the tile structure buys nothing there)
     if (staged) {
-        const uint32_t coarse_bits = getenv("MIRA_STAGED_COARSE_BITS") ? (uint32_t)atoi(getenv("MIRA_STAGED_COARSE_BITS")) : 8;   // development knob
-        const uint32_t fine_bits = (p.c - 1) - std::min<uint32_t>(p.c - 1, coarse_bits);      // coarse bin = top bits of the bucket id
+        const uint32_t fine_bits = (p.c - 1) - std::min<uint32_t>(p.c - 1, 8);      // coarse bin = top 8 bits of the bucket id (6..9 measured equal)
         const uint32_t CB = p.B >> fine_bits;                                       // <= 256 coarse bins per window
         LAUNCH(k_stage_cursors, ceil_div((uint64_t)p.Wt * CB, 256), 256, 0, st, reinterpret_cast<const uint32_t *>(g.offsets.p), p.Wt * CB, fine_bits,
                reinterpret_cast<uint32_t *>(g.coarse_offsets.p));

@@ -55,7 +55,7 @@ struct NttPass {
     uint64_t out_line_stride;
     uint64_t out_elem_stride;
     uint32_t tw_shift;         // post-twiddle omega^(l * k): T_hi[e >> tw_shift] * T_lo[e & mask]; 0xFFFFFFFF = none
-    uint32_t debug_skip;       // development only (MIRA_NTT_DEBUG_SKIP): 1 = skip butterfly layers, 2 = skip output multiply, 4 = skip LDS fill
+    uint32_t reserved;
 };
 
 // One workgroup per line.  blockDim.x = max(64, N/2) capped at 1024.  dynamic LDS = N * 36 B.
@@ -128,7 +128,7 @@ KERNEL void __launch_bounds__(1024) k_ntt_lines(const unsigned char *__restrict_
         }
         __syncthreads();
         if (idx + gridDim.x < ps.nlines) fetch(idx + gridDim.x);
-        for (uint32_t s = 0; s < ((ps.debug_skip & 1u) ? 0u : ps.log_len); s++) {
+        for (uint32_t s = 0; s < ps.log_len; s++) {
             const uint32_t half = 1u << s;
             const double bound = 1.0 + 3.0 * s;
             for (uint32_t bf = threadIdx.x; bf < N / 2; bf += blockDim.x) {
@@ -145,9 +145,7 @@ KERNEL void __launch_bounds__(1024) k_ntt_lines(const unsigned char *__restrict_
         const double bound = 1.0 + 3.0 * ps.log_len;
         for (uint32_t k = threadIdx.x; k < N; k += blockDim.x) {
             Fe29<F> v = L.load(k, bound);
-            if (ps.debug_skip & 2u) {
-                v = f29_carry(v); F29_SET(v, 1.0);
-            } else if (ps.tw_shift != 0xFFFFFFFFu) {
+            if (ps.tw_shift != 0xFFFFFFFFu) {
                 uint64_t e = (uint64_t)line * k;
                 Fe29<F> tw = f29_mul(tw_load<F>(t_hi + (size_t)(e >> ps.tw_shift) * TW_BYTES), tw_load<F>(t_lo + (size_t)(e & lo_mask) * TW_BYTES));
                 v = f29_mul(v, tw);

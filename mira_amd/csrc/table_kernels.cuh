@@ -10,9 +10,9 @@
 // sums come back as 64 plain partial sums.  Cost: W x the key size in HBM (13 x 64 B per point:
 // 3.3 GiB at 2^22, 52 GiB at 2^26) and 12 x 20 doublings per point at registration.
 //
-// With 2^19 buckets the LDS histogram of the single-level sort no longer fits; the sort is
-// two-level: 512 coarse bins of 1024 buckets (tiles of 32k points give 64-entry runs per bin that
-// combine in L2), then each coarse bin's ~100k entries by fine key, which also emits the offsets.
+// With 2^19 buckets a per-tile LDS histogram over the raw digits no longer fits; the LDS-staged
+// sort (sort_kernels.cuh) partitions by the top 9 bits first, counts the buckets from that
+// coarse-sorted stream (a tile then spans only ~2000 of them) and places by bucket.
 #pragma once
 #include "curve29.cuh"
 
@@ -84,7 +84,7 @@ KERNEL void k_digits32(const unsigned char *__restrict__ scalars, uint32_t n, in
     }
 }
 
-// level 1: grid = (ntiles, TABLE_W); LDS = TABLE_CB counters
+// coarse-bin histogram over the digits: grid = (ntiles, TABLE_W); LDS = TABLE_CB counters
 KERNEL void k_thist_coarse(const int32_t *__restrict__ digits, uint32_t n, uint32_t tile, uint32_t *__restrict__ counts) {
     __shared__ uint32_t bins[TABLE_CB];
     const uint32_t w = blockIdx.y;
@@ -100,76 +100,5 @@ KERNEL void k_thist_coarse(const int32_t *__restrict__ digits, uint32_t n, uint3
     for (uint32_t b = threadIdx.x; b < TABLE_CB; b += blockDim.x) {
         uint32_t cnt = bins[b];
         if (cnt) atomicAdd(&counts[b], cnt);
-    }
-}
-// entries: x = table index (w * N + first + i) | sign << 31, y = bucket.  N = registered key length,
-// first = offset of this MSM's bases inside the key (point-chunk sharding).
-KERNEL void k_tpartition(const int32_t *__restrict__ digits, uint32_t n, uint32_t N, uint32_t first, uint32_t tile,
-                         uint32_t *__restrict__ cursor, U2 *__restrict__ part) {
-    __shared__ uint32_t bins[TABLE_CB];
-    const uint32_t w = blockIdx.y;
-    for (uint32_t b = threadIdx.x; b < TABLE_CB; b += blockDim.x) bins[b] = 0;
-    __syncthreads();
-    const uint32_t base = blockIdx.x * tile, end = (base + tile < n) ? base + tile : n;
-    const int32_t *dw = digits + (size_t)w * n;
-    for (uint32_t i = base + threadIdx.x; i < end; i += blockDim.x) {
-        int32_t d = dw[i];
-        if (d != 0) atomicAdd(&bins[((uint32_t)(d < 0 ? -d : d) - 1) >> TABLE_FINE_BITS], 1u);
-    }
-    __syncthreads();
-    for (uint32_t b = threadIdx.x; b < TABLE_CB; b += blockDim.x) {
-        uint32_t cnt = bins[b];
-        if (cnt) bins[b] = atomicAdd(&cursor[b], cnt);
-    }
-    __syncthreads();
-    for (uint32_t i = base + threadIdx.x; i < end; i += blockDim.x) {
-        int32_t d = dw[i];
-        if (d != 0) {
-            uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1;
-            uint32_t pos = atomicAdd(&bins[b >> TABLE_FINE_BITS], 1u);
-            part[pos] = U2{(w * N + first + i) | (d < 0 ? 0x80000000u : 0u), b};
-        }
-    }
-}
-// level 2: workgroups walk the coarse bins; bucket id of fine key f in bin g is g * 1024 + f.
-// blockDim.x <= 1024.
-KERNEL void __launch_bounds__(1024) k_tsort_fine(const U2 *__restrict__ part, const uint32_t *__restrict__ coarse_offsets,
-                         uint32_t *__restrict__ sorted, uint32_t *__restrict__ offsets) {
-    constexpr uint32_t F = 1u << TABLE_FINE_BITS;
-    __shared__ uint32_t cnt[F];
-    __shared__ uint32_t cur[F];
-    for (uint32_t g = blockIdx.x; g < TABLE_CB; g += gridDim.x) {
-        const uint32_t base = coarse_offsets[g], endp = coarse_offsets[g + 1];
-        for (uint32_t f = threadIdx.x; f < F; f += blockDim.x) cnt[f] = 0;
-        __syncthreads();
-        for (uint32_t p = base + threadIdx.x; p < endp; p += blockDim.x) atomicAdd(&cnt[part[p].y & (F - 1)], 1u);
-        __syncthreads();
-        // exclusive scan of the F counters: per-lane chunk sums, one serial pass over the (<= 1024)
-        // chunk sums, then each lane rewrites its chunk as running cursors.  Any blockDim works.
-        const uint32_t per = (F + blockDim.x - 1) / blockDim.x;
-        const uint32_t lo = (threadIdx.x * per < F) ? threadIdx.x * per : F, hi = (lo + per < F) ? lo + per : F;
-        uint32_t s = 0;
-        for (uint32_t f = lo; f < hi; f++) s += cnt[f];
-        cur[threadIdx.x] = s;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t run = 0;
-            for (uint32_t t = 0; t < blockDim.x; t++) { uint32_t v = cur[t]; cur[t] = run; run += v; }
-        }
-        __syncthreads();
-        uint32_t run = base + cur[threadIdx.x];
-        for (uint32_t f = lo; f < hi; f++) {
-            uint32_t c = cnt[f];
-            offsets[(size_t)g * F + f] = run;
-            cnt[f] = run;                                  // cnt[] now holds the running cursors
-            run += c;
-        }
-        if (g == TABLE_CB - 1 && threadIdx.x == 0) offsets[TABLE_B] = endp;
-        __syncthreads();
-        for (uint32_t p = base + threadIdx.x; p < endp; p += blockDim.x) {
-            U2 e = part[p];
-            sorted[atomicAdd(&cnt[e.y & (F - 1)], 1u)] = e.x;
-        }
-        __syncthreads();
     }
 }

@@ -209,3 +209,32 @@ def test_fixed_base_tables(gpu_lib, cid, log_n):
     assert (cm.combine_partials(cid, np.stack([pa, pb]), ca, wa) == before).all()
     m = (1 << 18) + 777                                  # a prefix of the key, still table mode
     assert (key.commit_device(d, m) == C.commit(cid, key.bases()[:m], gpu_lib.download(d, (m, 4)))).all()
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_staged_sort_under_skew(gpu_lib, cid):
+    """The LDS-staged sort (n >= 2^19) on inputs that break its assumptions: witness-like vectors
+    (sparse: level-2 tiles span many coarse bins and take the direct-placement path), one giant
+    bucket, and a column-major mix -- per-window path and fixed-base tables, all against the oracle."""
+    n = 1 << 20
+    key = cm.CommitmentKey.synthetic(cid, n, seed=97)
+    bases = key.bases()
+    field = C.FIELD_FR if cid == 0 else C.FIELD_FQ
+    one = C.to_mont(field, np.array([1, 0, 0, 0], dtype=np.uint64))[0]
+    wit = C.synth_scalars(cid, n, seed=98, kind=1)
+    ones = np.tile(one, (n, 1))
+    mix = C.synth_scalars(cid, n, seed=99)
+    mix[: n // 2] = one                                   # half the vector in one bucket, half uniform
+    mix[n // 2: n // 2 + n // 8] = 0
+    cases = [wit, ones, mix]
+    want = [C.commit(cid, bases, v) for v in cases]
+    for c in (0, 16):                                      # planned width (bit-length pre-pass) and forced 16
+        gpu_lib.check(gpu_lib.c.mira_msm_set_window_bits(c))
+        try:
+            for v, w in zip(cases, want):
+                assert (key.commit(v) == w).all()
+        finally:
+            gpu_lib.check(gpu_lib.c.mira_msm_set_window_bits(0))
+    key.precompute()
+    for v, w in zip(cases, want):
+        assert (key.commit(v) == w).all()

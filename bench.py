@@ -124,7 +124,7 @@ def main():
     out = {
         "metric": "bn256_g1_msm_throughput", "value": round(value, 3), "unit": "M scalar-point pairs/s",
         "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u256 (8 x u32 limbs, Montgomery)",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u256 mod p (9 x 29-bit limbs in u32/u64, Montgomery)",
         "data": "synthetic",
         "config": {"workload": f"BN256 G1 MSM 2^{args.log_n} pairs per GPU via CommitmentKey::commit, {args.window_bits}-bit signed windows",
                    "pairs_per_gpu": n, "total_pairs": total_pairs, "window_bits": args.window_bits,

@@ -3,12 +3,12 @@ usage: python tools/collect_profiles.py <tag> <bench_json> <kernel_stats_dir> <p
 import collections, csv, glob, json, shutil, sys
 tag, bench, stats_dir, fdir, wdir = sys.argv[1:6]
 shutil.copy(bench, f"profiles/{tag}_bench.json")
-shutil.copy(glob.glob(f"{stats_dir}/*/*kernel_stats.csv")[0], f"profiles/{tag}_msm2p22_kernel_stats.csv")
+shutil.copy((glob.glob(f"{stats_dir}/*kernel_stats.csv") + glob.glob(f"{stats_dir}/*/*kernel_stats.csv"))[0], f"profiles/{tag}_msm2p22_kernel_stats.csv")
 out = {}
 lines = ["kernel,counter,launches,avg_value_KB"]
 for c, d in (("FETCH_SIZE", fdir), ("WRITE_SIZE", wdir)):
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(glob.glob(f"{d}/*/*counter_collection.csv")[0])):
+    for r in csv.DictReader(open((glob.glob(f"{d}/*counter_collection.csv") + glob.glob(f"{d}/*/*counter_collection.csv"))[0])):
         agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         lines.append(f"\"{k}\",{c},{len(v)},{sum(v) / len(v):.1f}")

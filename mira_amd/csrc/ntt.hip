@@ -90,9 +90,10 @@ static int ntt_device_locked(void *d_a, uint32_t log_n, const uint64_t omega[4],
     unsigned char *a = reinterpret_cast<unsigned char *>(d_a);
     const unsigned char *cnull = nullptr;
     auto threads_for = [](uint32_t m) { return std::min<uint32_t>(1024, std::max<uint32_t>(64, (1u << m) / 2)); };
+    auto lds_for = [](uint32_t m) { return ((size_t)NTT_LDS_BYTES_PER_ELEM << m) + 16 + ((size_t)NTT_LDS_BYTES_PER_ELEM << NTT_LDS_TW_LOG); };
     if (t.m2 == 0) {
         NttPass ps{t.m1, 1, 0, 1, 0, 1, 0xFFFFFFFFu, 0u};
-        LAUNCH_BARRIER(k_ntt_lines<Fr29>, 1, threads_for(t.m1), ((size_t)NTT_LDS_BYTES_PER_ELEM << t.m1), g.stream, (const unsigned char *)a, a, ps,
+        LAUNCH_BARRIER(k_ntt_lines<Fr29>, 1, threads_for(t.m1), lds_for(t.m1), g.stream, (const unsigned char *)a, a, ps,
                        tab + t.off_tw1, cnull, cnull, (const unsigned char *)scale_d);
         tm_mark("ntt_single");
     } else {
@@ -101,12 +102,12 @@ static int ntt_device_locked(void *d_a, uint32_t log_n, const uint64_t omega[4],
         unsigned char *tmp = reinterpret_cast<unsigned char *>(g.ntt_tmp.p);
         // pass 1: columns i2 of the n1 x n2 view; B[k1][i2] * omega^(i2 k1) -> tmp[i2 * n1 + k1]
         NttPass p1{t.m1, (uint32_t)n2, 1, n2, n1, 1, t.h, 0u};
-        LAUNCH_BARRIER(k_ntt_lines<Fr29>, std::min<uint32_t>((uint32_t)n2, NTT_PERSISTENT_GRID), threads_for(t.m1), ((size_t)NTT_LDS_BYTES_PER_ELEM << t.m1), g.stream, (const unsigned char *)a, tmp, p1,
+        LAUNCH_BARRIER(k_ntt_lines<Fr29>, std::min<uint32_t>((uint32_t)n2, NTT_PERSISTENT_GRID), threads_for(t.m1), lds_for(t.m1), g.stream, (const unsigned char *)a, tmp, p1,
                        tab + t.off_tw1, tab + t.off_lo, tab + t.off_hi, cnull);
         tm_mark("ntt_pass1");
         // pass 2: for each k1 the length-n2 transform over i2; X[k1 + n1 k2] -> a
         NttPass p2{t.m2, (uint32_t)n1, 1, n1, 1, n1, 0xFFFFFFFFu, 0u};
-        LAUNCH_BARRIER(k_ntt_lines<Fr29>, std::min<uint32_t>((uint32_t)n1, NTT_PERSISTENT_GRID), threads_for(t.m2), ((size_t)NTT_LDS_BYTES_PER_ELEM << t.m2), g.stream, (const unsigned char *)tmp, a, p2,
+        LAUNCH_BARRIER(k_ntt_lines<Fr29>, std::min<uint32_t>((uint32_t)n1, NTT_PERSISTENT_GRID), threads_for(t.m2), lds_for(t.m2), g.stream, (const unsigned char *)tmp, a, p2,
                        tab + t.off_tw2, cnull, cnull, (const unsigned char *)scale_d);
         tm_mark("ntt_pass2");
     }

@@ -11,6 +11,7 @@
 #include "field29.cuh"
 
 static constexpr int NTT_MAX_LOG_LINE = 12;   // 4096 elements * 36 B = 144 KiB of the 160 KiB LDS
+static constexpr int NTT_LDS_TW_LOG = 8;      // + the twiddles of the first 9 layers (256 * 36 B) -- see k_ntt_lines
 
 // 9 raw limbs (padded to 48 B) per table entry: canonical value in R' = 2^261 Montgomery form, ready to be a
 // multiplier operand.  Multiplying a reference-form element (x * 2^256) by such an entry with
@@ -58,7 +59,7 @@ struct NttPass {
     uint32_t reserved;
 };
 
-// One workgroup per line.  blockDim.x = max(64, N/2) capped at 1024.  dynamic LDS = N * 36 B.
+// One workgroup per line.  blockDim.x = max(64, N/2) capped at 1024.  dynamic LDS = N * 36 B + 16 + 256 * 36 B.
 //
 // Inside the line every value stays a loose 9 x 29-bit element (field29.cuh): a butterfly is one
 // multiplication (whose result is < 2 P whatever its input), one carry-free addition and one
@@ -95,6 +96,18 @@ KERNEL void __launch_bounds__(1024) k_ntt_lines(const unsigned char *__restrict_
     const uint32_t N = 1u << ps.log_len;
     NttLds<F> L{lds, lds + N, reinterpret_cast<uint32_t *>(lds + 2 * (size_t)N)};
     const uint32_t lo_mask = ps.tw_shift == 0xFFFFFFFFu ? 0 : ((1u << ps.tw_shift) - 1u);
+    // Twiddles of layers 0..tw_layers-1 (at most 256 values) sit in LDS behind the line.  Vector
+    // memory operations retire in order, so a twiddle fetched from global memory in a butterfly
+    // layer first waits for the whole prefetch of the next line issued before it; with the early
+    // layers fed from LDS the prefetch has 9 of the 12 layers to land (measured: 2 % per pass).
+    const uint32_t tw_layers = ps.log_len < NTT_LDS_TW_LOG + 1 ? ps.log_len : NTT_LDS_TW_LOG + 1;
+    U4 *tbase = lds + 2 * (size_t)N + (N + 3) / 4;
+    NttLds<F> T{tbase, tbase + (1u << NTT_LDS_TW_LOG), reinterpret_cast<uint32_t *>(tbase + 2 * (size_t)(1u << NTT_LDS_TW_LOG))};
+    if (tw_layers >= 2) {
+        const uint32_t cnt = 1u << (tw_layers - 1);      // omega_N^(j * N / (2 cnt)), j < cnt
+        for (uint32_t j = threadIdx.x; j < cnt; j += blockDim.x)
+            T.store(j, tw_load<F>(line_tw + (size_t)(j << (ps.log_len - tw_layers)) * TW_BYTES));
+    }
     // Persistent workgroups: each walks lines blockIdx.x, blockIdx.x + gridDim.x, ...  The next
     // line's elements are fetched into registers before the butterfly layers of the current line
     // start, so the strided HBM gather is hidden behind ~100k cycles of arithmetic.
@@ -135,7 +148,11 @@ KERNEL void __launch_bounds__(1024) k_ntt_lines(const unsigned char *__restrict_
                 const uint32_t j = bf & (half - 1);
                 const uint32_t i0 = ((bf >> s) << (s + 1)) + j, i1 = i0 + half;
                 Fe29<F> u = L.load(i0, bound), v = L.load(i1, bound);
-                if (s != 0) v = f29_mul(v, tw_load<F>(line_tw + (size_t)(j << (ps.log_len - 1 - s)) * TW_BYTES));
+                if (s != 0) {
+                    Fe29<F> tw = s < tw_layers ? T.load(j << (tw_layers - 1 - s), 1.0)
+                                               : tw_load<F>(line_tw + (size_t)(j << (ps.log_len - 1 - s)) * TW_BYTES);
+                    v = f29_mul(v, tw);
+                }
                 L.store(i0, f29_add(u, v));
                 L.store(i1, f29_sub<3>(u, v));
             }

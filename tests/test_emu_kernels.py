@@ -73,7 +73,7 @@ def test_emu_partial_and_combine(emu_lib):
     assert (got == C.msm_pippenger(cid, sc, bs)).all()
 
 
-@pytest.mark.parametrize("k", [0, 1, 3, 4, 10])
+@pytest.mark.parametrize("k", [0, 1, 3, 4, 10, 12])
 def test_emu_ntt(emu_lib, k):
     a = C.synth_scalars(0, 1 << k, seed=1000 + k)
     assert (F.fft(a, k, lib=emu_lib) == C.fft(a, k)).all()

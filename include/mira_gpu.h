@@ -116,6 +116,65 @@ int mira_fold_witness_device(int field, void *d_out, const void *d_w1, const voi
 int mira_fold_error_device(int field, void *d_e, const void *const *d_cross_terms, size_t num_terms, const uint64_t r[4], size_t n);
 int mira_g1_mul_add(int curve, const uint64_t acc[8], const uint64_t scalar[4], const uint64_t point[8], uint64_t out[8]);
 
+/* ---- the step before the MSM in one fold: cross-term evaluation ----------------------------
+ * GraphEvaluator::evaluate over all rows (src/polynomial/graph_evaluator.rs:361-390, called per
+ * row from commit_cross_terms, src/nifs/vanilla/mod.rs:100-121): out[row] = value of the last
+ * calculation, for row < num_rows.  The output stays in HBM, ready for mira_msm_batch_device and
+ * mira_fold_error_device.
+ *
+ * mira_graph is the reference structure flattened (graph_evaluator.rs:165-185):
+ *   constants   num_constants field elements (Montgomery, as the reference holds them)
+ *   rotations   num_rotations i32; a column read at rotation index k uses row
+ *               (row + rotations[k]).rem_euclid(num_rows)                  (:51-53)
+ *   code        the calculations in order; calculation i writes intermediate i (its `target`).
+ *               One header word  op | nparts << 8,  then the operands as value sources:
+ *                 ADD, SUB, MUL: a, b.   SQUARE, DOUBLE, NEGATE, STORE: a.
+ *                 HORNER: start, factor, parts[nparts]   (value = start; value = value*factor + part)
+ *   value source  kind << 29 | payload                                   (ValueSource, :56-68)
+ *                 CONSTANT: index into constants.  INTERMEDIATE: index of an earlier calculation.
+ *                 CHALLENGE: index into challenges.
+ *                 COLUMN: column | rotation_index << 20 -- Fixed{index, rotation} and
+ *                 Poly{index, rotation} after the caller has resolved the column (selector, fixed
+ *                 or witness slice: eval_column_var, src/plonk/eval.rs:57-69 and :136-229) to an
+ *                 entry of `columns`.
+ * columns[k]: device pointer to num_rows values; kind MIRA_COL_FIELD = field elements,
+ * MIRA_COL_BOOL = bytes (a selector: non-zero -> ONE, zero -> ZERO).  A null pointer marks a column
+ * index that does not resolve; using it is ColumnVariableIndexOutOfBoundary / InvalidWitnessIndex
+ * -> MIRA_E_BAD_ARG, as are a challenge or constant index out of range
+ * (ChallengeIndexOutOfBoundary) and malformed code.  No calculations -> out = 0 (:386-389).    */
+#define MIRA_OP_ADD 0u
+#define MIRA_OP_SUB 1u
+#define MIRA_OP_MUL 2u
+#define MIRA_OP_SQUARE 3u
+#define MIRA_OP_DOUBLE 4u
+#define MIRA_OP_NEGATE 5u
+#define MIRA_OP_HORNER 6u
+#define MIRA_OP_STORE 7u
+#define MIRA_SRC_CONSTANT 0u
+#define MIRA_SRC_INTERMEDIATE 1u
+#define MIRA_SRC_COLUMN 2u
+#define MIRA_SRC_CHALLENGE 3u
+#define MIRA_COL_FIELD 0u
+#define MIRA_COL_BOOL 1u
+typedef struct mira_graph {
+    const uint32_t *code;
+    size_t code_words;
+    uint32_t num_calculations;
+    uint32_t num_constants;
+    const uint64_t *constants;   /* num_constants * 4 limbs */
+    const int32_t *rotations;
+    uint32_t num_rotations;
+    uint32_t reserved;
+} mira_graph;
+typedef struct mira_eval_column {
+    const void *d_data;
+    uint32_t kind;
+    uint32_t reserved;
+} mira_eval_column;
+int mira_graph_eval_device(int field, const mira_graph *graph, const mira_eval_column *columns, uint32_t num_columns,
+                           const uint64_t *challenges /* num_challenges * 4 limbs, host */, uint32_t num_challenges,
+                           size_t num_rows, void *d_out /* num_rows field elements */);
+
 /* ---- NTT over bn256::Fr (src/fft.rs) -----------------------------------------------------
  * In place, natural order in and out.  `a` = 2^log_n elements.  log_n <= 24 in this build
  * (the field allows 28, src/fft.rs:13).                                                      */

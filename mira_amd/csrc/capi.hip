@@ -522,6 +522,19 @@ int mira_fold_error_device(int field, void *d_e, const void *const *d_cross_term
     if (!n || !num_terms) return MIRA_OK;
     return fold_error_device(field, d_e, d_cross_terms, num_terms, r, n);
 }
+int mira_graph_eval_device(int field, const mira_graph *graph, const mira_eval_column *columns, uint32_t num_columns, const uint64_t *challenges,
+                           uint32_t num_challenges, size_t num_rows, void *d_out) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    if ((field != MIRA_FIELD_FQ && field != MIRA_FIELD_FR) || !graph || (graph->code_words && !graph->code) || (graph->num_constants && !graph->constants) ||
+        (graph->num_rotations && !graph->rotations) || (num_columns && !columns) || (num_challenges && !challenges) || (num_rows && !d_out) ||
+        num_columns > 0xFFFFFu || graph->num_rotations > 512u) {
+        set_error("bad graph evaluation arguments");
+        return MIRA_E_BAD_ARG;
+    }
+    return graph_eval_device(field, graph, columns, num_columns, challenges, num_challenges, num_rows, d_out);
+}
 int mira_g1_mul_add(int curve, const uint64_t acc[8], const uint64_t scalar[4], const uint64_t point[8], uint64_t out[8]) {
     if ((curve != MIRA_CURVE_BN256 && curve != MIRA_CURVE_GRUMPKIN) || !acc || !scalar || !point || !out) { set_error("bad arguments"); return MIRA_E_BAD_ARG; }
     if (curve == MIRA_CURVE_BN256) g1_mul_add_t<FqP, FrP>(acc, scalar, point, out);

@@ -83,6 +83,7 @@ struct Ctx {
     // NTT workspace
     DevBuf ntt_tmp, ntt_stage, ntt_tables, ntt_consts;
     DevBuf fold_consts;
+    DevBuf graph_consts, graph_ws;   // cross-term evaluator: staged program, intermediates[slot][lane]
     std::string ntt_tables_key;
     uint64_t next_handle = 1;
 };
@@ -135,6 +136,10 @@ int fold_witness_device(int field, void *d_out, const void *d_w1, const void *d_
 int fold_error_device(int field, void *d_e, const void *const *d_terms, size_t K, const uint64_t r[4], size_t n);
 int export_bases_bn256(const Bases &bs, size_t first, size_t n, void *d_out);
 int export_bases_grumpkin(const Bases &bs, size_t first, size_t n, void *d_out);
+
+// graph.hip
+int graph_eval_device(int field, const mira_graph *gr, const mira_eval_column *columns, uint32_t num_columns, const uint64_t *challenges,
+                      uint32_t num_challenges, size_t num_rows, void *d_out);
 
 // ntt.hip
 enum NttKind { NTT_BEST, NTT_FFT, NTT_IFFT, NTT_COSET_FFT, NTT_COSET_IFFT };

@@ -1,0 +1,322 @@
+"""Host-side mirror of the reference's cross-term evaluation, the step before the MSM in one fold
+(SURVEY.md §8f row N1):
+
+* `Expression` (reference src/polynomial/expression.rs:112-120) and `Query` (index, rotation);
+* `GraphEvaluator.new(expr)`: the calculation graph the reference builds from an expression
+  (src/polynomial/graph_evaluator.rs:196-352) -- same constants table, rotation table, sharing of
+  repeated sub-expressions and simplifications, so graphs are comparable node for node;
+* `GraphEvaluator.evaluate_device(...)`: every row at once on the GPU (`mira_graph_eval_device`),
+  replacing the per-row `evaluate` loop of `commit_cross_terms` (src/nifs/vanilla/mod.rs:100-121);
+* `PlonkEvalDomain`: the column index space of `eval_column_var` / `eval_advice_var`
+  (src/plonk/eval.rs:57-69, 136-229) resolved to device pointers;
+* `commit_cross_terms`: evaluate every cross term into HBM and commit them in one batched MSM.
+
+Constants and challenges are plain Python integers below the field modulus on this side; device
+data is in the reference's Montgomery layout like everywhere else in this package."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+FIELD_FQ, FIELD_FR = 0, 1
+MODULUS = {
+    FIELD_FQ: 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47,   # bn256::Fq
+    FIELD_FR: 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001,   # bn256::Fr
+}
+OP_ADD, OP_SUB, OP_MUL, OP_SQUARE, OP_DOUBLE, OP_NEGATE, OP_HORNER, OP_STORE = range(8)
+SRC_CONSTANT, SRC_INTERMEDIATE, SRC_COLUMN, SRC_CHALLENGE = range(4)
+COL_FIELD, COL_BOOL = 0, 1
+
+
+def to_montgomery(values, field):
+    """ints -> (n, 4) uint64 limbs of v * 2^256 mod p, the layout the device reads."""
+    mod = MODULUS[field]
+    out = np.zeros((len(values), 4), dtype=np.uint64)
+    for i, v in enumerate(values):
+        m = (v % mod) * (1 << 256) % mod
+        for k in range(4):
+            out[i, k] = (m >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+    return out
+
+
+# ---------------------------------------------------------------- Expression (expression.rs:112-120)
+class Expression:
+    def to_tuple(self):
+        """Neutral nested-tuple form (what the test oracle evaluates)."""
+        raise NotImplementedError
+
+
+class Constant(Expression):
+    def __init__(self, value):
+        self.value = int(value)
+
+    def to_tuple(self):
+        return ("const", self.value)
+
+
+class Polynomial(Expression):
+    """A column query: `index` into selectors | fixed | advice, `rotation` relative to the row."""
+
+    def __init__(self, index, rotation=0):
+        self.index, self.rotation = int(index), int(rotation)
+
+    def to_tuple(self):
+        return ("poly", self.index, self.rotation)
+
+
+class Challenge(Expression):
+    def __init__(self, index):
+        self.index = int(index)
+
+    def to_tuple(self):
+        return ("chal", self.index)
+
+
+class Negated(Expression):
+    def __init__(self, a):
+        self.a = a
+
+    def to_tuple(self):
+        return ("neg", self.a.to_tuple())
+
+
+class Sum(Expression):
+    def __init__(self, a, b):
+        self.a, self.b = a, b
+
+    def to_tuple(self):
+        return ("sum", self.a.to_tuple(), self.b.to_tuple())
+
+
+class Product(Expression):
+    def __init__(self, a, b):
+        self.a, self.b = a, b
+
+    def to_tuple(self):
+        return ("prod", self.a.to_tuple(), self.b.to_tuple())
+
+
+class Scaled(Expression):
+    def __init__(self, a, factor):
+        self.a, self.factor = a, int(factor)
+
+    def to_tuple(self):
+        return ("scaled", self.a.to_tuple(), self.factor)
+
+
+# ---------------------------------------------------------------- GraphEvaluator
+# value sources are tuples ordered like the reference's derived PartialOrd (graph_evaluator.rs:55-68):
+# (SRC_CONSTANT, id) < (SRC_INTERMEDIATE, id); columns and challenges only appear inside Store
+_ZERO, _ONE, _TWO = (SRC_CONSTANT, 0), (SRC_CONSTANT, 1), (SRC_CONSTANT, 2)
+
+
+class GraphEvaluator:
+    def __init__(self, field=FIELD_FR):
+        self.field = field
+        self.mod = MODULUS[field]
+        self.constants = [0, 1, 2]            # the defaults of graph_evaluator.rs:183-192
+        self.rotations = []
+        self.calculations = []                # (op, sources...) ; calculation i writes intermediate i
+        self._known = {}                      # calculation -> intermediate that already holds it
+
+    @classmethod
+    def new(cls, expr, field=FIELD_FR):
+        """graph_evaluator.rs:196-203"""
+        ge = cls(field)
+        ge._calc((OP_STORE, ge._expr(expr)))
+        return ge
+
+    @property
+    def num_intermediates(self):
+        return len(self.calculations)
+
+    def _rotation(self, rot):                                   # add_rotation, :206-219
+        if rot not in self.rotations:
+            self.rotations.append(rot)
+        return self.rotations.index(rot)
+
+    def _constant(self, v):                                     # add_constant, :222-235
+        v %= self.mod
+        if v not in self.constants:
+            self.constants.append(v)
+        return (SRC_CONSTANT, self.constants.index(v))
+
+    def _calc(self, calc):                                      # add_calculation, :241-258
+        if calc not in self._known:
+            self._known[calc] = len(self.calculations)
+            self.calculations.append(calc)
+        return (SRC_INTERMEDIATE, self._known[calc])
+
+    def _expr(self, e):                                         # add_expression, :261-352
+        if isinstance(e, Constant):
+            return self._constant(e.value)
+        if isinstance(e, Polynomial):
+            return self._calc((OP_STORE, (SRC_COLUMN, e.index, self._rotation(e.rotation))))
+        if isinstance(e, Challenge):
+            return self._calc((OP_STORE, (SRC_CHALLENGE, e.index)))
+        if isinstance(e, Negated):
+            if isinstance(e.a, Constant):
+                return self._constant(-e.a.value)
+            a = self._expr(e.a)
+            return a if a == _ZERO else self._calc((OP_NEGATE, a))
+        if isinstance(e, Sum):
+            if isinstance(e.b, Negated):                        # a + (-b) is a subtraction
+                a, b = self._expr(e.a), self._expr(e.b.a)
+                if a == _ZERO:
+                    return self._calc((OP_NEGATE, b))
+                return a if b == _ZERO else self._calc((OP_SUB, a, b))
+            a, b = self._expr(e.a), self._expr(e.b)
+            return self._calc((OP_ADD,) + ((a, b) if a <= b else (b, a)))
+        if isinstance(e, Product):
+            a, b = self._expr(e.a), self._expr(e.b)
+            if _ZERO in (a, b):
+                return _ZERO
+            if a == _ONE:
+                return b
+            if b == _ONE:
+                return a
+            if a == _TWO:
+                return self._calc((OP_DOUBLE, b))
+            if b == _TWO:
+                return self._calc((OP_DOUBLE, a))
+            if a == b:
+                return self._calc((OP_SQUARE, a))
+            return self._calc((OP_MUL,) + ((a, b) if a <= b else (b, a)))
+        if isinstance(e, Scaled):
+            f = e.factor % self.mod
+            if f == 0:
+                return _ZERO
+            if f == 1:
+                return self._expr(e.a)
+            c = self._constant(f)
+            return self._calc((OP_MUL, self._expr(e.a), c))
+        raise TypeError(f"not an Expression: {e!r}")
+
+    # ---- the flattened form of include/mira_gpu.h ------------------------------------------
+    @staticmethod
+    def _source_word(src):
+        if src[0] == SRC_COLUMN:
+            return (SRC_COLUMN << 29) | src[1] | (src[2] << 20)
+        return (src[0] << 29) | src[1]
+
+    def flatten(self):
+        """-> (code uint32[], constants (n, 4) uint64, rotations int32[])"""
+        words = []
+        for calc in self.calculations:
+            op, srcs = calc[0], calc[1:]
+            words.append(op | ((len(srcs) - 2) << 8 if op == OP_HORNER else 0))
+            words.extend(self._source_word(s) for s in srcs)
+        return (np.array(words, dtype=np.uint32), to_montgomery(self.constants, self.field), np.array(self.rotations, dtype=np.int32))
+
+    def evaluate_device(self, columns, challenges, num_rows, d_out=None, lib=None):
+        """Every row at once.  columns: list of (device pointer, COL_FIELD | COL_BOOL) or None for an
+        index that does not resolve; challenges: ints.  Returns the device pointer of the
+        num_rows results (allocated here unless `d_out` is given)."""
+        lib = lib or _lib.load()
+        code, consts, rots = self.flatten()
+        g = _lib.MiraGraph(code.ctypes.data_as(ctypes.c_void_p), len(code), len(self.calculations), len(consts),
+                           consts.ctypes.data_as(ctypes.c_void_p), rots.ctypes.data_as(ctypes.c_void_p), len(rots), 0)
+        cols = (_lib.MiraEvalColumn * max(1, len(columns)))()
+        for k, c in enumerate(columns):
+            cols[k].d_data, cols[k].kind = (None, 0) if c is None else (c[0], c[1])
+        ch = to_montgomery(list(challenges), self.field)
+        out = d_out if d_out is not None else lib.alloc(max(1, num_rows) * 32)
+        try:
+            lib.check(lib.c.mira_graph_eval_device(self.field, ctypes.byref(g), cols, len(columns), ch.ctypes.data_as(ctypes.c_void_p), len(ch),
+                                                   num_rows, ctypes.c_void_p(out)))
+        except Exception:
+            if d_out is None:
+                lib.free(out)
+            raise
+        return out
+
+    def evaluate(self, getter, lib=None):
+        """Host-array convenience: getter = dict(selectors=[bool arrays], fixed=[(n, 4) uint64],
+        advice=[(n, 4) uint64], challenges=[ints]) as the reference's test mock
+        (graph_evaluator.rs:405-443); returns the (num_rows, 4) results."""
+        lib = lib or _lib.load()
+        sel, fix, adv = getter.get("selectors", []), getter.get("fixed", []), getter.get("advice", [])
+        num_rows = len(fix[0]) if fix else len(sel[0]) if sel else (len(adv[0]) if adv else 1)   # row_size, src/plonk/eval.rs:47-54
+        ptrs, cols = [], []
+        try:
+            for s in sel:
+                a = np.ascontiguousarray(np.asarray(s), dtype=np.uint8)
+                ptrs.append(lib.alloc(max(1, a.nbytes))); lib.upload(ptrs[-1], a); cols.append((ptrs[-1], COL_BOOL))
+            for f in list(fix) + list(adv):
+                a = np.ascontiguousarray(f, dtype=np.uint64).reshape(-1, 4)
+                ptrs.append(lib.alloc(max(1, a.nbytes))); lib.upload(ptrs[-1], a); cols.append((ptrs[-1], COL_FIELD))
+            d = self.evaluate_device(cols, getter.get("challenges", []), num_rows, lib=lib)
+            ptrs.append(d)
+            return lib.download(d, (num_rows, 4))
+        finally:
+            for p in ptrs:
+                lib.free(p)
+
+
+# ---------------------------------------------------------------- PlonkEvalDomain (src/plonk/eval.rs:93-229)
+class PlonkEvalDomain:
+    """Device-resident evaluation data of one fold step.  selectors: device byte columns, fixed:
+    device field columns, W1s / W2s: lists of (device pointer, length in elements) -- the witness
+    vectors of the two instances, each a concatenation of row_size-long columns."""
+
+    def __init__(self, num_advice, num_lookup, challenges, selectors, fixed, W1s, W2s, row_size):
+        self.num_advice, self.num_lookup = num_advice, num_lookup
+        self.challenges, self.selectors, self.fixed = list(challenges), list(selectors), list(fixed)
+        self.W1s, self.W2s, self.row_size = list(W1s), list(W2s), row_size
+
+    def _advice(self, index):
+        """eval_advice_var (src/plonk/eval.rs:152-228): advice index -> (device pointer) or None."""
+        max_width = self.num_advice + self.num_lookup * 5
+        first = index < max_width
+        if not first:
+            index -= max_width
+        ws = self.W1s if first else self.W2s
+        if index < self.num_advice:
+            i, j = 0, index
+        else:
+            lookup, sub = divmod(index - self.num_advice, 5)
+            first_round = sub < 3
+            if not first_round:
+                sub -= 3
+            if len(ws) == 2:
+                i, j = (0, self.num_advice + lookup * 3 + sub) if first_round else (1, lookup * 2 + sub)
+            elif len(ws) == 3:
+                i, j = (1, lookup * 3 + sub) if first_round else (2, lookup * 2 + sub)
+            else:
+                return None                                     # Error::InvalidWitnessIndex
+        if i >= len(ws) or ws[i][1] < (j + 1) * self.row_size:
+            return None
+        return ws[i][0] + j * self.row_size * 32
+
+    def columns(self):
+        """The column table for `evaluate_device`: selectors, fixed, then both instances' advice."""
+        cols = [(p, COL_BOOL) for p in self.selectors] + [(p, COL_FIELD) for p in self.fixed]
+        for a in range(2 * (self.num_advice + self.num_lookup * 5)):
+            p = self._advice(a)
+            cols.append(None if p is None else (p, COL_FIELD))
+        return cols
+
+
+def commit_cross_terms(key, evaluators, domain, lib=None):
+    """The evaluation and commit spans of commit_cross_terms (src/nifs/vanilla/mod.rs:100-127):
+    evaluators[k] is the GraphEvaluator of cross term k, or None for an absent term (a zero vector,
+    :115).  Returns (device pointer of the len(evaluators) x row_size cross terms, commitments
+    (len, 8) uint64); the caller frees the pointer (mira_fold_error_device consumes it first)."""
+    lib = lib or _lib.load()
+    n, count = domain.row_size, len(evaluators)
+    d = lib.alloc(max(1, n * count) * 32)
+    try:
+        cols = domain.columns()
+        zero = None
+        for k, ev in enumerate(evaluators):
+            if ev is None:
+                zero = zero if zero is not None else np.zeros((n, 4), dtype=np.uint64)
+                lib.upload(d + k * n * 32, zero)
+            else:
+                ev.evaluate_device(cols, domain.challenges, n, d_out=d + k * n * 32, lib=lib)
+        commits = key.commit_batch_device(d, n, count) if count else np.zeros((0, 8), dtype=np.uint64)
+    except Exception:
+        lib.free(d)
+        raise
+    return d, commits

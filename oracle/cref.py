@@ -158,3 +158,32 @@ def fold_error(field, e, cross_terms, r):
     terms = [_u64(t).reshape(-1, 4) for t in cross_terms]
     ptrs = (ctypes.c_void_p * len(terms))(*[t.ctypes.data for t in terms])
     lib().oracle_fold_error(field, _p(e), ptrs, ctypes.c_size_t(len(terms)), _p(_u64(r)), ctypes.c_size_t(len(e))); return e
+
+
+def graph_eval(field, code, num_calculations, constants, rotations, columns, challenges, num_rows):
+    """GraphEvaluator::evaluate for rows 0..num_rows (src/polynomial/graph_evaluator.rs:361-390).
+    `code` etc. in the flattened layout of include/mira_gpu.h; `columns` = list of host arrays:
+    (n, 4) uint64 field columns or 1-D uint8/bool selector columns (None = unresolved index)."""
+    code = np.ascontiguousarray(code, dtype=np.uint32)
+    constants = _u64(constants).reshape(-1, 4)
+    rotations = np.ascontiguousarray(rotations, dtype=np.int32)
+    challenges = _u64(challenges).reshape(-1, 4)
+    keep, ptrs, kinds = [], [], []
+    for c in columns:
+        if c is None:
+            ptrs.append(None); kinds.append(0); continue
+        a = np.asarray(c)
+        if a.dtype == np.uint64:
+            a = np.ascontiguousarray(a).reshape(-1, 4); kinds.append(0)
+        else:
+            a = np.ascontiguousarray(a, dtype=np.uint8); kinds.append(1)
+        keep.append(a); ptrs.append(a.ctypes.data)
+    cp = (ctypes.c_void_p * max(1, len(ptrs)))(*ptrs)
+    kinds = np.ascontiguousarray(kinds + [0], dtype=np.uint32)
+    out = np.zeros((num_rows, 4), dtype=np.uint64)
+    rc = lib().oracle_graph_eval(field, _p(code), ctypes.c_size_t(len(code)), ctypes.c_uint32(num_calculations), _p(constants), ctypes.c_uint32(len(constants)),
+                                 _p(rotations), ctypes.c_uint32(len(rotations)), cp, _p(kinds), ctypes.c_uint32(len(ptrs)),
+                                 _p(challenges), ctypes.c_uint32(len(challenges)), ctypes.c_size_t(num_rows), _p(out))
+    if rc != 0:
+        raise ValueError("oracle_graph_eval: malformed graph")
+    return out

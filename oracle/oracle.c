@@ -434,6 +434,73 @@ void oracle_fold_error(int f, u64 *e, const u64 *const *terms, size_t K, const u
     }
 }
 
+/* ------------------------------------------------------------------ cross-term evaluation
+ * GraphEvaluator::evaluate (src/polynomial/graph_evaluator.rs:361-390) for every row, rows in
+ * parallel as src/nifs/vanilla/mod.rs:104-113 does.  The graph arrives flattened exactly as
+ * include/mira_gpu.h describes (the oracle shares no code with the product, only that layout):
+ * one intermediate per calculation, as the reference keeps them (:354-359).
+ * columns[k]: host pointer; kinds[k] 0 = field elements, 1 = bytes (selector -> ONE / ZERO,
+ * src/plonk/eval.rs:57-69).  Returns 0, or -1 on malformed input.                            */
+static size_t rot_row(long row, int rot, long nrows) {          /* get_rotation_idx, :51-53 */
+    long r = (row + rot) % nrows; if (r < 0) r += nrows; return (size_t)r;
+}
+int oracle_graph_eval(int f, const uint32_t *code, size_t code_words, uint32_t ncalc, const u64 *constants, uint32_t nconst,
+                      const int32_t *rotations, uint32_t nrot, const void *const *columns, const uint32_t *kinds, uint32_t ncols,
+                      const u64 *challenges, uint32_t nchal, size_t nrows, u64 *out) {
+    const field_t *F = fld(f);
+    int bad = 0;
+    if (ncalc == 0) { memset(out, 0, nrows * 32); return 0; }  /* Ok(F::ZERO), :386-389 */
+#pragma omp parallel
+    {
+        fe *inter = (fe *)malloc((size_t)ncalc * sizeof(fe));   /* EvaluationData::intermediates */
+#pragma omp for
+        for (long row = 0; row < (long)nrows; row++) {
+            size_t pc = 0;
+            for (uint32_t i = 0; i < ncalc && !bad; i++) {
+                if (pc >= code_words) { bad = 1; break; }
+                uint32_t head = code[pc++], op = head & 0xFF, nparts = head >> 8;
+                uint32_t cnt = op <= 2 ? 2 : op == 6 ? 2 + nparts : 1;
+                if (op > 7 || pc + cnt > code_words) { bad = 1; break; }
+                fe val[2], cur;
+                for (uint32_t k = 0; k < cnt; k++) {            /* get_value, :100-134 */
+                    uint32_t s = code[pc + k], kind = s >> 29, pl = s & 0x1FFFFFFFu;
+                    fe v;
+                    if (kind == 0) { if (pl >= nconst) { bad = 1; break; } v = *(const fe *)(constants + 4 * (size_t)pl); }
+                    else if (kind == 1) { if (pl >= i) { bad = 1; break; } v = inter[pl]; }
+                    else if (kind == 3) { if (pl >= nchal) { bad = 1; break; } v = *(const fe *)(challenges + 4 * (size_t)pl); }
+                    else if (kind == 2) {
+                        uint32_t col = pl & 0xFFFFF, ri = pl >> 20;
+                        if (col >= ncols || ri >= nrot || !columns[col]) { bad = 1; break; }
+                        size_t r = rot_row(row, rotations[ri], (long)nrows);
+                        if (kinds[col] == 1) v = ((const unsigned char *)columns[col])[r] ? F->r1 : (fe){{0, 0, 0, 0}};
+                        else v = ((const fe *)columns[col])[r];
+                    } else { bad = 1; break; }
+                    if (op == 6 && k >= 2) {                    /* Horner: value = value * factor + part, :148-155 */
+                        f_mul(&cur, &cur, &val[1], F); f_add(&cur, &cur, &v, F);
+                    } else { val[k] = v; if (op == 6 && k == 0) cur = v; }
+                }
+                if (bad) break;
+                pc += cnt;
+                fe r;
+                switch (op) {                                   /* :136-158 */
+                    case 0: f_add(&r, &val[0], &val[1], F); break;
+                    case 1: f_sub(&r, &val[0], &val[1], F); break;
+                    case 2: f_mul(&r, &val[0], &val[1], F); break;
+                    case 3: f_mul(&r, &val[0], &val[0], F); break;
+                    case 4: f_add(&r, &val[0], &val[0], F); break;
+                    case 5: { fe z = {{0, 0, 0, 0}}; f_sub(&r, &z, &val[0], F); break; }
+                    case 6: r = cur; break;
+                    default: r = val[0]; break;
+                }
+                inter[i] = r;
+            }
+            if (!bad) memcpy(out + 4 * row, &inter[ncalc - 1], 32);   /* the last calculation's target, :384-385 */
+        }
+        free(inter);
+    }
+    return bad ? -1 : 0;
+}
+
 /* ------------------------------------------------------------------ NTT (src/fft.rs) */
 static fe fr_pow_u64(const fe *a, u64 e) {
     fe ee = {{e, 0, 0, 0}}, r; f_pow(&r, a, &ee, &FR); return r;

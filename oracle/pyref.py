@@ -173,6 +173,69 @@ def fold_error(e, cross_terms, r, mod):
     return out
 
 
+# ---------------------------------------------------------------- cross-term evaluation
+# Direct evaluation of an Expression tree (reference src/polynomial/expression.rs:112-120) with
+# Python integers -- independent of the calculation graph the product builds from the same tree
+# (src/polynomial/graph_evaluator.rs:261-352), so it checks graph construction and the device VM
+# together.  Trees are nested tuples:
+#   ("const", v) ("poly", index, rotation) ("chal", index) ("neg", a) ("sum", a, b)
+#   ("prod", a, b) ("scaled", a, f)            v, f: plain integers mod `mod`
+# getter: dict(selectors=[[bool]], fixed=[[int]], advice=[[int]], challenges=[int]); column index
+# space = selectors, then fixed, then advice (eval_column_var, src/plonk/eval.rs:57-69).
+def plonk_advice_location(num_advice, num_lookup, len_w1s, len_w2s, index):
+    """PlonkEvalDomain::eval_advice_var's index arithmetic (src/plonk/eval.rs:152-206):
+    advice index -> (is_first_instance, witness vector i, column j inside it), or None where the
+    reference returns Error::InvalidWitnessIndex for the witness count."""
+    max_width = num_advice + num_lookup * 5
+    is_first = index < max_width
+    if not is_first:
+        index -= max_width
+    num_witness = len_w1s if is_first else len_w2s
+    if index < num_advice:
+        return (is_first, 0, index)
+    lookup_index, lookup_sub = (index - num_advice) // 5, (index - num_advice) % 5
+    first_round = lookup_sub < 3
+    if not first_round:
+        lookup_sub -= 3
+    if num_witness == 2:
+        return (is_first, 0, num_advice + lookup_index * 3 + lookup_sub) if first_round else (is_first, 1, lookup_index * 2 + lookup_sub)
+    if num_witness == 3:
+        return (is_first, 1, lookup_index * 3 + lookup_sub) if first_round else (is_first, 2, lookup_index * 2 + lookup_sub)
+    return None
+
+
+def eval_expression(expr, getter, row, num_rows, mod):
+    kind = expr[0]
+    if kind == "const":
+        return expr[1] % mod
+    if kind == "poly":
+        index, rot = expr[1], expr[2]
+        r = (row + rot) % num_rows                       # rem_euclid, graph_evaluator.rs:51-53
+        sel, fix, adv = getter["selectors"], getter["fixed"], getter["advice"]
+        if index < len(sel):
+            return 1 if sel[index][r] else 0
+        index -= len(sel)
+        if index < len(fix):
+            return fix[index][r] % mod
+        index -= len(fix)
+        if index >= len(adv):
+            raise IndexError("column variable index out of boundary")
+        return adv[index][r] % mod
+    if kind == "chal":
+        if expr[1] >= len(getter["challenges"]):
+            raise IndexError("challenge index out of boundary")
+        return getter["challenges"][expr[1]] % mod
+    if kind == "neg":
+        return (-eval_expression(expr[1], getter, row, num_rows, mod)) % mod
+    if kind == "sum":
+        return (eval_expression(expr[1], getter, row, num_rows, mod) + eval_expression(expr[2], getter, row, num_rows, mod)) % mod
+    if kind == "prod":
+        return eval_expression(expr[1], getter, row, num_rows, mod) * eval_expression(expr[2], getter, row, num_rows, mod) % mod
+    if kind == "scaled":
+        return eval_expression(expr[1], getter, row, num_rows, mod) * expr[2] % mod
+    raise ValueError(kind)
+
+
 # ----------------------------------------------------------------------------- NTT
 def get_omega_or_inv(k, is_inverse):
     """src/fft.rs:12-23"""

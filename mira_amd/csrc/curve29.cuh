@@ -38,7 +38,7 @@ template <class F> HD Xyzz29<F> xyzz29_double_affine(const Aff29<F> &p) {
     Fe29<F> s = f29_mul(p.x, v);
     Fe29<F> m = f29_triple(f29_sqr(p.x));                       // < 6
     r.x = f29_sub<5>(f29_sqr(m), f29_dbl(s));                   // 2S < 4  -> X < 7
-    r.y = f29_sub<3>(f29_mul(m, f29_sub<8>(s, r.x)), f29_mul(w, p.y));   // (S - X) < 10, * 6 = 60 -> Y < 5
+    r.y = f29_mul2_add(m, f29_sub<8>(s, r.x), w, f29_neg<3>(p.y));       // (S - X) < 10, * 6 = 60 ; 2 * 3 (a negated base has y < 2 P) -> Y < 2
     r.zz = v; r.zzz = w;
     return r;
 }
@@ -52,7 +52,7 @@ template <class F> HD Xyzz29<F> xyzz29_double(const Xyzz29<F> &p) {
     Fe29<F> s = f29_mul(p.x, v);                                // 18
     Fe29<F> m = f29_triple(f29_sqr(p.x));                       // 81 <= 168 ; m < 6
     r.x = f29_sub<5>(f29_sqr(m), f29_dbl(s));                   // < 7
-    r.y = f29_sub<3>(f29_mul(m, f29_sub<8>(s, r.x)), f29_mul(w, p.y));   // 6 * 10 ; 2 * 5 -> < 5
+    r.y = f29_mul2_add(m, f29_sub<8>(s, r.x), w, f29_neg<6>(p.y));       // 6 * 10 ; 2 * 6 -> < 2
     r.zz = f29_mul(v, p.zz); r.zzz = f29_mul(w, p.zzz);
     return r;
 }
@@ -77,7 +77,7 @@ template <class F> HD void xyzz29_add_affine(Xyzz29<F> &acc, const Aff29<F> &q) 
     Fe29<F> ppp = f29_mul(p, pp);                               // 24
     Fe29<F> qq = f29_mul(acc.x, pp);                            // 18
     Fe29<F> x3 = f29_sub<7>(f29_sqr(r), f29_add(ppp, f29_dbl(qq)));        // 64 ; PPP + 2Q < 6 -> X3 < 9
-    Fe29<F> y3 = f29_sub<3>(f29_mul(r, f29_sub<10>(qq, x3)), f29_mul(acc.y, ppp));   // 8 * 12 = 96 ; 5 * 2 -> Y3 < 5
+    Fe29<F> y3 = f29_mul2_add(r, f29_sub<10>(qq, x3), f29_neg<6>(acc.y), ppp);      // R (Q - X3) - Y1 PPP in one reduction: 8 * 12 + 6 * 2 = 108 -> Y3 < 2
     acc.x = x3; acc.y = y3;
     acc.zz = f29_mul(acc.zz, pp);
     acc.zzz = f29_mul(acc.zzz, ppp);
@@ -102,7 +102,7 @@ template <class F> HD void xyzz29_add(Xyzz29<F> &acc, const Xyzz29<F> &q) {
     Fe29<F> ppp = f29_mul(p, pp);
     Fe29<F> qq = f29_mul(u1, pp);
     Fe29<F> x3 = f29_sub<7>(f29_sqr(r), f29_add(ppp, f29_dbl(qq)));        // < 9
-    Fe29<F> y3 = f29_sub<3>(f29_mul(r, f29_sub<10>(qq, x3)), f29_mul(s1, ppp));   // 5 * 12 -> < 5
+    Fe29<F> y3 = f29_mul2_add(r, f29_sub<10>(qq, x3), f29_neg<2>(s1), ppp);        // 5 * 12 + 2 * 2 -> < 2
     acc.x = x3; acc.y = y3;
     acc.zz = f29_mul(f29_mul(acc.zz, q.zz), pp);
     acc.zzz = f29_mul(f29_mul(acc.zzz, q.zzz), ppp);

@@ -159,6 +159,40 @@ template <class F> HD Fe29<F> f29_mul(const Fe29<F> &a, const Fe29<F> &b) {
     F29_SET(r, F29_GET(a) * F29_GET(b) / 168.9 + 1.0);
     return r;
 }
+// (a * b + c * d) * 2^-261 mod P with ONE Montgomery reduction: the two products share the 18
+// column accumulators.  All four operands must be carried (limbs < 2^29 + 8, which every f29
+// function returns): a column then holds at most 18 products < 2^58.01 plus 9 reduction products
+// < 2^58 and a carry, < 2^62.8.  Result loose, < (a b + c d) / (2^261 P) + 1 in multiples of P.
+template <class F> HD Fe29<F> f29_mul2_add(const Fe29<F> &a, const Fe29<F> &b, const Fe29<F> &c2, const Fe29<F> &d) {
+    F29_ASSERT(F29_GET(a) * F29_GET(b) + F29_GET(c2) * F29_GET(d) <= F29_RP_OVER_P);
+    uint64_t c[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) c[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+        for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)a.l[i] * b.l[j];
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+        for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)c2.l[i] * d.l[j];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        uint32_t m = ((uint32_t)c[k] * F::N0) & M29;
+#pragma unroll
+        for (int j = 0; j < 9; j++) c[k + j] += (uint64_t)m * F::P[j];
+        c[k + 1] += c[k] >> 29;
+    }
+    Fe29<F> r;
+#pragma unroll
+    for (int i = 9; i < 17; i++) {
+        r.l[i - 9] = (uint32_t)c[i] & M29;
+        c[i + 1] += c[i] >> 29;
+    }
+    r.l[8] = (uint32_t)c[17];
+    F29_SET(r, (F29_GET(a) * F29_GET(b) + F29_GET(c2) * F29_GET(d)) / 168.9 + 1.0);
+    return r;
+}
 template <class F> HD Fe29<F> f29_sqr(const Fe29<F> &a) {
     F29_ASSERT(F29_GET(a) * F29_GET(a) <= F29_RP_OVER_P);
     uint64_t c[18];

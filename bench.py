@@ -78,7 +78,7 @@ def main():
         key = cm.CommitmentKey.synthetic(cid, n)
     else:
         from mira_amd.dist import ShardedCommitmentKey
-        skey = ShardedCommitmentKey.synthetic(cid, n * world)        # rank r holds bases [r*n, (r+1)*n)
+        skey = ShardedCommitmentKey.synthetic(cid, n * world, window_bits=args.window_bits)        # rank r holds bases [r*n, (r+1)*n)
         key = skey.key
     d_scalars = cm.synth_scalars_device(cid, n, index0=index0)
     log(f"[rank {rank}] inputs generated on GPU in {time.time() - t0:.1f}s (n = 2^{args.log_n} per GPU)")

@@ -136,6 +136,7 @@ class CommitmentKey:
         """Build the fixed-base window tables in HBM (13 x the key size); large commits on this key
         then take 13 instead of 16 bucket additions per pair.  Results are bit-identical."""
         self.lib.check(self.lib.c.mira_msm_precompute(self.handle))
+        self.precomputed = True
         return self
 
     def check_on_curve(self):

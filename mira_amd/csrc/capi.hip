@@ -108,22 +108,54 @@ static int upload_consts() {
 // ------------------------------------------------------------------------------------------
 // MSM plan
 
+// Estimated time of one submission in microseconds for window width c, from measurements of this
+// pipeline on MI355X (tools/small_probe.py, tools/window_probe.py); good to ~15 %:
+//   base          the whole call on a handful of points: launches, the 16-entry minimum segment,
+//                 running sums, (c - 1)-bit scalar multiplications and window trees -- pure latency
+//   accumulate    12 000 mixed additions per microsecond beyond that first segment
+//   heavy buckets 10 per level of general additions when some bucket is cut into more than
+//                 HEAVY_SPAN partials.  The predictable ones come from the scalar lengths: the
+//                 scalars of length len share the 2^((len - 1) mod c) values their top digit can
+//                 take (254-bit scalars under c = 12 or 14: a top window of two bits), and a length
+//                 that is a multiple of c always carries a 1 into the next window
+//   digits + sort 94 000 digit slots (n * W, zero or not) per microsecond; counters of a batch:
+//                 5 800 buckets per microsecond
+// bitlen_hist: lengths of the actual scalars, summed over the batch; null = uniform field elements.
+static double plan_cost_us(uint32_t c, double n, uint32_t count, const uint32_t *bitlen_hist) {
+    static const double base_us[17] = {0, 0, 0, 0, 309, 328, 393, 409, 464, 497, 518, 551, 563, 664, 753, 797, 895};
+    const double W = std::ceil(256.0 / c), B = (double)(1u << (c - 1));
+    double h[256] = {0};                                     // scalars per length, per MSM
+    if (bitlen_hist) {
+        for (uint32_t len = 1; len < 256; len++) h[len] = (double)bitlen_hist[len] / count;
+    } else {                                                 // both moduli are 0.756 * 2^254
+        h[254] = 0.339 * n;
+        for (int len = 253; len > 200; len--) h[len] = 0.661 * n * std::exp2((double)len - 254.0);
+    }
+    double adds = 0, load = 0;
+    for (uint32_t len = 1; len < 256; len++) {
+        if (h[len] == 0) continue;
+        adds += h[len] * std::ceil((double)len / c);
+        load = std::max(load, h[len] / std::exp2((double)((len - 1) % c)));
+        if (len % c == 0) load = std::max(load, h[len]);
+    }
+    const double total_adds = adds * count;
+    const double acc = std::max(0.0, total_adds / 12000.0 - 240.0);
+    const double seg = std::max(16.0, total_adds / (256.0 * 4 * 3 * 64));
+    const double partials = load / seg;
+    const double heavy = partials > 6.0 ? 10.0 * (std::ceil(std::log2(partials)) + 3.0) : 0.0;
+    return base_us[c] + acc + heavy + n * W * count / 94000.0 + W * (count - 1) * B / 5800.0;
+}
+
 static MsmPlan make_plan(size_t n, int32_t forced_c, uint32_t count = 1, uint64_t stride = 0, const uint32_t *bitlen_hist = nullptr) {
     MsmPlan p;
-    uint32_t best_c = 4;
+    // Candidate widths: narrow ones for latency-bound sizes, 13 / 15 / 16 beyond.  12 and 14 leave
+    // full-length scalars a two-bit top window and never win; 6..11 were not worth calibrating.
+    static const uint32_t candidates[] = {4, 5, 13, 15, 16};
+    uint32_t best_c = 13;
     double best = 1e300;
-    for (uint32_t c = 4; c <= 16; c++) {
-        double W = std::ceil(256.0 / c);
-        // bucket additions: one per non-zero digit.  Dense estimate n * W, or, with the bit-length
-        // histogram of the actual scalars (summed over the batch), ceil(len / c) digits each.
-        double adds = (double)n * W;
-        if (bitlen_hist) {
-            adds = 0;
-            for (uint32_t len = 1; len < 256; len++) adds += (double)bitlen_hist[len] * std::ceil((double)len / c);
-            adds /= count;
-        }
-        double cost = adds + 6.0 * W * (double)(1u << (c - 1));
-        if (cost < best) { best = cost; best_c = c; }
+    for (uint32_t c : candidates) {
+        const double cost = plan_cost_us(c, (double)n, count, bitlen_hist);
+        if (cost < best * 0.975) { best = cost; best_c = c; }   // a wider window has to win clearly: its unmodelled costs (heavy buckets of skewed data) only grow
     }
     p.c = forced_c ? (uint32_t)forced_c : best_c;
     p.W = (256 + p.c - 1) / p.c;
@@ -142,7 +174,7 @@ static MsmPlan make_plan(size_t n, int32_t forced_c, uint32_t count = 1, uint64_
     p.L = 16;   // minimum segment length (small MSMs: more, shorter segments beat fewer fix-up links)
     p.T = (uint32_t)std::min<uint64_t>(p.lanes, ceil_div(entries, p.L));   // upper bound of segments
     // reduction chunk: the chain is 2m running-sum adds, then ceil(B/m/512) + 9 in k_window_sum
-    p.m = std::min<uint32_t>(p.B, p.B <= 4096 ? 4 : 16);   // measured: m = 8 at B = 32768 is slower (65k lanes of scalar-mul work)
+    p.m = std::min<uint32_t>(p.B, p.B <= 4096 ? 4 : 8);    // measured (tools/window_probe.py): 4 / 8 beat 16 and 32 at every size
     p.nchunks = p.B / p.m;
     return p;
 }
@@ -190,16 +222,17 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
     }
     const size_t table_min_n = getenv("MIRA_TABLE_MIN_N") ? (size_t)atoll(getenv("MIRA_TABLE_MIN_N")) : TABLE_MIN_N;   // tests lower it
     const bool table_mode = bs.tables && (sharded || n >= table_min_n) && g.forced_c == 0;
-    // data-dependent planning for single (unsharded) commits: ranks of a sharded MSM must agree on
-    // the window width, so they keep the dense estimate
-    uint32_t hist[256];
+    // Data-dependent planning for single (unsharded) commits (ranks of a sharded MSM must agree on
+    // the window width, so they keep the dense estimate).  The statistics are those of the previous
+    // commit of the same length over this key -- successive fold steps commit witnesses of one
+    // shape -- so no call waits for a pre-pass: this call's histogram is enqueued ahead of its MSM
+    // kernels and read after the synchronisation that ends it.
     const size_t hist_min_n = getenv("MIRA_PLAN_HIST_MIN_N") ? (size_t)atoll(getenv("MIRA_PLAN_HIST_MIN_N")) : PLAN_HIST_MIN_N;   // tests lower it
     const bool use_hist = !table_mode && !sharded && g.forced_c == 0 && n >= hist_min_n && d_scalars;
-    if (use_hist) {
-        int rc2 = bs.curve == MIRA_CURVE_BN256 ? scalar_bitlen_hist_bn256(d_scalars, n, 1, n, hist) : scalar_bitlen_hist_grumpkin(d_scalars, n, 1, n, hist);
-        if (rc2) return rc2;
-    }
-    MsmPlan p = make_plan(n, g.forced_c, 1, 0, use_hist ? hist : nullptr);
+    // a rank of a sharded MSM that was not given a width takes 16, whatever its chunk length: partials
+    // of different widths cannot be combined, and chunk lengths differ between ranks
+    const int32_t width = (sharded && g.forced_c == 0) ? 16 : g.forced_c;
+    MsmPlan p = make_plan(n, width, 1, 0, (use_hist && bs.stat_n == n) ? bs.stat_hist : nullptr);
     if (n >= (1ull << 31) || (uint64_t)n * p.W >= (1ull << 32)) { set_error("n too large for 32-bit entry offsets"); return MIRA_E_UNSUPPORTED; }
     if (p.W > MIRA_MAX_WINDOWS) { set_error("window configuration exceeds MIRA_MAX_WINDOWS"); return MIRA_E_UNSUPPORTED; }
     *c_out = p.c; *W_out = p.W;
@@ -212,8 +245,16 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
         return bs.curve == MIRA_CURVE_BN256 ? msm_launch_table_bn256(bs, first, d_scalars, n, out_partial)
                                              : msm_launch_table_grumpkin(bs, first, d_scalars, n, out_partial);
     }
-    if (bs.curve == MIRA_CURVE_BN256) return msm_launch_bn256(bs, first, d_scalars, n, p, out_partial);
-    return msm_launch_grumpkin(bs, first, d_scalars, n, p, out_partial);
+    if (use_hist) {
+        int rc2 = bs.curve == MIRA_CURVE_BN256 ? scalar_bitlen_hist_bn256(d_scalars, n, 1, n) : scalar_bitlen_hist_grumpkin(d_scalars, n, 1, n);
+        if (rc2) return rc2;
+    }
+    rc = bs.curve == MIRA_CURVE_BN256 ? msm_launch_bn256(bs, first, d_scalars, n, p, out_partial) : msm_launch_grumpkin(bs, first, d_scalars, n, p, out_partial);
+    if (rc == MIRA_OK && use_hist) {                         // msm_launch ends with a stream synchronisation
+        memcpy(bs.stat_hist, g.hist_host, sizeof bs.stat_hist);
+        bs.stat_n = n;
+    }
+    return rc;
 }
 
 static int combine_locked(int curve, const uint64_t *partials, size_t nparts, uint32_t c, uint32_t W, uint64_t out[8]) {

@@ -31,6 +31,7 @@ static inline hipError_t rt_d2h(void *h, const void *d, size_t n, hipStream_t s)
 static inline hipError_t rt_d2d(void *d, const void *s_, size_t n, hipStream_t s) { return hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, s); }
 static inline hipError_t rt_sync(hipStream_t s) { return hipStreamSynchronize(s); }
 static inline hipError_t rt_last() { return hipGetLastError(); }
+static inline hipError_t rt_host_alloc(void **p, size_t n) { return hipHostMalloc(p, n, hipHostMallocDefault); }
 #else
 #define RT_CHECK(expr) do { (void)(expr); } while (0)
 static inline int rt_malloc(void **p, size_t n) { *p = aligned_alloc(64, (n + 63) / 64 * 64); return *p ? 0 : 1; }
@@ -41,6 +42,7 @@ static inline int rt_d2h(void *h, const void *d, size_t n, hipStream_t) { memcpy
 static inline int rt_d2d(void *d, const void *s_, size_t n, hipStream_t) { memcpy(d, s_, n); return 0; }
 static inline int rt_sync(hipStream_t) { return 0; }
 static inline int rt_last() { return 0; }
+static inline int rt_host_alloc(void **p, size_t n) { *p = malloc(n); return *p ? 0 : 1; }
 #endif
 
 struct DevBuf {
@@ -83,7 +85,9 @@ struct Ctx {
     // NTT workspace
     DevBuf ntt_tmp, ntt_stage, ntt_tables, ntt_consts;
     DevBuf fold_consts;
-    DevBuf graph_consts, graph_ws;   // cross-term evaluator: staged program, intermediates[slot][lane]
+    DevBuf graph_consts, graph_ws;
+    DevBuf hist_dev;
+    uint32_t *hist_host = nullptr;   // 1 KiB of pinned host memory: the histogram comes back without a host-side wait   // cross-term evaluator: staged program, intermediates[slot][lane]
     std::string ntt_tables_key;
     uint64_t next_handle = 1;
 };
@@ -95,6 +99,10 @@ struct Bases {
     void *d = nullptr;
     bool owned = false;
     void *tables = nullptr;   // fixed-base window tables (table_kernels.cuh), TABLE_W * n points, or null
+    // bit-length histogram of the scalars of the previous commit of stat_n elements over this key
+    // (planning input for the next one of the same length; never affects a result)
+    mutable uint32_t stat_hist[256] = {0};
+    mutable size_t stat_n = 0;
 };
 
 void tm_begin();
@@ -118,8 +126,8 @@ int msm_launch_table_bn256(const Bases &bs, size_t first, const void *d_scalars,
 int msm_launch_table_grumpkin(const Bases &bs, size_t first, const void *d_scalars, size_t n, uint64_t *host_sums);
 int build_tables_bn256(Bases &bs);
 int build_tables_grumpkin(Bases &bs);
-int scalar_bitlen_hist_bn256(const void *d_scalars, size_t n, size_t count, size_t stride, uint32_t host_hist[256]);
-int scalar_bitlen_hist_grumpkin(const void *d_scalars, size_t n, size_t count, size_t stride, uint32_t host_hist[256]);
+int scalar_bitlen_hist_bn256(const void *d_scalars, size_t n, size_t count, size_t stride);
+int scalar_bitlen_hist_grumpkin(const void *d_scalars, size_t n, size_t count, size_t stride);
 int curve_init_bn256();
 int convert_bases_bn256(const void *d_src, void *d_dst, size_t n);
 int convert_bases_grumpkin(const void *d_src, void *d_dst, size_t n);

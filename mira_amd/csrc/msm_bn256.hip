@@ -18,4 +18,4 @@ int msm_launch_table_bn256(const Bases &bs, size_t first, const void *d_scalars,
     return msm_launch_table<Fq29, FrP>(bs, first, d_scalars, n, host_sums);
 }
 int build_tables_bn256(Bases &bs) { return build_tables<Fq29>(bs); }
-int scalar_bitlen_hist_bn256(const void *d_scalars, size_t n, size_t count, size_t stride, uint32_t host_hist[256]) { return scalar_bitlen_hist<FrP>(d_scalars, n, count, stride, host_hist); }
+int scalar_bitlen_hist_bn256(const void *d_scalars, size_t n, size_t count, size_t stride) { return scalar_bitlen_hist<FrP>(d_scalars, n, count, stride); }

@@ -18,4 +18,4 @@ int msm_launch_table_grumpkin(const Bases &bs, size_t first, const void *d_scala
     return msm_launch_table<Fr29, FqP>(bs, first, d_scalars, n, host_sums);
 }
 int build_tables_grumpkin(Bases &bs) { return build_tables<Fr29>(bs); }
-int scalar_bitlen_hist_grumpkin(const void *d_scalars, size_t n, size_t count, size_t stride, uint32_t host_hist[256]) { return scalar_bitlen_hist<FqP>(d_scalars, n, count, stride, host_hist); }
+int scalar_bitlen_hist_grumpkin(const void *d_scalars, size_t n, size_t count, size_t stride) { return scalar_bitlen_hist<FqP>(d_scalars, n, count, stride); }

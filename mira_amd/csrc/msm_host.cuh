@@ -94,9 +94,10 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size
            reinterpret_cast<uint32_t *>(g.head_key.p), reinterpret_cast<unsigned char *>(g.tail_part.p),
            reinterpret_cast<uint32_t *>(g.tail_key.p));
     tm_mark("accumulate");
-    LAUNCH(k_fixup<F>, ceil_div(p.T, 128), 128, 0, st, (const uint32_t *)plan, reinterpret_cast<const uint32_t *>(g.offsets.p),
+    const uint32_t fix_by_bucket = p.NB < p.T ? p.NB : 0u;   // fewer buckets than segments: index the fix-up by bucket
+    LAUNCH(k_fixup<F>, ceil_div(fix_by_bucket ? fix_by_bucket : p.T, 128), 128, 0, st, (const uint32_t *)plan, reinterpret_cast<const uint32_t *>(g.offsets.p),
            reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
-           reinterpret_cast<const uint32_t *>(g.tail_key.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p), heavy_count, heavy_runs, heavy_subs);
+           reinterpret_cast<const uint32_t *>(g.tail_key.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p), heavy_count, heavy_runs, heavy_subs, fix_by_bucket);
     LAUNCH_BARRIER(k_fixup_heavy_a<F>, FIXUP_HEAVY_GRID, HEAVY_BLOCK, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_subs,
                    reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<unsigned char *>(g.heavy_out.p));
     LAUNCH_BARRIER(k_fixup_heavy_b<F>, FIXUP_HEAVY_GRID, HEAVY_BLOCK, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_runs,
@@ -266,7 +267,7 @@ static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars
     tm_mark("accumulate");
     LAUNCH(k_fixup<F>, ceil_div(T, 128), 128, 0, st, (const uint32_t *)plan, reinterpret_cast<const uint32_t *>(g.offsets.p),
            reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
-           reinterpret_cast<const uint32_t *>(g.tail_key.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p), heavy_count, heavy_runs, heavy_subs);
+           reinterpret_cast<const uint32_t *>(g.tail_key.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p), heavy_count, heavy_runs, heavy_subs, 0u);
     LAUNCH_BARRIER(k_fixup_heavy_a<F>, FIXUP_HEAVY_GRID, HEAVY_BLOCK, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_subs,
                    reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<unsigned char *>(g.heavy_out.p));
     LAUNCH_BARRIER(k_fixup_heavy_b<F>, FIXUP_HEAVY_GRID, HEAVY_BLOCK, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_runs,
@@ -286,16 +287,17 @@ static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars
     return MIRA_OK;
 }
 
-// bit-length histogram of `count` scalar vectors (planning pre-pass; one small D2H + sync)
-template <class FS> static int scalar_bitlen_hist(const void *d_scalars, size_t n, size_t count, size_t stride, uint32_t host_hist[256]) {
+// bit-length histogram of `count` scalar vectors, enqueued on the work stream: the 1 KiB result
+// lands in g.hist_host (pinned) by the time the stream is next synchronised
+template <class FS> static int scalar_bitlen_hist(const void *d_scalars, size_t n, size_t count, size_t stride) {
     int rc;
-    if ((rc = g.block_sums.ensure(1024 * 4))) return rc;
-    RT_CHECK(rt_memset(g.block_sums.p, 0, 1024, g.stream));
+    if ((rc = g.hist_dev.ensure(1024))) return rc;
+    if (!g.hist_host) RT_CHECK(rt_host_alloc(reinterpret_cast<void **>(&g.hist_host), 1024));
+    RT_CHECK(rt_memset(g.hist_dev.p, 0, 1024, g.stream));
     const uint32_t blocks = std::min<uint32_t>(1024, ceil_div(n, 256));
     LAUNCH_BARRIER_FLEX(k_bitlen_hist<FS>, dim3(blocks, (uint32_t)count), 256, 0, g.stream, reinterpret_cast<const unsigned char *>(d_scalars),
-                        (uint32_t)n, (uint64_t)stride, reinterpret_cast<uint32_t *>(g.block_sums.p));
+                        (uint32_t)n, (uint64_t)stride, reinterpret_cast<uint32_t *>(g.hist_dev.p));
     RT_CHECK(rt_last());
-    RT_CHECK(rt_d2h(host_hist, g.block_sums.p, 1024, g.stream));
-    RT_CHECK(rt_sync(g.stream));
+    RT_CHECK(rt_d2h(g.hist_host, g.hist_dev.p, 1024, g.stream));
     return MIRA_OK;
 }

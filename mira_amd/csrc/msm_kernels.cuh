@@ -324,13 +324,28 @@ template <class F>
 KERNEL void __launch_bounds__(128) k_fixup(const uint32_t *__restrict__ plan, const uint32_t *__restrict__ offsets,
                     const unsigned char *__restrict__ head_part, const unsigned char *__restrict__ tail_part,
                     const uint32_t *__restrict__ tail_key, unsigned char *__restrict__ bucket_sums,
-                    uint32_t *__restrict__ heavy_ctr, U4 *__restrict__ runs, U4 *__restrict__ subs) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+                    uint32_t *__restrict__ heavy_ctr, U4 *__restrict__ runs, U4 *__restrict__ subs, uint32_t num_buckets) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t L = plan[0], T = plan[1];
-    if (t >= T) return;
-    const uint32_t key = tail_key[t];
-    if (key == KEY_NONE) return;
-    const uint32_t run_end = offsets[key + 1];
+    // One lane per cut run.  Indexed by segment (the lane that holds the run's tail partial) when
+    // segments are fewer than buckets; by bucket (num_buckets != 0) when buckets are fewer -- small
+    // MSMs, where every bucket is cut several times and only one segment in four holds a tail.
+    uint32_t t, key, run_end;
+    if (num_buckets) {
+        key = gid;
+        if (key >= num_buckets) return;
+        const uint32_t run_start = offsets[key];
+        run_end = offsets[key + 1];
+        if (run_end == run_start) return;
+        t = run_start / L;
+        if ((run_end - 1) / L == t) return;        // inside one segment: k_accumulate wrote the bucket itself
+    } else {
+        t = gid;
+        if (t >= T) return;
+        key = tail_key[t];
+        if (key == KEY_NONE) return;
+        run_end = offsets[key + 1];
+    }
     const uint32_t span = (run_end - 1) / L - t;   // lanes t+1 .. t+span hold head partials of this run
     if (span > (uint32_t)HEAVY_SPAN) {
         const uint32_t nsub = (span + HEAVY_SUB - 1) / HEAVY_SUB;

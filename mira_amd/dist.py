@@ -27,7 +27,7 @@ class ShardedCommitmentKey:
     `commit_device(d_scalars_local, n_global)` commits the first n_global scalars of the global
     vector; this rank passes the device pointer of ITS part of that prefix."""
 
-    def __init__(self, curve, local_key, total_len, group=None, lib=None):
+    def __init__(self, curve, local_key, total_len, group=None, lib=None, window_bits=0):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
@@ -38,13 +38,14 @@ class ShardedCommitmentKey:
         self.total_len = total_len
         self.lo, self.hi = chunk_bounds(total_len, self.world, self.rank)
         self.lib = lib or local_key.lib
+        self.window_bits = window_bits        # 0: derived from the global length (see _agreed_window_bits)
         assert len(local_key) == self.hi - self.lo, "local key does not match this rank's chunk"
 
     @classmethod
-    def synthetic(cls, curve, total_len, group=None, seed=0x42415345, lib=None):
+    def synthetic(cls, curve, total_len, group=None, seed=0x42415345, lib=None, window_bits=0):
         import torch.distributed as dist
         lo, hi = chunk_bounds(total_len, dist.get_world_size(group), dist.get_rank(group))
-        return cls(curve, CommitmentKey.synthetic(curve, hi - lo, seed=seed, index0=lo, lib=lib), total_len, group, lib)
+        return cls(curve, CommitmentKey.synthetic(curve, hi - lo, seed=seed, index0=lo, lib=lib), total_len, group, lib, window_bits)
 
     def len(self):
         return self.total_len
@@ -62,12 +63,29 @@ class ShardedCommitmentKey:
         self.dist.all_gather_into_tensor(out, mine, group=self.group)
         return out.cpu().numpy().view(np.uint64).reshape(self.world, -1)
 
+    def _agreed_window_bits(self, n_global):
+        """Every rank must cut its scalars into the same windows, but the ranks' chunk lengths differ
+        (a prefix of the key ends inside one rank's chunk), so the width cannot be left to each
+        rank's planner: it is derived from the global length, which all ranks know."""
+        if self.window_bits:
+            return self.window_bits
+        per_rank = -(-n_global // self.world)
+        return 13 if per_rank < (1 << 18) else 15 if per_rank < (1 << 21) else 16
+
     def commit_device(self, d_scalars_local, n_global):
-        """src/commitment.rs:78-87 over the sharded key; every rank returns the same point."""
+        """src/commitment.rs:78-87 over the sharded key; every rank returns the same point.
+        Fixed-base tables (`precompute()`) must be built on all ranks or on none."""
         if n_global > self.total_len:
             raise TooLongInput(n_global, self.total_len)
         n_local = self.local_prefix(n_global)
-        part, c, w = self.key.commit_partial_device(0, d_scalars_local, n_local)
+        tables = getattr(self.key, "precomputed", False)   # table partials have one layout whatever the length
+        if not tables:
+            self.lib.check(self.lib.c.mira_msm_set_window_bits(self._agreed_window_bits(n_global)))
+        try:
+            part, c, w = self.key.commit_partial_device(0, d_scalars_local, n_local)
+        finally:
+            if not tables:
+                self.lib.check(self.lib.c.mira_msm_set_window_bits(self.window_bits))
         gathered = self._all_gather(np.ascontiguousarray(part[: w * 16]))
         parts = np.zeros((self.world, _lib.MIRA_PARTIAL_U64), dtype=np.uint64)
         parts[:, : w * 16] = gathered

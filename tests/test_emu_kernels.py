@@ -66,11 +66,16 @@ def test_emu_partial_and_combine(emu_lib):
     d = emu_lib.alloc(n * 32)
     emu_lib.upload(d, sc)
     parts = []
-    for first, cnt in ((0, 250), (250, 350)):
-        part, c, w = key.commit_partial_device(first, d + first * 32, cnt)
-        parts.append(part)
-    got = cm.combine_partials(cid, np.stack(parts), c, w, lib=emu_lib)
-    assert (got == C.msm_pippenger(cid, sc, bs)).all()
+    want = C.msm_pippenger(cid, sc, bs)
+    for forced in (9, 0):                                      # 0: unequal chunks still share one width (16)
+        emu_lib.check(emu_lib.c.mira_msm_set_window_bits(forced))
+        parts, widths = [], set()
+        for first, cnt in ((0, 250), (250, 350)):
+            part, c, w = key.commit_partial_device(first, d + first * 32, cnt)
+            parts.append(part); widths.add((c, w))
+        assert widths == {(forced or 16, -(-256 // (forced or 16)))}
+        assert (cm.combine_partials(cid, np.stack(parts), c, w, lib=emu_lib) == want).all()
+    emu_lib.check(emu_lib.c.mira_msm_set_window_bits(0))
 
 
 @pytest.mark.parametrize("k", [0, 1, 3, 4, 10, 12])
@@ -137,14 +142,19 @@ def test_emu_fixed_base_tables(emu_lib, monkeypatch):
 
 
 def test_emu_data_dependent_planning(emu_lib, monkeypatch):
-    """The bit-length pre-pass changes only the window width, never the result."""
+    """The bit-length statistics of one commit plan the next one of the same length over the key:
+    they change only the window width, never the result."""
     monkeypatch.setenv("MIRA_PLAN_HIST_MIN_N", "1")
     cid, n = 0, 300
     bs = C.synth_bases(cid, n, seed=50)
     key = cm.CommitmentKey(cid, bs, lib=emu_lib)
     sc = C.synth_scalars(cid, n, seed=52, kind=1)
-    assert (key.commit(sc) == C.commit(cid, bs, sc)).all()
+    want = C.commit(cid, bs, sc)
+    assert (key.commit(sc) == want).all()                     # planned from the dense estimate
+    assert (key.commit(sc) == want).all()                     # planned from the first call's histogram
     assert not key.commit(np.zeros((n, 4), dtype=np.uint64)).any()
+    assert not key.commit(np.zeros((n, 4), dtype=np.uint64)).any()   # planned from an all-zero histogram
+    assert (key.commit(sc) == want).all()
 
 
 def test_emu_staged_sort(emu_lib, monkeypatch):

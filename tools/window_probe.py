@@ -9,12 +9,11 @@ for cid, n, kind in cases:
     row = []
     for c in (0, 11, 12, 13, 14, 15, 16):
         lib.check(lib.c.mira_msm_set_window_bits(c))
-        cc = key.commit_partial_device(0, d, n)[1]
         key.commit_device(d, n)
         ts = []
         for _ in range(7):
             t0 = time.perf_counter(); key.commit_device(d, n); ts.append((time.perf_counter() - t0) * 1e3)
-        row.append(f"c={c}({cc}): {sorted(ts)[3]:.3f}")
+        row.append(f"c={c}: {sorted(ts)[3]:.3f}")
     lib.check(lib.c.mira_msm_set_window_bits(0))
     print(f"curve {cid} n {n} kind {kind}  " + "  ".join(row), flush=True)
     key.close(); lib.free(d)

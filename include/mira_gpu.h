@@ -178,8 +178,8 @@ int mira_graph_eval_device(int field, const mira_graph *graph, const mira_eval_c
                            size_t num_rows, void *d_out /* num_rows field elements */);
 
 /* ---- NTT over bn256::Fr (src/fft.rs) -----------------------------------------------------
- * In place, natural order in and out.  `a` = 2^log_n elements.  log_n <= 24 in this build
- * (the field allows 28, src/fft.rs:13).                                                      */
+ * In place, natural order in and out.  `a` = 2^log_n elements, log_n <= 28 = Fr::S as in the
+ * reference (src/fft.rs:13); the device needs a second buffer of the same size above 2^12.      */
 /* best_fft(a, omega, log_n), src/fft.rs:51 */
 int mira_ntt_bn256_fr(uint64_t *a, uint32_t log_n, const uint64_t omega[4]);
 int mira_ntt_bn256_fr_device(void *d_a, uint32_t log_n, const uint64_t omega[4]);

@@ -6,7 +6,7 @@
 // ------------------------------------------------------------------------------------------
 // NTT host side
 using HFr = hostf::HFe<FrP>;
-static constexpr uint32_t NTT_PERSISTENT_GRID = 256;   // one 1024-lane workgroup per CU (144 KiB of LDS each)
+static constexpr uint32_t NTT_PERSISTENT_GRID = 256;   // workgroups per resident round: one per CU times what fits a CU
 static HFr fr_root_of_unity(bool inverse) {
     // ROOT_OF_UNITY = 7^((r-1) >> 28); multiplicative generator 7, S = 28 (halo2curves bn256::Fr)
     uint64_t e[4];
@@ -25,46 +25,84 @@ static HFr get_omega_or_inv_h(uint32_t k, bool inverse) {   // src/fft.rs:12-23
     return w;
 }
 
-// device tables for (log_n, omega): [line_tw(m1) | line_tw(m2) | t_lo | t_hi]
+// Schedule of one transform: up to three passes of lines of at most 2^max_line points
+// (n = n1 n2 n3; index algebra in ntt_device_locked).  Device tables for (log_n, omega):
+//   line_tw[p]   omega_N^j, j < N/2, for the line length N of pass p (shared when lengths repeat)
+//   lo[s], hi[s] the two halves of the post-twiddle exponent of pass s < passes - 1
 struct NttTables {
-    uint32_t m1, m2, h;
-    size_t off_tw1, off_tw2, off_lo, off_hi;
+    uint32_t passes, m[3], h[2];
+    size_t off_tw[3], off_lo[2], off_hi[2];
 };
+// test-only knob: a smaller maximum line makes the two- and three-pass schedules reachable at sizes
+// the CPU emulation can run
+static uint32_t ntt_max_log_line() {
+    const char *e = getenv("MIRA_NTT_MAX_LOG_LINE");
+    const int v = e ? atoi(e) : NTT_MAX_LOG_LINE;
+    return (uint32_t)std::min(std::max(v, 1), NTT_MAX_LOG_LINE);
+}
 static int ntt_prepare_tables(uint32_t log_n, const uint64_t omega[4], NttTables &t) {
-    t.m1 = log_n <= NTT_MAX_LOG_LINE ? log_n : (log_n + 1) / 2;
-    t.m2 = log_n - t.m1;
-    t.h = t.m1;   // exponent split for omega^(i2 * k1): low h bits / rest
-    const size_t n_tw1 = t.m1 ? (size_t)1 << (t.m1 - 1) : 1, n_tw2 = t.m2 ? (size_t)1 << (t.m2 - 1) : 1;
-    const size_t n_lo = (size_t)1 << t.h, n_hi = (size_t)1 << (log_n - t.h);
-    t.off_tw1 = 0; t.off_tw2 = t.off_tw1 + n_tw1 * TW_BYTES; t.off_lo = t.off_tw2 + n_tw2 * TW_BYTES; t.off_hi = t.off_lo + n_lo * TW_BYTES;
+    const uint32_t max_line = ntt_max_log_line();
+    t.passes = log_n <= max_line ? 1 : log_n <= 2 * max_line ? 2 : 3;
+    uint32_t rest = log_n;
+    for (uint32_t p = 0; p < 3; p++) {                        // balanced split, larger factors first
+        t.m[p] = p < t.passes ? (rest + (t.passes - p) - 1) / (t.passes - p) : 0;
+        rest -= t.m[p];
+    }
+    // exponent ranges of the post-twiddles: pass 0 uses powers of omega_n below n, pass 1 (of three)
+    // powers of omega_n^(n1) below n / n1
+    const uint32_t range[2] = {log_n, log_n - t.m[0]};
+    size_t off = 0;
+    size_t n_tw[3], n_lo[2] = {0, 0}, n_hi[2] = {0, 0};
+    for (uint32_t p = 0; p < 3; p++) {
+        n_tw[p] = (p < t.passes) ? (t.m[p] ? (size_t)1 << (t.m[p] - 1) : 1) : 0;
+        t.off_tw[p] = off; off += n_tw[p] * TW_BYTES;
+    }
+    for (uint32_t q = 0; q + 1 < t.passes; q++) {
+        t.h[q] = (range[q] + 1) / 2;
+        n_lo[q] = (size_t)1 << t.h[q]; n_hi[q] = (size_t)1 << (range[q] - t.h[q]);
+        t.off_lo[q] = off; off += n_lo[q] * TW_BYTES;
+        t.off_hi[q] = off; off += n_hi[q] * TW_BYTES;
+    }
     std::string key((const char *)omega, 32);
-    key += std::to_string(log_n);
+    key += std::to_string(log_n) + "/" + std::to_string(max_line);
     if (key == g.ntt_tables_key) return MIRA_OK;
     int rc;
-    if ((rc = g.ntt_tables.ensure(t.off_hi + n_hi * TW_BYTES))) return rc;
+    if ((rc = g.ntt_tables.ensure(off))) return rc;
     if ((rc = g.ntt_consts.ensure(256))) return rc;
     RT_CHECK(rt_h2d(g.ntt_consts.p, omega, 32, g.stream));
     unsigned char *tab = reinterpret_cast<unsigned char *>(g.ntt_tables.p);
     const unsigned char *w = reinterpret_cast<const unsigned char *>(g.ntt_consts.p);
     const unsigned char *none = nullptr;
     const uint64_t n = (uint64_t)1 << log_n;
-    LAUNCH(k_pow_table<Fr29>, ceil_div(n_tw1, 256), 256, 0, g.stream, w, n >> t.m1, (uint32_t)n_tw1, none, tab + t.off_tw1);
-    if (t.m2) {
-        LAUNCH(k_pow_table<Fr29>, ceil_div(n_tw2, 256), 256, 0, g.stream, w, n >> t.m2, (uint32_t)n_tw2, none, tab + t.off_tw2);
-        LAUNCH(k_pow_table<Fr29>, ceil_div(n_lo, 256), 256, 0, g.stream, w, (uint64_t)1, (uint32_t)n_lo, none, tab + t.off_lo);
-        LAUNCH(k_pow_table<Fr29>, ceil_div(n_hi, 256), 256, 0, g.stream, w, (uint64_t)1 << t.h, (uint32_t)n_hi, none, tab + t.off_hi);
+    for (uint32_t p = 0; p < t.passes; p++)
+        LAUNCH(k_pow_table<Fr29>, ceil_div(n_tw[p], 256), 256, 0, g.stream, w, n >> t.m[p], (uint32_t)n_tw[p], none, tab + t.off_tw[p]);
+    for (uint32_t q = 0; q + 1 < t.passes; q++) {
+        const uint64_t base_stride = q == 0 ? 1 : (uint64_t)1 << t.m[0];   // omega_n, then omega_n^(n1)
+        LAUNCH(k_pow_table<Fr29>, ceil_div(n_lo[q], 256), 256, 0, g.stream, w, base_stride, (uint32_t)n_lo[q], none, tab + t.off_lo[q]);
+        LAUNCH(k_pow_table<Fr29>, ceil_div(n_hi[q], 256), 256, 0, g.stream, w, base_stride << t.h[q], (uint32_t)n_hi[q], none, tab + t.off_hi[q]);
     }
     RT_CHECK(rt_last());
     g.ntt_tables_key = key;
     return MIRA_OK;
 }
 
-// best_fft on device memory, optional final scale (Montgomery, host limbs) for ifft
+// best_fft on device memory, optional final scale (Montgomery, host limbs) for ifft.
+//
+// One pass (n <= 4096): the line is the transform.  Two passes, n = n1 n2 (four-step), input index
+// i = i1 n2 + i2, output k = k1 + n1 k2:
+//   pass 0  for every i2: length-n1 transform over i1 (stride n2), times w^(i2 k1)  -> tmp[i2 n1 + k1]
+//   pass 1  for every k1: length-n2 transform over i2 (stride n1)                    -> a[k1 + n1 k2]
+// Three passes, n = n1 n2 n3 (log_n 25..28), m = n2 n3, i = i1 m + j, j = j2 n3 + j3,
+// k = k1 + n1 (k2 + n2 k3) -- the four-step split applied to n = n1 m and again to m = n2 n3:
+//   pass 0  for every j: length-n1 over i1 (stride m), times w^(j k1)               -> tmp[j n1 + k1]
+//   pass 1  for every (j3, k1): length-n2 over j2 (stride n3 n1), times w_m^(j3 k2)  -> a[j3 n1 n2 + k2 n1 + k1]
+//   pass 2  for every (k2, k1): length-n3 over j3 (stride n1 n2), in place           -> a[k1 + n1 k2 + n1 n2 k3]
+// (pass 2 reads and writes one and the same set of addresses per line).
 static int ntt_device_locked(void *d_a, uint32_t log_n, const uint64_t omega[4], const uint64_t *scale) {
     int rc;
     if (!d_a || !omega) { set_error("null argument"); return MIRA_E_BAD_ARG; }
     if (log_n > 28) { set_error("k=" + std::to_string(log_n) + " should no larger than F::S=28"); return MIRA_E_BAD_ARG; }
-    if (log_n > 2 * NTT_MAX_LOG_LINE) { set_error("log_n > 24 is not supported by this build"); return MIRA_E_UNSUPPORTED; }
+    if (log_n > 3 * ntt_max_log_line()) { set_error("log_n exceeds three passes of the configured line length"); return MIRA_E_UNSUPPORTED; }
     NttTables t;
     tm_begin();
     if ((rc = ntt_prepare_tables(log_n, omega, t))) return rc;
@@ -91,25 +129,31 @@ static int ntt_device_locked(void *d_a, uint32_t log_n, const uint64_t omega[4],
     const unsigned char *cnull = nullptr;
     auto threads_for = [](uint32_t m) { return std::min<uint32_t>(1024, std::max<uint32_t>(64, (1u << m) / 2)); };
     auto lds_for = [](uint32_t m) { return ((size_t)NTT_LDS_BYTES_PER_ELEM << m) + 16 + ((size_t)NTT_LDS_BYTES_PER_ELEM << NTT_LDS_TW_LOG); };
-    if (t.m2 == 0) {
-        NttPass ps{t.m1, 1, 0, 1, 0, 1, 0xFFFFFFFFu, 0u};
-        LAUNCH_BARRIER(k_ntt_lines<Fr29>, 1, threads_for(t.m1), lds_for(t.m1), g.stream, (const unsigned char *)a, a, ps,
-                       tab + t.off_tw1, cnull, cnull, (const unsigned char *)scale_d);
-        tm_mark("ntt_single");
+    auto run = [&](const NttPass &ps, const unsigned char *src, unsigned char *dst, uint32_t p, int tw, const char *name) {
+        // persistent grid: as many workgroups per CU as LDS and the 2048-lane limit allow (one for
+        // 4096-point lines, eight for the 512-point lines of the three-pass schedule)
+        const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(8, (160 * 1024) / lds_for(ps.log_len)), 2048 / threads_for(ps.log_len)));
+        LAUNCH_BARRIER(k_ntt_lines<Fr29>, std::min<uint32_t>(ps.nlines, NTT_PERSISTENT_GRID * per_cu), threads_for(ps.log_len), lds_for(ps.log_len), g.stream, src, dst, ps,
+                       tab + t.off_tw[p], tw >= 0 ? tab + t.off_lo[tw] : cnull, tw >= 0 ? tab + t.off_hi[tw] : cnull,
+                       tw >= 0 ? cnull : (const unsigned char *)scale_d);
+        tm_mark(name);
+    };
+    const uint64_t n1 = (uint64_t)1 << t.m[0], n2 = (uint64_t)1 << t.m[1], n3 = (uint64_t)1 << t.m[2];
+    const uint32_t NONE = 0xFFFFFFFFu;
+    if (t.passes == 1) {
+        run(NttPass{t.m[0], 1, 0, 0, 0, 0, 1, 0, 0, 1, NONE, 0u}, a, a, 0, -1, "ntt_single");
     } else {
-        const uint64_t n1 = (uint64_t)1 << t.m1, n2 = (uint64_t)1 << t.m2;
         if ((rc = g.ntt_tmp.ensure(((size_t)32) << log_n))) return rc;
         unsigned char *tmp = reinterpret_cast<unsigned char *>(g.ntt_tmp.p);
-        // pass 1: columns i2 of the n1 x n2 view; B[k1][i2] * omega^(i2 k1) -> tmp[i2 * n1 + k1]
-        NttPass p1{t.m1, (uint32_t)n2, 1, n2, n1, 1, t.h, 0u};
-        LAUNCH_BARRIER(k_ntt_lines<Fr29>, std::min<uint32_t>((uint32_t)n2, NTT_PERSISTENT_GRID), threads_for(t.m1), lds_for(t.m1), g.stream, (const unsigned char *)a, tmp, p1,
-                       tab + t.off_tw1, tab + t.off_lo, tab + t.off_hi, cnull);
-        tm_mark("ntt_pass1");
-        // pass 2: for each k1 the length-n2 transform over i2; X[k1 + n1 k2] -> a
-        NttPass p2{t.m2, (uint32_t)n1, 1, n1, 1, n1, 0xFFFFFFFFu, 0u};
-        LAUNCH_BARRIER(k_ntt_lines<Fr29>, std::min<uint32_t>((uint32_t)n1, NTT_PERSISTENT_GRID), threads_for(t.m2), lds_for(t.m2), g.stream, (const unsigned char *)tmp, a, p2,
-                       tab + t.off_tw2, cnull, cnull, (const unsigned char *)scale_d);
-        tm_mark("ntt_pass2");
+        if (t.passes == 2) {
+            run(NttPass{t.m[0], (uint32_t)n2, 0, 0, 1, 0, n2, n1, 0, 1, t.h[0], 0u}, a, tmp, 0, 0, "ntt_pass1");
+            run(NttPass{t.m[1], (uint32_t)n1, 0, 0, 1, 0, n1, 1, 0, n1, NONE, 0u}, tmp, a, 1, -1, "ntt_pass2");
+        } else {
+            const uint64_t m = n2 * n3;
+            run(NttPass{t.m[0], (uint32_t)m, 0, 0, 1, 0, m, n1, 0, 1, t.h[0], 0u}, a, tmp, 0, 0, "ntt_pass1");
+            run(NttPass{t.m[1], (uint32_t)(n1 * n3), t.m[0], t.m[0], n1, 1, n3 * n1, n1 * n2, 1, n1, t.h[1], 0u}, tmp, a, 1, 1, "ntt_pass2");
+            run(NttPass{t.m[2], (uint32_t)(n1 * n2), 0, 0, 1, 0, n1 * n2, 1, 0, n1 * n2, NONE, 0u}, a, a, 2, -1, "ntt_pass3");
+        }
     }
     RT_CHECK(rt_last());
     RT_CHECK(rt_sync(g.stream));

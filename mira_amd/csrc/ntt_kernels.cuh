@@ -50,12 +50,13 @@ KERNEL void k_pow_table(const unsigned char *__restrict__ base, uint64_t stride,
 
 struct NttPass {
     uint32_t log_len;          // line length N = 1 << log_len (<= 4096)
-    uint32_t nlines;           // number of lines = grid size
-    uint64_t in_line_stride;   // element index of line l, element q: l * in_line_stride + q * in_elem_stride
-    uint64_t in_elem_stride;
-    uint64_t out_line_stride;
-    uint64_t out_elem_stride;
-    uint32_t tw_shift;         // post-twiddle omega^(l * k): T_hi[e >> tw_shift] * T_lo[e & mask]; 0xFFFFFFFF = none
+    uint32_t nlines;           // number of lines
+    // line l = q << split | r starts at element q * hi + r * lo; its elements are elem_stride apart
+    uint32_t split;
+    uint32_t tw_line_shift;    // post-twiddle exponent (l >> tw_line_shift) * k
+    uint64_t in_hi, in_lo, in_elem_stride;
+    uint64_t out_hi, out_lo, out_elem_stride;
+    uint32_t tw_shift;         // post-twiddle w^e = T_hi[e >> tw_shift] * T_lo[e & mask]; 0xFFFFFFFF = none
     uint32_t reserved;
 };
 
@@ -96,6 +97,7 @@ KERNEL void __launch_bounds__(1024) k_ntt_lines(const unsigned char *__restrict_
     const uint32_t N = 1u << ps.log_len;
     NttLds<F> L{lds, lds + N, reinterpret_cast<uint32_t *>(lds + 2 * (size_t)N)};
     const uint32_t lo_mask = ps.tw_shift == 0xFFFFFFFFu ? 0 : ((1u << ps.tw_shift) - 1u);
+    const uint32_t split_mask = (1u << ps.split) - 1u;
     // Twiddles of layers 0..tw_layers-1 (at most 256 values) sit in LDS behind the line.  Vector
     // memory operations retire in order, so a twiddle fetched from global memory in a butterfly
     // layer first waits for the whole prefetch of the next line issued before it; with the early
@@ -120,7 +122,8 @@ KERNEL void __launch_bounds__(1024) k_ntt_lines(const unsigned char *__restrict_
     constexpr int PRE = 4;                               // N / blockDim.x <= 4 (4096 points, 1024 lanes)
     Fe<S> pre[PRE];
     auto fetch = [&](uint32_t idx) {
-        const unsigned char *in = src + (size_t)line_of(idx) * ps.in_line_stride * 32;
+        const uint32_t fl = line_of(idx);
+        const unsigned char *in = src + ((size_t)(fl >> ps.split) * ps.in_hi + (size_t)(fl & split_mask) * ps.in_lo) * 32;
 #pragma unroll
         for (int k = 0; k < PRE; k++) {
             uint32_t q = threadIdx.x + k * blockDim.x;
@@ -158,12 +161,12 @@ KERNEL void __launch_bounds__(1024) k_ntt_lines(const unsigned char *__restrict_
             }
             __syncthreads();
         }
-        unsigned char *out = dst + (size_t)line * ps.out_line_stride * 32;
+        unsigned char *out = dst + ((size_t)(line >> ps.split) * ps.out_hi + (size_t)(line & split_mask) * ps.out_lo) * 32;
         const double bound = 1.0 + 3.0 * ps.log_len;
         for (uint32_t k = threadIdx.x; k < N; k += blockDim.x) {
             Fe29<F> v = L.load(k, bound);
             if (ps.tw_shift != 0xFFFFFFFFu) {
-                uint64_t e = (uint64_t)line * k;
+                uint64_t e = (uint64_t)(line >> ps.tw_line_shift) * k;
                 Fe29<F> tw = f29_mul(tw_load<F>(t_hi + (size_t)(e >> ps.tw_shift) * TW_BYTES), tw_load<F>(t_lo + (size_t)(e & lo_mask) * TW_BYTES));
                 v = f29_mul(v, tw);
             } else {

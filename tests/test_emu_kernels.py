@@ -9,6 +9,7 @@ import pytest
 from helpers import golden_msm_case, load_golden, mont_to_ints
 from mira_amd import commitment as cm
 from mira_amd import fft as F
+from mira_amd import _lib
 from oracle import cref as C
 from oracle import pyref as P
 
@@ -95,6 +96,22 @@ def test_emu_ntt_four_step(emu_lib):
     assert (F.fft(a, k, lib=emu_lib) == C.fft(a, k)).all()
     w = C.get_omega_or_inv(k, True)
     assert (F.best_fft(a, w, k, lib=emu_lib) == C.best_fft(a, w, k)).all()
+
+
+@pytest.mark.parametrize("max_line,ks", [(3, (4, 5, 6, 7, 8, 9)), (4, (9, 11, 12)), (2, (5, 6))])
+def test_emu_ntt_pass_schedules(emu_lib, monkeypatch, max_line, ks):
+    """Two- and three-pass schedules (the latter serves log_n 25..28 on the GPU) at emulation sizes:
+    the test-only MIRA_NTT_MAX_LOG_LINE shortens the lines so that every split is exercised."""
+    monkeypatch.setenv("MIRA_NTT_MAX_LOG_LINE", str(max_line))
+    for k in ks:
+        a = C.synth_scalars(0, 1 << k, seed=2000 + k)
+        assert (F.fft(a, k, lib=emu_lib) == C.fft(a, k)).all(), k
+        assert (F.ifft(a, k, lib=emu_lib) == C.ifft(a, k)).all(), k
+    w = C.get_omega_or_inv(ks[-1], True)
+    a = C.synth_scalars(0, 1 << ks[-1], seed=7)
+    assert (F.best_fft(a, w, ks[-1], lib=emu_lib) == C.best_fft(a, w, ks[-1])).all()
+    with pytest.raises(_lib.MiraError):
+        F.fft(C.synth_scalars(0, 1 << (3 * max_line + 1), seed=1), 3 * max_line + 1, lib=emu_lib)
 
 
 def test_emu_omega(emu_lib):

@@ -64,3 +64,13 @@ def test_full_size_2p24_properties(gpu_lib):
     w = C.get_omega_or_inv(k, False)
     assert (fe[0] == e1[1]).all() and (fe[1] == w).all()
     assert (fe[2] == C.f_mul(C.FIELD_FR, w, w)).all()
+
+
+def test_three_pass_2p25_vs_oracle(gpu_lib):
+    """log_n 25..28 take three passes of lines (n = n1 n2 n3): 2^25 bit-exact against the oracle,
+    forward and inverse."""
+    k = 25
+    a = C.synth_scalars(0, 1 << k, seed=91)
+    fa = F.fft(a, k)
+    assert (fa == C.fft(a, k)).all()
+    assert (F.ifft(fa, k) == a).all()

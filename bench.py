@@ -402,6 +402,34 @@ def extras(lib, cm, with_cpu):
             lib.free(p)
     except Exception as e:
         ex["cross_term_eval_k17"] = {"error": repr(e)}
+
+    # ---- ProtoGalaxy's weighted tree reduction: compute_F's shape at k = 17
+    # with 8 gates -- 2^20 gate evaluations folded for 32 challenges
+    try:
+        levels, points = 20, 32
+        n = 1 << levels
+        d = cm.synth_scalars_device(cm.CURVE_BN256, n, seed=0x4000)
+        d_w = cm.synth_scalars_device(cm.CURVE_BN256, points * levels, seed=0x4001)
+        w = lib.download(d_w, (points * levels, 4))
+        lib.free(d_w)
+        out = np.zeros((points, 4), dtype=np.uint64)
+        call = lambda: lib.check(lib.c.mira_pow_tree_reduce_device(1, ctypes.c_void_p(d), n, 0, w.ctypes.data_as(ctypes.c_void_p), points,
+                                                                   out.ctypes.data_as(ctypes.c_void_p)))
+        call()
+        walls = []
+        for _ in range(7):
+            t0 = time.perf_counter(); call(); walls.append((time.perf_counter() - t0) * 1e3)
+        ex["protogalaxy_tree_2p20x32"] = {"ms": round(sorted(walls)[3], 3), "leaves": n, "challenges": points,
+                                          "G_leaf_challenge_pairs_per_s": round(n * points / sorted(walls)[3] / 1e6, 2)}
+        if with_cpu:
+            from oracle import cref as C
+            host = lib.download(d, (n, 4))
+            t0 = time.perf_counter(); want = C.pow_tree(1, host, w.reshape(points, levels, 4)); dtc = (time.perf_counter() - t0) * 1e3
+            ex["protogalaxy_tree_2p20x32"].update({"cpu_ms": round(dtc, 1), "cpu_cores": min(points, C.num_threads()), "cpu_kind": "port",
+                                                   "bit_exact": bool((out == want).all())})
+        lib.free(d)
+    except Exception as e:
+        ex["protogalaxy_tree_2p20x32"] = {"error": repr(e)}
     return ex
 
 

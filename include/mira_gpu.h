@@ -177,6 +177,22 @@ int mira_graph_eval_device(int field, const mira_graph *graph, const mira_eval_c
                            const uint64_t *challenges /* num_challenges * 4 limbs, host */, uint32_t num_challenges,
                            size_t num_rows, void *d_out /* num_rows field elements */);
 
+/* ---- ProtoGalaxy's polynomial pipeline around the NTT (src/nifs/protogalaxy/poly/mod.rs) -------
+ * mira_pow_tree_reduce_device: the weighted tree reduction of compute_F (:131-166) and compute_G
+ * (:263-290), itertools::tree_reduce with node(left, right) = left + right * weights[p][height]:
+ *     out[p] = sum_i leaves[p][i] * prod_{j : bit j of i} weights[p][j],   i < n_leaves = 2^levels
+ * leaves: device; point p's leaves start at element p * leaf_point_stride, 0 = every point reads
+ * the same leaves (compute_F: the challenge sits on the edges; compute_G: in the leaves).
+ * weights: host, num_points x levels elements.  out: host, num_points elements -- the input of
+ * the small ifft that yields the coefficients.  n_leaves must be a power of two (the reference's
+ * tree is `unreachable!` otherwise) -> MIRA_E_UNSUPPORTED.
+ * mira_lincomb_device: out[i] = sum_k coeffs[k] * vecs[k][i], k < num_vecs <= 16 -- the witness of
+ * FoldedTrace at one challenge, L_0(X) * acc + sum_j L_j(X) * trace_j (folded_trace.rs:54-131). */
+int mira_pow_tree_reduce_device(int field, const void *d_leaves, size_t n_leaves, size_t leaf_point_stride,
+                                const uint64_t *weights, uint32_t num_points, uint64_t *out);
+int mira_lincomb_device(int field, void *d_out, const void *const *d_vecs, const uint64_t *coeffs /* num_vecs * 4 limbs, host */,
+                        size_t num_vecs, size_t n);
+
 /* ---- NTT over bn256::Fr (src/fft.rs) -----------------------------------------------------
  * In place, natural order in and out.  `a` = 2^log_n elements, log_n <= 28 = Fr::S as in the
  * reference (src/fft.rs:13); the device needs a second buffer of the same size above 2^12.      */

@@ -563,6 +563,32 @@ int mira_fold_error_device(int field, void *d_e, const void *const *d_cross_term
     if (!n || !num_terms) return MIRA_OK;
     return fold_error_device(field, d_e, d_cross_terms, num_terms, r, n);
 }
+int mira_lincomb_device(int field, void *d_out, const void *const *d_vecs, const uint64_t *coeffs, size_t num_vecs, size_t n) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    if ((field != MIRA_FIELD_FQ && field != MIRA_FIELD_FR) || num_vecs == 0 || num_vecs > 16 || !d_vecs || !coeffs || (n && !d_out)) { set_error("bad linear-combination arguments"); return MIRA_E_BAD_ARG; }
+    for (size_t k = 0; k < num_vecs; k++)
+        if (n && !d_vecs[k]) { set_error("null vector"); return MIRA_E_BAD_ARG; }
+    if (!n) return MIRA_OK;
+    return lincomb_device(field, d_out, d_vecs, coeffs, num_vecs, n);
+}
+int mira_pow_tree_reduce_device(int field, const void *d_leaves, size_t n_leaves, size_t leaf_point_stride, const uint64_t *weights, uint32_t num_points, uint64_t *out) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    if ((field != MIRA_FIELD_FQ && field != MIRA_FIELD_FR) || !d_leaves || !out || num_points == 0 || num_points > 65535 || n_leaves == 0) { set_error("bad tree-reduction arguments"); return MIRA_E_BAD_ARG; }
+    if (n_leaves & (n_leaves - 1)) {
+        // itertools::tree_reduce would pair nodes of different heights: `unreachable!` in the reference
+        set_error("tree reduction needs a power-of-two number of leaves, got " + std::to_string(n_leaves));
+        return MIRA_E_UNSUPPORTED;
+    }
+    uint32_t levels = 0;
+    while (((size_t)1 << levels) < n_leaves) levels++;
+    if (levels && !weights) { set_error("null weights"); return MIRA_E_BAD_ARG; }
+    if (leaf_point_stride != 0 && leaf_point_stride < n_leaves) { set_error("leaf_point_stride shorter than the leaves"); return MIRA_E_BAD_ARG; }
+    return pow_tree_reduce_device(field, d_leaves, levels, leaf_point_stride, weights, num_points, out);
+}
 int mira_graph_eval_device(int field, const mira_graph *graph, const mira_eval_column *columns, uint32_t num_columns, const uint64_t *challenges,
                            uint32_t num_challenges, size_t num_rows, void *d_out) {
     std::lock_guard<std::mutex> lk(g_lock);

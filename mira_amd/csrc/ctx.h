@@ -87,6 +87,7 @@ struct Ctx {
     DevBuf fold_consts;
     DevBuf graph_consts, graph_ws;
     DevBuf hist_dev;
+    DevBuf tree_w, tree_a, tree_b;   // weighted tree reduction: level weights, ping-pong partial results
     uint32_t *hist_host = nullptr;   // 1 KiB of pinned host memory: the histogram comes back without a host-side wait   // cross-term evaluator: staged program, intermediates[slot][lane]
     std::string ntt_tables_key;
     uint64_t next_handle = 1;
@@ -142,6 +143,8 @@ int check_bases_grumpkin(const Bases &bs, uint32_t *d_bad);
 // fold.hip
 int fold_witness_device(int field, void *d_out, const void *d_w1, const void *d_w2, const uint64_t r[4], size_t n);
 int fold_error_device(int field, void *d_e, const void *const *d_terms, size_t K, const uint64_t r[4], size_t n);
+int lincomb_device(int field, void *d_out, const void *const *d_vecs, const uint64_t *coeffs, size_t K, size_t n);
+int pow_tree_reduce_device(int field, const void *d_leaves, uint32_t levels, size_t leaf_point_stride, const uint64_t *weights, uint32_t P, uint64_t *out);
 int export_bases_bn256(const Bases &bs, size_t first, size_t n, void *d_out);
 int export_bases_grumpkin(const Bases &bs, size_t first, size_t n, void *d_out);
 

@@ -57,6 +57,73 @@ template <class F, class FP> static int fold_error_t(void *d_e, const void *cons
     tm_end();
     return MIRA_OK;
 }
+template <class F, class FP> static int lincomb_t(void *d_out, const void *const *d_vecs, const uint64_t *coeffs, size_t K, size_t n) {
+    int rc;
+    if ((rc = g.fold_consts.ensure(48 * (FOLD_MAX_TERMS + 1)))) return rc;
+    uint32_t cm[12 * FOLD_MAX_TERMS];
+    FoldTerms vecs;
+    memset(&vecs, 0, sizeof vecs);
+    for (size_t k = 0; k < K; k++) {
+        to_mult48<FP>(coeffs + 4 * k, cm + 12 * k);
+        vecs.t[k] = reinterpret_cast<const unsigned char *>(d_vecs[k]);
+    }
+    RT_CHECK(rt_h2d(reinterpret_cast<unsigned char *>(g.fold_consts.p) + 48, cm, 48 * K, g.stream));
+    tm_begin();
+    LAUNCH(k_lincomb<F>, fold_grid(n), 256, 0, g.stream, reinterpret_cast<unsigned char *>(d_out), vecs, (uint32_t)K,
+           (const unsigned char *)(reinterpret_cast<unsigned char *>(g.fold_consts.p) + 48), (uint64_t)n);
+    tm_mark("lincomb");
+    RT_CHECK(rt_last());
+    RT_CHECK(rt_sync(g.stream));
+    tm_end();
+    return MIRA_OK;
+}
+int lincomb_device(int field, void *d_out, const void *const *d_vecs, const uint64_t *coeffs, size_t K, size_t n) {
+    return field == 1 ? lincomb_t<Fr29, FrP>(d_out, d_vecs, coeffs, K, n) : lincomb_t<Fq29, FqP>(d_out, d_vecs, coeffs, K, n);
+}
+
+// Rounds of k_pow_tree until one value per point is left: each round folds up to 11 levels
+// (8 leaves per lane, 256 lanes per workgroup).
+template <class FP> static int pow_tree_t(const void *d_leaves, uint32_t levels_total, size_t leaf_point_stride, const uint64_t *weights, uint32_t P, uint64_t *out) {
+    int rc;
+    const size_t n = (size_t)1 << levels_total;
+    if (levels_total == 0) {                                  // a single leaf per point is its own root
+        for (uint32_t p = 0; p < P; p++) RT_CHECK(rt_d2h(out + 4 * p, reinterpret_cast<const unsigned char *>(d_leaves) + (size_t)p * leaf_point_stride * 32, 32, g.stream));
+        RT_CHECK(rt_sync(g.stream));
+        return MIRA_OK;
+    }
+    const size_t wbytes = (size_t)P * levels_total * 32;
+    const size_t first_out = n >> std::min<uint32_t>(levels_total, 11);
+    if ((rc = g.tree_w.ensure(wbytes))) return rc;
+    if ((rc = g.tree_a.ensure(std::max<size_t>(1, first_out) * P * 32))) return rc;
+    if ((rc = g.tree_b.ensure(std::max<size_t>(1, first_out >> std::min<size_t>(11, levels_total > 11 ? levels_total - 11 : 0)) * P * 32 + 32))) return rc;
+    RT_CHECK(rt_h2d(g.tree_w.p, weights, wbytes, g.stream));
+    tm_begin();
+    const unsigned char *in = reinterpret_cast<const unsigned char *>(d_leaves);
+    uint64_t in_stride = leaf_point_stride;
+    uint32_t level0 = 0;
+    size_t n_cur = n;
+    unsigned char *bufs[2] = {reinterpret_cast<unsigned char *>(g.tree_a.p), reinterpret_cast<unsigned char *>(g.tree_b.p)};
+    int which = 0;
+    while (level0 < levels_total) {
+        const uint32_t levels = std::min<uint32_t>(11, levels_total - level0);
+        const uint32_t serial = levels > 8 ? levels - 8 : 0;
+        const uint32_t block = 1u << (levels - serial);
+        const size_t n_out = n_cur >> levels;
+        LAUNCH_BARRIER(k_pow_tree<FP>, dim3((uint32_t)n_out, P), block, (size_t)block * 32, g.stream, in, in_stride, serial, levels, level0,
+                       (const unsigned char *)g.tree_w.p, levels_total, bufs[which], (uint64_t)n_out);
+        in = bufs[which]; in_stride = n_out; n_cur = n_out; level0 += levels; which ^= 1;
+    }
+    tm_mark("pow_tree");
+    RT_CHECK(rt_last());
+    RT_CHECK(rt_d2h(out, in, (size_t)P * 32, g.stream));     // n_cur == 1: point p's root at element p
+    RT_CHECK(rt_sync(g.stream));
+    tm_end();
+    return MIRA_OK;
+}
+int pow_tree_reduce_device(int field, const void *d_leaves, uint32_t levels, size_t leaf_point_stride, const uint64_t *weights, uint32_t P, uint64_t *out) {
+    return field == 1 ? pow_tree_t<FrP>(d_leaves, levels, leaf_point_stride, weights, P, out) : pow_tree_t<FqP>(d_leaves, levels, leaf_point_stride, weights, P, out);
+}
+
 int fold_witness_device(int field, void *d_out, const void *d_w1, const void *d_w2, const uint64_t r[4], size_t n) {
     return field == 1 ? fold_witness_t<Fr29, FrP>(d_out, d_w1, d_w2, r, n) : fold_witness_t<Fq29, FqP>(d_out, d_w1, d_w2, r, n);
 }

@@ -49,3 +49,55 @@ KERNEL void k_fold_error(unsigned char *__restrict__ e, FoldTerms terms, uint32_
         fe_store(e + i * 32, acc);
     }
 }
+
+// out[i] = sum_k coeffs[k] * vecs[k][i]   (arbitrary coefficients, multiplier form, 48 B each):
+// FoldedTrace's witness folding, reference src/nifs/protogalaxy/poly/folded_trace.rs:54-131 --
+// per challenge X the cell L_0(X) * acc[col][row] + sum_j L_j(X) * trace_j[col][row].
+template <class F>
+KERNEL void k_lincomb(unsigned char *__restrict__ out, FoldTerms vecs, uint32_t K, const unsigned char *__restrict__ coeffs, uint64_t n) {
+    using S = typename F::Sat;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        Fe<S> acc = fe_zero<S>();
+        for (uint32_t k = 0; k < K; k++) {
+            Fe<S> t = fe_load<S>(vecs.t[k] + i * 32);
+            acc = fe_add(acc, fold_canonical(f29_mul(f29_unpack_canonical<F>(t), fold_const_load<F>(coeffs + (size_t)k * 48))));
+        }
+        fe_store(out + i * 32, acc);
+    }
+}
+
+// One round of ProtoGalaxy's weighted tree reduction (compute_F / compute_G, reference
+// src/nifs/protogalaxy/poly/mod.rs:131-166, 263-290): node(left, right) at height j is
+// left + right * w[p][j].  A workgroup folds 2^levels consecutive values of point p = blockIdx.y:
+// each lane first folds 2^serial of them in registers, then the workgroup folds log2(blockDim.x)
+// more levels through LDS.  in: point p's values start at element p * in_stride (0: every point
+// reads the same leaves); w: [p][total_levels] canonical Montgomery elements.
+static constexpr uint32_t TREE_MAX_SERIAL = 3;
+template <class FP>
+KERNEL void k_pow_tree(const unsigned char *__restrict__ in, uint64_t in_stride, uint32_t serial, uint32_t levels, uint32_t level0,
+                       const unsigned char *__restrict__ w, uint32_t total_levels, unsigned char *__restrict__ out, uint64_t out_stride) {
+    DYN_SHARED(unsigned char, red);
+    const uint32_t p = blockIdx.y;
+    const unsigned char *wp = w + ((size_t)p * total_levels + level0) * 32;
+    const unsigned char *src = in + ((size_t)p * in_stride + ((size_t)blockIdx.x << levels) + ((size_t)threadIdx.x << serial)) * 32;
+    Fe<FP> v[1u << TREE_MAX_SERIAL];
+    const uint32_t cnt0 = 1u << serial;
+    for (uint32_t q = 0; q < (1u << TREE_MAX_SERIAL); q++)
+        if (q < cnt0) v[q] = fe_load<FP>(src + (size_t)q * 32);
+    for (uint32_t j = 0, cnt = cnt0; j < serial; j++, cnt >>= 1) {
+        const Fe<FP> wj = fe_load<FP>(wp + (size_t)j * 32);
+        for (uint32_t q = 0; q < (1u << (TREE_MAX_SERIAL - 1)); q++)
+            if (q < (cnt >> 1)) v[q] = fe_add(v[2 * q], fe_mul(v[2 * q + 1], wj));
+    }
+    Fe<FP> acc = v[0];
+    fe_store(red + (size_t)threadIdx.x * 32, acc);
+    __syncthreads();
+    for (uint32_t j = serial, width = blockDim.x; j < levels; j++, width >>= 1) {
+        const bool active = threadIdx.x < (width >> 1);
+        if (active) acc = fe_add(fe_load<FP>(red + (size_t)(2 * threadIdx.x) * 32), fe_mul(fe_load<FP>(red + (size_t)(2 * threadIdx.x + 1) * 32), fe_load<FP>(wp + (size_t)j * 32)));
+        __syncthreads();
+        if (active) fe_store(red + (size_t)threadIdx.x * 32, acc);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) fe_store(out + ((size_t)p * out_stride + blockIdx.x) * 32, acc);
+}

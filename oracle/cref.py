@@ -187,3 +187,15 @@ def graph_eval(field, code, num_calculations, constants, rotations, columns, cha
     if rc != 0:
         raise ValueError("oracle_graph_eval: malformed graph")
     return out
+
+
+def pow_tree(field, leaves, weights, point_stride=0):
+    """tree_reduce with node = left + right * weights[p][height] (src/nifs/protogalaxy/poly/mod.rs:131-166, 263-290).
+    leaves (n or points*n, 4), weights (points, levels, 4); returns (points, 4)."""
+    leaves = _u64(leaves).reshape(-1, 4)
+    weights = _u64(weights)
+    points, levels = weights.shape[0], weights.shape[1]
+    n = 1 << levels
+    out = np.zeros((points, 4), dtype=np.uint64)
+    lib().oracle_pow_tree(field, _p(leaves), ctypes.c_size_t(n), ctypes.c_size_t(point_stride), _p(weights), ctypes.c_uint32(levels), ctypes.c_uint32(points), _p(out))
+    return out

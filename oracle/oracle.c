@@ -501,6 +501,27 @@ int oracle_graph_eval(int f, const uint32_t *code, size_t code_words, uint32_t n
     return bad ? -1 : 0;
 }
 
+/* ------------------------------------------------------------------ ProtoGalaxy tree reduction
+ * The tree_reduce of compute_F / compute_G (src/nifs/protogalaxy/poly/mod.rs:131-166, 263-290):
+ * adjacent nodes of height h merge as left + right * weights[p][h]; n = 2^levels leaves.
+ * leaves: point p's leaves at element p * point_stride (0 = shared).  out: one element per point. */
+void oracle_pow_tree(int f, const u64 *leaves, size_t n, size_t point_stride, const u64 *weights, uint32_t levels, uint32_t points, u64 *out) {
+    const field_t *F = fld(f);
+#pragma omp parallel for
+    for (long p = 0; p < (long)points; p++) {
+        fe *cur = (fe *)malloc(n * sizeof(fe));
+        memcpy(cur, leaves + 4 * (size_t)p * point_stride, n * sizeof(fe));
+        size_t cnt = n;
+        for (uint32_t h = 0; h < levels; h++, cnt >>= 1)
+            for (size_t i = 0; i < cnt / 2; i++) {
+                fe t; f_mul(&t, &cur[2 * i + 1], (const fe *)(weights + 4 * ((size_t)p * levels + h)), F);
+                f_add(&cur[i], &cur[2 * i], &t, F);
+            }
+        memcpy(out + 4 * p, &cur[0], 32);
+        free(cur);
+    }
+}
+
 /* ------------------------------------------------------------------ NTT (src/fft.rs) */
 static fe fr_pow_u64(const fe *a, u64 e) {
     fe ee = {{e, 0, 0, 0}}, r; f_pow(&r, a, &ee, &FR); return r;

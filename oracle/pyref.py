@@ -17,6 +17,10 @@ What is restated, with the reference lines each function follows
                               halo2curves; its *result* is a unique group element, so it is
                               restated here as plain double-and-add.
 * concatenate_with_padding    src/util.rs:189-193
+* cross-term evaluation       src/polynomial/expression.rs:112-120 evaluated directly (eval_expression),
+                              src/plonk/eval.rs:152-206 (plonk_advice_location)
+* ProtoGalaxy polynomials     src/nifs/protogalaxy/poly/mod.rs:66-179, 218-303, 339-382,
+                              folded_trace.rs, src/polynomial/lagrange.rs (pg_*)
 
 Pinning (tests/test_oracle_pins.py):
 * NTT: the 8-point known-answer vector of src/fft.rs:240-257, and the ifft(fft(x)) == x
@@ -369,3 +373,119 @@ def synth_base(i, cv, seed=SEED_BASES):
 
 def synth_bases(n, cv, seed=SEED_BASES):
     return [synth_base(i, cv, seed) for i in range(n)]
+
+
+# ---------------------------------------------------------------- ProtoGalaxy polynomials
+# Restatement of reference src/nifs/protogalaxy/poly/mod.rs (compute_F :66-179, compute_G :218-303,
+# compute_K :339-382), src/polynomial/lagrange.rs and folded_trace.rs over bn256::Fr with Python
+# integers.  Gates are expression tuples (eval_expression above); a trace is
+# dict(challenges=[int], W=[[int]]) with ONE witness vector holding num_advice columns of 2^k rows
+# and no lookups, so that advice column j is W[0][j * rows : (j + 1) * rows]
+# (src/plonk/eval.rs:171-176).  structure = dict(k, gates, selectors, fixed, num_advice).
+def _pg_getter(structure, trace):
+    rows = 1 << structure["k"]
+    w = trace["W"][0]
+    return dict(selectors=structure["selectors"], fixed=structure["fixed"], challenges=trace["challenges"],
+                advice=[w[j * rows:(j + 1) * rows] for j in range(structure["num_advice"])])
+
+
+def pg_iter_evaluate_witness(structure, trace):
+    """[gate1(row0), ..., gate1(rowN), gate2(row0), ...]  (src/plonk/mod.rs:1158-1178)"""
+    rows, getter = 1 << structure["k"], _pg_getter(structure, trace)
+    return [eval_expression(g, getter, r, rows, R_MOD) for g in structure["gates"] for r in range(rows)]
+
+
+def pg_cyclic_subgroup(log_n):
+    w, out, v = get_omega_or_inv(log_n, False), [], 1          # lagrange.rs:22-26
+    for _ in range(1 << log_n):
+        out.append(v); v = v * w % R_MOD
+    return out
+
+
+def pg_vanish(log_n, point):
+    return (pow(point, 1 << log_n, R_MOD) - 1) % R_MOD         # lagrange.rs:81-83
+
+
+def pg_lagrange(X, log_n):
+    n, z, out = 1 << log_n, pg_vanish(log_n, X), []            # lagrange.rs:50-74
+    inv_n = pow(n, R_MOD - 2, R_MOD)
+    for value in pg_cyclic_subgroup(log_n):
+        d = (X - value) % R_MOD
+        out.append(1 if (z == 0 and d == 0) else value * inv_n * z * pow(d, R_MOD - 2, R_MOD) % R_MOD)
+    return out
+
+
+def _pg_tree_reduce(nodes, combine):
+    """itertools::tree_reduce on a power-of-two number of items: adjacent pairs, level by level
+    (any other count reaches `unreachable!` in the reference)"""
+    assert len(nodes) & (len(nodes) - 1) == 0 and nodes
+    height = 0
+    while len(nodes) > 1:
+        nodes = [combine(nodes[i], nodes[i + 1], height) for i in range(0, len(nodes), 2)]
+        height += 1
+    return nodes[0]
+
+
+def pg_compute_F(betas, delta, structure, trace):
+    leaves = pg_iter_evaluate_witness(structure, trace)
+    count = len(leaves)
+    if count == 0:
+        return []
+    levels = (count - 1).bit_length()
+    points_count = 1
+    while points_count < levels:
+        points_count *= 2
+    log_points = points_count.bit_length() - 1
+    betas = list(betas)[:levels]
+    powers = [[(b + X * delta) % R_MOD for b in betas] for X in pg_cyclic_subgroup(log_points)]   # :104-113
+    # a node holds one value per challenge; a leaf is the same value for all of them (:131-166)
+    root = _pg_tree_reduce([[v] * points_count for v in leaves],
+                           lambda l, r, h: [(a + b * powers[p][h]) % R_MOD for p, (a, b) in enumerate(zip(l, r))])
+    ifft(root, log_points)                                                                   # :169-172
+    return root
+
+
+def pg_fold_traces(points, accumulator, traces):
+    """FoldedTrace::new (folded_trace.rs:19-131, 133-179)"""
+    all_traces = [accumulator] + list(traces)
+    log_n = 0
+    while (1 << log_n) < len(traces) + 1:
+        log_n += 1
+    out = []
+    for X in points:
+        L = pg_lagrange(X, log_n)
+        W = [[sum(l * t["W"][c][i] for l, t in zip(L, all_traces)) % R_MOD for i in range(len(col))] for c, col in enumerate(accumulator["W"])]
+        ch = [sum(l * t["challenges"][i] for l, t in zip(L, all_traces)) % R_MOD for i in range(len(accumulator["challenges"]))]
+        out.append(dict(challenges=ch, W=W))
+    return out
+
+
+def pg_compute_G(structure, betas_stroke, accumulator, traces, max_degree):
+    rows, count = 1 << structure["k"], (1 << structure["k"]) * len(structure["gates"])
+    if count == 0:
+        return []
+    points_count = 1
+    while points_count < len(traces) * max_degree + 1:
+        points_count *= 2
+    log_points = points_count.bit_length() - 1
+    levels = (count - 1).bit_length()
+    bs = list(betas_stroke)[:levels]
+    folded = pg_fold_traces(pg_cyclic_subgroup(log_points), accumulator, traces)
+    per_point = [pg_iter_evaluate_witness(structure, ft) for ft in folded]
+    leaves = [[per_point[p][i] for p in range(points_count)] for i in range(count)]        # try_multi_product, :258-262
+    root = _pg_tree_reduce(leaves, lambda l, r, h: [(a + b * bs[h]) % R_MOD for a, b in zip(l, r)])   # :263-290
+    ifft(root, log_points)
+    return root
+
+
+def pg_compute_K(structure, f_alpha, betas_stroke, accumulator, traces, max_degree):
+    g = pg_compute_G(structure, betas_stroke, accumulator, traces, max_degree)
+    log_n = len(g).bit_length() - 1
+    g_evals = list(g)
+    coset_fft(g_evals)                                                                       # :358
+    k_evals = []
+    for w, g_y in zip(pg_cyclic_subgroup(log_n), g_evals):
+        pt = FR_ZETA * w % R_MOD
+        l_y = f_alpha * pg_lagrange(pt, log_n)[0] % R_MOD
+        k_evals.append((g_y - l_y) * pow(pg_vanish(log_n, pt), R_MOD - 2, R_MOD) % R_MOD)  # :360-376
+    return coset_ifft(k_evals)

@@ -76,7 +76,7 @@ template <class F> HD void xyzz29_add_affine(Xyzz29<F> &acc, const Aff29<F> &q) 
     Fe29<F> pp = f29_sqr(p);                                    // 144 <= 168
     Fe29<F> ppp = f29_mul(p, pp);                               // 24
     Fe29<F> qq = f29_mul(acc.x, pp);                            // 18
-    Fe29<F> x3 = f29_sub<7>(f29_sqr(r), f29_add(ppp, f29_dbl(qq)));        // 64 ; PPP + 2Q < 6 -> X3 < 9
+    Fe29<F> x3 = f29_sub_b_2c<7>(f29_sqr(r), ppp, qq);                     // 64 ; PPP + 2Q < 6 -> X3 < 9
     Fe29<F> y3 = f29_mul2_add(r, f29_sub<10>(qq, x3), f29_neg<6>(acc.y), ppp);      // R (Q - X3) - Y1 PPP in one reduction: 8 * 12 + 6 * 2 = 108 -> Y3 < 2
     acc.x = x3; acc.y = y3;
     acc.zz = f29_mul(acc.zz, pp);
@@ -101,7 +101,7 @@ template <class F> HD void xyzz29_add(Xyzz29<F> &acc, const Xyzz29<F> &q) {
     Fe29<F> pp = f29_sqr(p);
     Fe29<F> ppp = f29_mul(p, pp);
     Fe29<F> qq = f29_mul(u1, pp);
-    Fe29<F> x3 = f29_sub<7>(f29_sqr(r), f29_add(ppp, f29_dbl(qq)));        // < 9
+    Fe29<F> x3 = f29_sub_b_2c<7>(f29_sqr(r), ppp, qq);                     // < 9
     Fe29<F> y3 = f29_mul2_add(r, f29_sub<10>(qq, x3), f29_neg<2>(s1), ppp);        // 5 * 12 + 2 * 2 -> < 2
     acc.x = x3; acc.y = y3;
     acc.zz = f29_mul(f29_mul(acc.zz, q.zz), pp);

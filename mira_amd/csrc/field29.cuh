@@ -127,6 +127,18 @@ template <int K, class F> HD Fe29<F> f29_sub(const Fe29<F> &a, const Fe29<F> &b)
     F29_ASSERT(F29_GET(r) <= 40.0);
     return f29_carry(r);
 }
+// a - b - 2 c + K P in one pass (one carry instead of three).  Requires b + 2 c < K P; the bias
+// limbs (>= 2^31) still dominate b + 2 c limb by limb since carried limbs are < 2^29 + 8.
+template <int K, class F> HD Fe29<F> f29_sub_b_2c(const Fe29<F> &a, const Fe29<F> &b, const Fe29<F> &c) {
+    constexpr F29Bias<F, K> bias{};
+    Fe29<F> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + bias.l[i] - b.l[i] - 2u * c.l[i];
+    F29_ASSERT(F29_GET(b) + 2.0 * F29_GET(c) <= (double)K - 0.01);
+    F29_SET(r, F29_GET(a) + (double)K);
+    F29_ASSERT(F29_GET(r) <= 40.0);
+    return f29_carry(r);
+}
 template <int K, class F> HD Fe29<F> f29_neg(const Fe29<F> &b) { return f29_sub<K>(f29_zero<F>(), b); }
 // multiply by a small constant by repeated addition (3 x = 2 x + x)
 template <class F> HD Fe29<F> f29_triple(const Fe29<F> &a) { return f29_add(f29_dbl(a), a); }

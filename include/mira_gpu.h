@@ -90,10 +90,11 @@ int mira_msm_batch_device(uint64_t handle, const void *d_scalars, size_t n, size
 /* Point-chunk sharding across GPUs (one process per GPU): each rank runs mira_msm_partial on
  * its chunk, the ranks all-gather the MIRA_PARTIAL_U64 words, and every rank combines.
  * `first` = index of the chunk's first base inside the registered key.  Every rank must make the
- * same choices: the same window width -- mira_msm_set_window_bits, or 16 when none is set: a
- * partial's width never depends on the chunk length, which differs between ranks -- and either all
- * or none with mira_msm_precompute'd keys (a handle with tables always answers with table-mode
- * partials here, whatever its chunk length). */
+ * same choices: the same window width -- *window_bits on entry (4..16), or, if that is 0, the
+ * mira_msm_set_window_bits value, or 16: a partial's width never depends on the chunk length,
+ * which differs between ranks -- and either all or none with mira_msm_precompute'd keys (a handle
+ * with tables answers with table-mode partials here whatever its chunk length, unless a width is
+ * requested).  On return *window_bits / *num_windows describe the partial (0 / 64 for tables). */
 int mira_msm_partial_device(uint64_t handle, size_t first, const void *d_scalars, size_t n,
                             uint64_t out_partial[MIRA_PARTIAL_U64], int32_t *window_bits, int32_t *num_windows);
 int mira_msm_combine(int curve, const uint64_t *partials /* nparts * MIRA_PARTIAL_U64 */, size_t nparts,

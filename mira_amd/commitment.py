@@ -185,12 +185,13 @@ class CommitmentKey:
                                                         out.ctypes.data_as(ctypes.c_void_p)))
         return out
 
-    def commit_partial_device(self, first, d_scalars, n):
-        """Window sums of sum_i v[i] * ck[first + i]; combine with `combine_partials`."""
+    def commit_partial_device(self, first, d_scalars, n, window_bits=0):
+        """Window sums of sum_i v[i] * ck[first + i]; combine with `combine_partials`.  All partials
+        of one MSM must be cut with the same `window_bits` (0: the library's length-independent default)."""
         if first + n > self._len:
             raise TooLongInput(first + n, self._len)
         part = np.zeros(_lib.MIRA_PARTIAL_U64, dtype=np.uint64)
-        c, w = ctypes.c_int32(), ctypes.c_int32()
+        c, w = ctypes.c_int32(window_bits), ctypes.c_int32()
         self.lib.check(self.lib.c.mira_msm_partial_device(self.handle, first, ctypes.c_void_p(d_scalars), n,
                                                           part.ctypes.data_as(ctypes.c_void_p), ctypes.byref(c), ctypes.byref(w)))
         return part, c.value, w.value

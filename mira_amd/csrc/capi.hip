@@ -210,7 +210,7 @@ static void sum_partials(const uint64_t *partials, size_t nparts, uint32_t W, ui
 // kind of partial, so the choice between table and per-window mode then depends only on whether
 // the handle has tables (and on the forced width), never on this rank's chunk length.
 static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scalars, size_t n, uint64_t *out_partial,
-                              uint32_t *c_out, uint32_t *W_out, bool sharded = false) {
+                              uint32_t *c_out, uint32_t *W_out, bool sharded = false, int32_t requested_c = 0) {
     int rc = ensure_ctx();
     if (rc) return rc;
     auto it = g_bases.find(handle);
@@ -221,7 +221,7 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
         return MIRA_E_TOO_LONG;
     }
     const size_t table_min_n = getenv("MIRA_TABLE_MIN_N") ? (size_t)atoll(getenv("MIRA_TABLE_MIN_N")) : TABLE_MIN_N;   // tests lower it
-    const bool table_mode = bs.tables && (sharded || n >= table_min_n) && g.forced_c == 0;
+    const bool table_mode = bs.tables && (sharded || n >= table_min_n) && g.forced_c == 0 && requested_c == 0;
     // Data-dependent planning for single (unsharded) commits (ranks of a sharded MSM must agree on
     // the window width, so they keep the dense estimate).  The statistics are those of the previous
     // commit of the same length over this key -- successive fold steps commit witnesses of one
@@ -231,7 +231,7 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
     const bool use_hist = !table_mode && !sharded && g.forced_c == 0 && n >= hist_min_n && d_scalars;
     // a rank of a sharded MSM that was not given a width takes 16, whatever its chunk length: partials
     // of different widths cannot be combined, and chunk lengths differ between ranks
-    const int32_t width = (sharded && g.forced_c == 0) ? 16 : g.forced_c;
+    const int32_t width = requested_c ? requested_c : (sharded && g.forced_c == 0) ? 16 : g.forced_c;
     MsmPlan p = make_plan(n, width, 1, 0, (use_hist && bs.stat_n == n) ? bs.stat_hist : nullptr);
     if (n >= (1ull << 31) || (uint64_t)n * p.W >= (1ull << 32)) { set_error("n too large for 32-bit entry offsets"); return MIRA_E_UNSUPPORTED; }
     if (p.W > MIRA_MAX_WINDOWS) { set_error("window configuration exceeds MIRA_MAX_WINDOWS"); return MIRA_E_UNSUPPORTED; }
@@ -508,8 +508,9 @@ int mira_msm_partial_device(uint64_t handle, size_t first, const void *d_scalars
                             int32_t *window_bits, int32_t *num_windows) {
     std::lock_guard<std::mutex> lk(g_lock);
     if (!out_partial || !window_bits || !num_windows) { set_error("null output"); return MIRA_E_BAD_ARG; }
+    if (*window_bits != 0 && (*window_bits < 4 || *window_bits > 16)) { set_error("window_bits must be 0 or 4..16"); return MIRA_E_BAD_ARG; }
     uint32_t c, W;
-    int rc = msm_partial_locked(handle, first, d_scalars, n, out_partial, &c, &W, true);
+    int rc = msm_partial_locked(handle, first, d_scalars, n, out_partial, &c, &W, true, *window_bits);
     if (rc) return rc;
     *window_bits = (int32_t)c; *num_windows = (int32_t)W;
     return MIRA_OK;

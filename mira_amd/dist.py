@@ -78,14 +78,9 @@ class ShardedCommitmentKey:
         if n_global > self.total_len:
             raise TooLongInput(n_global, self.total_len)
         n_local = self.local_prefix(n_global)
-        tables = getattr(self.key, "precomputed", False)   # table partials have one layout whatever the length
-        if not tables:
-            self.lib.check(self.lib.c.mira_msm_set_window_bits(self._agreed_window_bits(n_global)))
-        try:
-            part, c, w = self.key.commit_partial_device(0, d_scalars_local, n_local)
-        finally:
-            if not tables:
-                self.lib.check(self.lib.c.mira_msm_set_window_bits(self.window_bits))
+        # table partials have one layout whatever the length; otherwise every rank names the same width
+        tables = getattr(self.key, "precomputed", False)
+        part, c, w = self.key.commit_partial_device(0, d_scalars_local, n_local, window_bits=0 if tables else self._agreed_window_bits(n_global))
         gathered = self._all_gather(np.ascontiguousarray(part[: w * 16]))
         parts = np.zeros((self.world, _lib.MIRA_PARTIAL_U64), dtype=np.uint64)
         parts[:, : w * 16] = gathered

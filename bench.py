@@ -172,10 +172,11 @@ def cpu_baseline_msm(lib, cm, key, d_scalars, n, window_bits):
     """The oracle's restatement of best_multiexp (kind "port") on a bounded sample of the same
     workload, all host cores; the same sample re-run on the GPU gives the parity flag."""
     from oracle import cref as C
-    sample = min(n, 1 << 20)
+    threads = C.num_threads()
+    # about 1 M pairs/s on 256 threads: the whole 2^22 workload there (~4 s), a quarter of it on a small host
+    sample = min(n, 1 << 22 if threads >= 64 else 1 << 20)
     bases = lib.download(key._owned_ptr, (sample, 8))
     sc = lib.download(d_scalars, (sample, 4))
-    threads = C.num_threads()
     t0 = time.perf_counter()
     want = C.msm_pippenger(cm.CURVE_BN256, sc, bases, threads)
     dt = time.perf_counter() - t0

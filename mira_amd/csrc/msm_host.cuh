@@ -192,7 +192,7 @@ static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars
     const size_t entries = (size_t)n * TABLE_W;
     const uint32_t lanes = 256u * 4u * 3u * 64u, Lmin = 16;
     const uint32_t T = (uint32_t)std::min<uint64_t>(lanes, ceil_div(entries, Lmin));
-    const uint32_t m = 16, nchunks = TABLE_B / m;
+    const uint32_t m = 8, nchunks = TABLE_B / m;
     if ((rc = g.digits.ensure(entries * 4))) return rc;
     if ((rc = g.counts.ensure(((size_t)TABLE_CB + 1) * 4))) return rc;
     if ((rc = g.coarse_offsets.ensure(((size_t)TABLE_CB + 1) * 4))) return rc;

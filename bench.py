@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--log-n", type=int, default=22, help="log2 of pairs per GPU")
+    ap.add_argument("--total-log-n", type=int, default=0, help="strong scaling (BASELINE configs[4]): one MSM of 2^N pairs cut into --gpus chunks; overrides --log-n")
     ap.add_argument("--window-bits", type=int, default=16)
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
@@ -72,6 +73,9 @@ def main():
 
     cid = cm.CURVE_BN256
     n = 1 << args.log_n
+    strong = args.total_log_n > 0
+    if strong:                                             # one fixed-size MSM, point chunks of 2^total / world
+        n = (1 << args.total_log_n) // world
     index0 = rank * n
     t0 = time.time()
     if dist is None:
@@ -81,7 +85,7 @@ def main():
         skey = ShardedCommitmentKey.synthetic(cid, n * world, window_bits=args.window_bits)        # rank r holds bases [r*n, (r+1)*n)
         key = skey.key
     d_scalars = cm.synth_scalars_device(cid, n, index0=index0)
-    log(f"[rank {rank}] inputs generated on GPU in {time.time() - t0:.1f}s (n = 2^{args.log_n} per GPU)")
+    log(f"[rank {rank}] inputs generated on GPU in {time.time() - t0:.1f}s (n = {n} per GPU)")
 
     def sync_all():
         lib.check(lib.c.mira_dev_sync())
@@ -124,15 +128,16 @@ def main():
     out = {
         "metric": "bn256_g1_msm_throughput", "value": round(value, 3), "unit": "M scalar-point pairs/s",
         "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u256 mod p (9 x 29-bit limbs in u32/u64, Montgomery)",
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u256 mod p (9 x 29-bit limbs in u32/u64, Montgomery)",
         "data": "synthetic",
-        "config": {"workload": f"BN256 G1 MSM 2^{args.log_n} pairs per GPU via CommitmentKey::commit, {args.window_bits}-bit signed windows",
+        "config": {"workload": (f"BN256 G1 MSM 2^{args.total_log_n} pairs point-sharded over {n_gpus} GPU(s)" if strong else f"BN256 G1 MSM 2^{args.log_n} pairs per GPU")
+                               + f" via CommitmentKey::commit, {args.window_bits}-bit signed windows",
                    "pairs_per_gpu": n, "total_pairs": total_pairs, "window_bits": args.window_bits,
                    "parallelism": f"point-chunk x{n_gpus}" if n_gpus > 1 else "single GPU",
                    "inputs": "uniform Fr scalars, bases k_i*G, resident in HBM"},
         "roofline": {"bound": "hbm", "kernel": "k_accumulate", "achieved": None if achieved is None else round(achieved, 2),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 5),
-                     "traffic": load_traffic(args.log_n), "algorithmic_bytes_per_launch": MSM_BYTES_PER_PAIR * n,
+                     "traffic": load_traffic((n.bit_length() - 1) if n & (n - 1) == 0 else -1), "algorithmic_bytes_per_launch": MSM_BYTES_PER_PAIR * n,
                      "avg_launch_ms": round(t_acc, 4),
                      "alu": None if t_acc <= 0 else {
                          "achieved_G_modmul_per_s": round(160 * n / (t_acc * 1e-3) / 1e9, 1), "microbench_peak_G_modmul_per_s": 171.0,

@@ -37,21 +37,69 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def host_cpu_info():
+    """What the host actually gives this process: logical CPUs, the affinity mask and the cgroup CPU
+    quota.  The CPU baseline runs on `effective` threads -- what rayon's default pool would use
+    (std::thread::available_parallelism honours both the mask and the quota)."""
+    logical = os.cpu_count() or 1
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else logical
+    quota = None
+    try:                                                   # cgroup v2
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, period = f.read().split()[:2]
+            if q != "max":
+                quota = int(q) / int(period)
+    except Exception:
+        try:                                               # cgroup v1
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = int(f.read())
+            if q > 0:
+                quota = q / period
+        except Exception:
+            pass
+    effective = max(1, min(affinity, int(quota + 0.999) if quota else affinity))
+    return {"logical_cpus": logical, "sched_affinity": affinity, "cgroup_cpu_quota": quota, "effective": effective}
+
+
+def launch_ranks(n_gpus, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks through torch.distributed.run
+    as a CHILD process (this process has not touched the GPU and never will) and pass its output
+    and exit code on."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    log(f"[bench] --gpus {n_gpus} without WORLD_SIZE: launching {' '.join(cmd)}")
+    return subprocess.call(cmd)
+
+
 def main():
-    # Libraries (RCCL prints its version banner) write to stdout; the contract is ONE JSON line
-    # there.  Keep the real stdout aside and point fd 1 at stderr for the duration of the run.
-    real_stdout = os.fdopen(os.dup(1), "w")
-    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--log-n", type=int, default=22, help="log2 of pairs per GPU")
-    ap.add_argument("--total-log-n", type=int, default=0, help="strong scaling (BASELINE configs[4]): one MSM of 2^N pairs cut into --gpus chunks; overrides --log-n")
+    ap.add_argument("--log-n", type=int, default=0, help="weak scaling: log2 of pairs per GPU (default 22 at --gpus 1)")
+    ap.add_argument("--total-log-n", type=int, default=0,
+                    help="strong scaling (BASELINE configs[4]): one MSM of 2^N pairs cut into --gpus point chunks (default 26 at --gpus > 1)")
     ap.add_argument("--window-bits", type=int, default=16)
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--emulate", action="store_true",
+                    help="REHEARSAL ONLY: gloo + the test-only host emulation of the kernels, to exercise the multi-rank launch on a box without GPUs; never a measurement")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    # Libraries (RCCL prints its version banner) write to stdout; the contract is ONE JSON line
+    # there.  Keep the real stdout aside and point fd 1 at stderr for the duration of the run.
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -60,44 +108,65 @@ def main():
     if world > 1 or os.environ.get("MIRA_BENCH_FORCE_DIST"):      # FORCE_DIST: exercise the RCCL path with one rank
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    n_gpus = max(world, 1)
-    world = n_gpus
+        if args.emulate:
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    ranks_seen = dist.get_world_size() if dist is not None else 1
+    if ranks_seen != args.gpus:
+        log(f"[bench] --gpus {args.gpus} but {ranks_seen} rank(s) are running")
+        sys.exit(3)
+    n_gpus = ranks_seen
 
     from mira_amd import _lib
     from mira_amd import commitment as cm
-    lib = _lib.load()
-    lib.check(lib.c.mira_init(local_rank))
+    if args.emulate:
+        import subprocess
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "mira_amd", "csrc"), "emu"])
+        lib = _lib.MiraLib(os.path.join(ROOT, "tests", "emu", "libmira_emu.so"))
+        _lib._lib = lib                                            # the host mirror's default library for this rehearsal
+    else:
+        lib = _lib.load()
+    lib.check(lib.c.mira_init(0 if args.emulate else local_rank))
     lib.check(lib.c.mira_msm_set_window_bits(args.window_bits))
 
     cid = cm.CURVE_BN256
-    n = 1 << args.log_n
-    strong = args.total_log_n > 0
-    if strong:                                             # one fixed-size MSM, point chunks of 2^total / world
-        n = (1 << args.total_log_n) // world
-    index0 = rank * n
+    # N = 1: BASELINE configs[1] (2^22).  N > 1: BASELINE configs[4], ONE 2^26 MSM cut into N point
+    # chunks (strong scaling) unless --log-n asks for the weak-scaling variant.
+    strong = args.total_log_n > 0 or (n_gpus > 1 and args.log_n == 0)
+    total_log_n = args.total_log_n or 26
+    log_n = args.log_n or 22
+    if strong:
+        total = 1 << total_log_n
+        from mira_amd.dist import chunk_bounds
+        lo, hi = chunk_bounds(total, n_gpus, rank)
+        n, index0 = hi - lo, lo
+    else:
+        n = 1 << log_n
+        total, index0 = n * n_gpus, rank * n
     t0 = time.time()
     if dist is None:
         key = cm.CommitmentKey.synthetic(cid, n)
     else:
         from mira_amd.dist import ShardedCommitmentKey
-        skey = ShardedCommitmentKey.synthetic(cid, n * world, window_bits=args.window_bits)        # rank r holds bases [r*n, (r+1)*n)
+        skey = ShardedCommitmentKey.synthetic(cid, total, window_bits=args.window_bits)        # rank r holds bases [lo_r, hi_r)
         key = skey.key
     d_scalars = cm.synth_scalars_device(cid, n, index0=index0)
-    log(f"[rank {rank}] inputs generated on GPU in {time.time() - t0:.1f}s (n = {n} per GPU)")
+    log(f"[rank {rank}] inputs generated on GPU in {time.time() - t0:.1f}s (n = {n} on this GPU)")
 
     def sync_all():
         lib.check(lib.c.mira_dev_sync())
         if dist is not None:
-            import torch
-            torch.cuda.synchronize()
+            if not args.emulate:
+                import torch
+                torch.cuda.synchronize()
             dist.barrier()
 
     def step():
         if dist is None:
             return key.commit_device(d_scalars, n)
-        return skey.commit_device(d_scalars, n * world)           # partial MSM + RCCL all-gather + combine
+        return skey.commit_device(d_scalars, total)               # partial MSM + RCCL all-gather + combine
 
     for _ in range(args.warmup):
         result = step()
@@ -114,40 +183,44 @@ def main():
     lib.check(lib.c.mira_set_timing(0))
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.emulate else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     ms_per_step = elapsed / args.steps * 1e3
-    total_pairs = n * n_gpus
-    value = total_pairs / (elapsed / args.steps) / 1e6
+    value = total / (elapsed / args.steps) / 1e6
     stages = {k: v / args.steps for k, v in stage_acc.items()}
     t_acc = stages.get("accumulate", 0.0)
     achieved = (MSM_BYTES_PER_PAIR * n / (t_acc * 1e-3) / 1e9) if t_acc > 0 else None
+    adds_per_pair = (256 + args.window_bits - 1) // args.window_bits
 
     out = {
         "metric": "bn256_g1_msm_throughput", "value": round(value, 3), "unit": "M scalar-point pairs/s",
-        "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "n_gpus": n_gpus, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u256 mod p (9 x 29-bit limbs in u32/u64, Montgomery)",
-        "data": "synthetic",
-        "config": {"workload": (f"BN256 G1 MSM 2^{args.total_log_n} pairs point-sharded over {n_gpus} GPU(s)" if strong else f"BN256 G1 MSM 2^{args.log_n} pairs per GPU")
+        "data": "synthetic" if not args.emulate else "synthetic -- CPU EMULATION REHEARSAL of the launch path, not a measurement",
+        "config": {"workload": (f"BN256 G1 MSM 2^{total_log_n} pairs point-sharded over {n_gpus} GPU(s)" if strong else f"BN256 G1 MSM 2^{log_n} pairs per GPU")
                                + f" via CommitmentKey::commit, {args.window_bits}-bit signed windows",
-                   "pairs_per_gpu": n, "total_pairs": total_pairs, "window_bits": args.window_bits,
+                   "pairs_per_gpu": n, "total_pairs": total, "window_bits": args.window_bits,
                    "parallelism": f"point-chunk x{n_gpus}" if n_gpus > 1 else "single GPU",
                    "inputs": "uniform Fr scalars, bases k_i*G, resident in HBM"},
         "roofline": {"bound": "hbm", "kernel": "k_accumulate", "achieved": None if achieved is None else round(achieved, 2),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 5),
-                     "traffic": load_traffic((n.bit_length() - 1) if n & (n - 1) == 0 else -1), "algorithmic_bytes_per_launch": MSM_BYTES_PER_PAIR * n,
+                     "traffic": load_traffic((n.bit_length() - 1) if n & (n - 1) == 0 else -1),
+                     "traffic_source": "profiles/pmc_traffic.json: a separate rocprofv3 --pmc pass of this command on the builder's box, not this run",
+                     "algorithmic_bytes_per_launch": MSM_BYTES_PER_PAIR * n,
                      "avg_launch_ms": round(t_acc, 4),
                      "alu": None if t_acc <= 0 else {
-                         "achieved_G_modmul_per_s": round(160 * n / (t_acc * 1e-3) / 1e9, 1), "microbench_peak_G_modmul_per_s": 171.0,
-                         "frac": round(160 * n / (t_acc * 1e-3) / 1e9 / 171.0, 3),
-                         "note": "16 mixed XYZZ additions x 10 field multiplications per pair; peak = f29_mul microbenchmark "
-                                 "(profiles/r01_b_microbench_f29.txt); PMC: ~82 % of the VALU issue bound at the 2.05 GHz held under load"},
+                         "achieved_G_modmul_per_s": round(10 * adds_per_pair * n / (t_acc * 1e-3) / 1e9, 1), "microbench_peak_G_modmul_per_s": 171.0,
+                         "frac": round(10 * adds_per_pair * n / (t_acc * 1e-3) / 1e9 / 171.0, 3),
+                         "note": f"{adds_per_pair} mixed XYZZ additions x 10 field multiplications per pair; peak = f29_mul microbenchmark "
+                                 "(profiles/r01_b_microbench_f29.txt)"},
                      "note": "integer-ALU bound (about 160 modular multiplications per pair); see DESIGN.md section 4"},
         "stages_ms": {k: round(v, 4) for k, v in stages.items()},
     }
 
+    if strong and n_gpus > 1 and dist is not None and not args.emulate:
+        out["extras"] = multi_gpu_extras(lib, cm, dist, rank, n_gpus, total_log_n, args)
     if rank == 0 and n_gpus == 1 and not args.no_cpu:
         out["cpu_baseline"], parity = cpu_baseline_msm(lib, cm, key, d_scalars, n, args.window_bits)
         out["parity"] = parity
@@ -160,6 +233,58 @@ def main():
     if rank == 0:
         real_stdout.write(json.dumps(out) + "\n")
         real_stdout.flush()
+
+
+def multi_gpu_extras(lib, cm, dist, rank, n_gpus, total_log_n, args):
+    """Beside the strong-scaling headline of an N-GPU run: (a) the weak-scaling variant (2^22 pairs
+    per GPU, all ranks), (b) on rank 0 alone the SAME 2^total MSM on one GPU -- the N = 1 point of the
+    strong-scaling curve, measured in the same job."""
+    import torch
+    from mira_amd.dist import ShardedCommitmentKey
+    ex = {}
+    cid = cm.CURVE_BN256
+
+    def barrier():
+        lib.check(lib.c.mira_dev_sync()); torch.cuda.synchronize(); dist.barrier()
+
+    def timed(fn, reps):
+        fn(); barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()) / reps
+    try:
+        n = 1 << 22
+        wkey = ShardedCommitmentKey.synthetic(cid, n * n_gpus, seed=0x5745414B, window_bits=args.window_bits)
+        d = cm.synth_scalars_device(cid, n, index0=rank * n, seed=0x5745414C)
+        dt = timed(lambda: wkey.commit_device(d, n * n_gpus), 10)
+        ex["weak_2p22_per_gpu"] = {"ms_per_step": round(dt * 1e3, 4), "M_pairs_per_s": round(n * n_gpus / dt / 1e6, 2), "scaling": "weak"}
+        wkey.key.close(); lib.free(d)
+    except Exception as e:
+        ex["weak_2p22_per_gpu"] = {"error": repr(e)}
+    try:
+        res = None
+        if rank == 0:
+            n = 1 << total_log_n
+            key1 = cm.CommitmentKey.synthetic(cid, n)
+            d1 = cm.synth_scalars_device(cid, n)
+            key1.commit_device(d1, n)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                p1 = key1.commit_device(d1, n)
+            dt = (time.perf_counter() - t0) / 3
+            res = {"n_gpus": 1, "ms_per_step": round(dt * 1e3, 3), "M_pairs_per_s": round(n / dt / 1e6, 2),
+                   "note": f"the same 2^{total_log_n} MSM on rank 0's GPU alone, same job"}
+            key1.close(); lib.free(d1)
+        dist.barrier()
+        ex["strong_scaling_reference_1gpu"] = res
+    except Exception as e:
+        ex["strong_scaling_reference_1gpu"] = {"error": repr(e)}
+        dist.barrier()
+    return ex
 
 
 def load_traffic(log_n):
@@ -177,17 +302,24 @@ def cpu_baseline_msm(lib, cm, key, d_scalars, n, window_bits):
     """The oracle's restatement of best_multiexp (kind "port") on a bounded sample of the same
     workload, all host cores; the same sample re-run on the GPU gives the parity flag."""
     from oracle import cref as C
-    threads = C.num_threads()
-    # about 1 M pairs/s on 256 threads: the whole 2^22 workload there (~4 s), a quarter of it on a small host
-    sample = min(n, 1 << 22 if threads >= 64 else 1 << 20)
-    bases = lib.download(key._owned_ptr, (sample, 8))
+    cpu = host_cpu_info()
+    threads = cpu["effective"]                             # rayon's default: available_parallelism (mask and cgroup quota)
+    C.set_threads(threads)                                 # ... for every later CPU leg of this run as well
+    sample = min(n, 1 << 22 if threads >= 12 else 1 << 20)  # ~1.5 M bucket additions per second per core
+    bases = key.download(0, sample)
     sc = lib.download(d_scalars, (sample, 4))
     t0 = time.perf_counter()
     want = C.msm_pippenger(cm.CURVE_BN256, sc, bases, threads)
     dt = time.perf_counter() - t0
     got = key.commit_device(d_scalars, sample)
+    one = min(sample, 1 << 17)                             # the same algorithm on ONE thread (c = ceil(ln n) = 12 there)
+    t0 = time.perf_counter()
+    C.msm_pippenger(cm.CURVE_BN256, sc[:one], bases[:one], 1)
+    dt1 = time.perf_counter() - t0
     base = {"value": round(sample / dt / 1e6, 4), "unit": "M scalar-point pairs/s", "cores": threads, "kind": "port",
-            "sample": f"first 2^{sample.bit_length() - 1} of the 2^{n.bit_length() - 1} pairs, {dt:.2f} s, C restatement of halo2 best_multiexp"}
+            "sample": f"first 2^{sample.bit_length() - 1} of the 2^{n.bit_length() - 1} pairs, {dt:.2f} s, C restatement of halo2 best_multiexp "
+                      f"(chunk per thread, c = ceil(ln chunk) windows)",
+            "host": cpu, "one_thread": {"value": round(one / dt1 / 1e6, 4), "sample": f"first 2^{one.bit_length() - 1} pairs, {dt1:.2f} s"}}
     return base, {"sample_pairs": sample, "bit_exact_vs_oracle": bool((got == want).all())}
 
 
@@ -332,7 +464,7 @@ def extras(lib, cm, with_cpu):
             from oracle import cref as C
             cpu_in = []
             for c, (nw, cnt) in plan.items():
-                bases = lib.download(keys[c]._owned_ptr, (nw, 8))
+                bases = keys[c].download()
                 cpu_in.append((c, bases, lib.download(wit[c], (nw, 4))))
                 for i in range(cnt):
                     cpu_in.append((c, bases[:n], lib.download(cross[c] + i * n * 32, (n, 4))))

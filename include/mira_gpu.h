@@ -103,6 +103,17 @@ int mira_msm_combine(int curve, const uint64_t *partials /* nparts * MIRA_PARTIA
  * sharded MSM must use the same c. */
 int mira_msm_set_window_bits(int32_t c);
 
+/* Thresholds of the engine's internal choices, for tests and tuning runs (they never change a
+ * result): the smallest MSM that takes the LDS-staged two-level sort, the smallest MSM that uses a
+ * handle's window tables, the smallest commit whose scalar-length statistics plan the next one, and
+ * the longest NTT line (log2) -- shorter lines make the two- and three-pass schedules reachable at
+ * small sizes.  value < 0 restores the default. */
+#define MIRA_TUNE_STAGED_MIN_N 0
+#define MIRA_TUNE_TABLE_MIN_N 1
+#define MIRA_TUNE_PLAN_HIST_MIN_N 2
+#define MIRA_TUNE_NTT_MAX_LOG_LINE 3
+int mira_set_tuning(int knob, int64_t value);
+
 /* Read a range of the registered key back in the reference layout (cache file writing,
  * save_to_file, src/commitment.rs:96-101). */
 int mira_msm_download_bases(uint64_t handle, size_t first, size_t n, uint64_t *bases_out /* n * 8 limbs */);

@@ -26,8 +26,9 @@ SYMBOLS = [
     "mira_fft_bn256_fr_device", "mira_ifft_bn256_fr_device", "mira_coset_fft_bn256_fr", "mira_coset_ifft_bn256_fr",
     "mira_get_omega_or_inv", "mira_synth_scalars_device", "mira_synth_bases_device",
     "mira_dev_alloc", "mira_dev_free", "mira_dev_upload", "mira_dev_download", "mira_dev_sync",
-    "mira_set_timing", "mira_get_timings",
+    "mira_set_timing", "mira_get_timings", "mira_set_tuning",
 ]
+TUNE_STAGED_MIN_N, TUNE_TABLE_MIN_N, TUNE_PLAN_HIST_MIN_N, TUNE_NTT_MAX_LOG_LINE = 0, 1, 2, 3
 
 
 def _preload_hip_runtime():
@@ -104,6 +105,7 @@ class MiraLib:
             "mira_synth_bases_device": [ctypes.c_int, sz, u64, u64, vp],
             "mira_dev_alloc": [sz, vp], "mira_dev_free": [vp], "mira_dev_upload": [vp, vp, sz], "mira_dev_download": [vp, vp, sz],
             "mira_dev_sync": [], "mira_set_timing": [ctypes.c_int], "mira_get_timings": [vp, vp, ctypes.c_int],
+            "mira_set_tuning": [ctypes.c_int, ctypes.c_int64],
         }
         for name, args in sig.items():
             fn = getattr(c, name)
@@ -132,6 +134,10 @@ class MiraLib:
         out = np.empty(shape, dtype=dtype)
         self.check(self.c.mira_dev_download(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), out.nbytes))
         return out
+
+    def tune(self, knob, value):
+        """mira_set_tuning; value < 0 restores the default."""
+        self.check(self.c.mira_set_tuning(knob, value))
 
     def timings(self):
         names = (ctypes.c_char_p * 32)()

@@ -53,10 +53,11 @@ class CommitmentKey:
         the absent halo2curves crate."""
         lib = lib or _lib.load()
         ptr = lib.alloc(max(n, 1) * 64)
-        lib.check(lib.c.mira_synth_bases_device(curve, n, index0, seed, ctypes.c_void_p(ptr)))
-        key = cls(curve, device_ptr=ptr, length=n, lib=lib)
-        key._owned_ptr = ptr
-        return key
+        try:
+            lib.check(lib.c.mira_synth_bases_device(curve, n, index0, seed, ctypes.c_void_p(ptr)))
+            return cls(curve, device_ptr=ptr, length=n, lib=lib)
+        finally:
+            lib.free(ptr)                               # register keeps its own resident copy: one copy of the key in HBM
 
     def __len__(self):
         return self._len
@@ -73,11 +74,8 @@ class CommitmentKey:
         return np.zeros(8, dtype=np.uint64)
 
     def bases(self):
-        """Download the key (tests)."""
-        ptr = getattr(self, "_owned_ptr", None)
-        if ptr is None:
-            raise ValueError("bases were registered from host memory; keep your own copy")
-        return self.lib.download(ptr, (self._len, 8))
+        """The whole key back in the reference layout (tests)."""
+        return self.download()
 
     # ---- commitment-key cache (src/commitment.rs:96-167): raw dump of [C], 2^k x 64 bytes ----
     def download(self, first=0, n=None):
@@ -200,10 +198,6 @@ class CommitmentKey:
         if getattr(self, "handle", None):
             self.lib.c.mira_msm_unregister(self.handle)
             self.handle = 0
-        ptr = getattr(self, "_owned_ptr", None)
-        if ptr:
-            self.lib.free(ptr)
-            self._owned_ptr = None
 
     def __del__(self):
         try:

@@ -220,14 +220,14 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
         set_error("Can't commit too long input: input len: " + std::to_string(first + n) + ", but limit is " + std::to_string(bs.n));
         return MIRA_E_TOO_LONG;
     }
-    const size_t table_min_n = getenv("MIRA_TABLE_MIN_N") ? (size_t)atoll(getenv("MIRA_TABLE_MIN_N")) : TABLE_MIN_N;   // tests lower it
+    const size_t table_min_n = tuned(MIRA_TUNE_TABLE_MIN_N, TABLE_MIN_N);
     const bool table_mode = bs.tables && (sharded || n >= table_min_n) && g.forced_c == 0 && requested_c == 0;
     // Data-dependent planning for single (unsharded) commits (ranks of a sharded MSM must agree on
     // the window width, so they keep the dense estimate).  The statistics are those of the previous
     // commit of the same length over this key -- successive fold steps commit witnesses of one
     // shape -- so no call waits for a pre-pass: this call's histogram is enqueued ahead of its MSM
     // kernels and read after the synchronisation that ends it.
-    const size_t hist_min_n = getenv("MIRA_PLAN_HIST_MIN_N") ? (size_t)atoll(getenv("MIRA_PLAN_HIST_MIN_N")) : PLAN_HIST_MIN_N;   // tests lower it
+    const size_t hist_min_n = tuned(MIRA_TUNE_PLAN_HIST_MIN_N, PLAN_HIST_MIN_N);
     const bool use_hist = !table_mode && !sharded && g.forced_c == 0 && n >= hist_min_n && d_scalars;
     // a rank of a sharded MSM that was not given a width takes 16, whatever its chunk length: partials
     // of different widths cannot be combined, and chunk lengths differ between ranks
@@ -517,6 +517,12 @@ int mira_msm_partial_device(uint64_t handle, size_t first, const void *d_scalars
 }
 int mira_msm_combine(int curve, const uint64_t *partials, size_t nparts, int32_t window_bits, int32_t num_windows, uint64_t out_affine[8]) {
     return combine_locked(curve, partials, nparts, (uint32_t)window_bits, (uint32_t)num_windows, out_affine);
+}
+int mira_set_tuning(int knob, int64_t value) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    if (knob < 0 || knob > MIRA_TUNE_NTT_MAX_LOG_LINE) { set_error("unknown tuning knob"); return MIRA_E_BAD_ARG; }
+    g.tune[knob] = value;
+    return MIRA_OK;
 }
 int mira_msm_set_window_bits(int32_t c) {
     std::lock_guard<std::mutex> lk(g_lock);

@@ -78,6 +78,7 @@ struct Ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int32_t forced_c = 0;
+    int64_t tune[4] = {-1, -1, -1, -1};   // mira_set_tuning overrides, < 0 = default
     Timing tm;
     // MSM workspace (grow-only, shared by all handles: calls are serialised by the ABI lock)
     DevBuf digits, counts, offsets, cursor, block_sums, sorted_idx, bucket_sums, part, coarse_offsets, fine_counts, fine_cursor;
@@ -110,6 +111,7 @@ void tm_begin();
 void tm_mark(const char *name);
 void tm_end();
 
+static inline size_t tuned(int knob, size_t dflt) { return g.tune[knob] < 0 ? dflt : (size_t)g.tune[knob]; }
 static inline uint32_t ceil_div(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
 // window width c, W windows, B = 2^(c-1) buckets per window, histogram tiling; accumulate:

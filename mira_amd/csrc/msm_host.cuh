@@ -25,7 +25,7 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size
     if (scan_blocks > 1024) { set_error("window configuration exceeds the scan capacity"); return MIRA_E_UNSUPPORTED; }
     if ((rc = g.block_sums.ensure(1024 * 4))) return rc;
     if ((rc = g.sorted_idx.ensure(entries * 4 + 8))) return rc;
-    const size_t staged_min_n = getenv("MIRA_STAGED_MIN_N") ? (size_t)atoll(getenv("MIRA_STAGED_MIN_N")) : (size_t)1 << 19;   // tests lower it
+    const size_t staged_min_n = tuned(MIRA_TUNE_STAGED_MIN_N, (size_t)1 << 19);
     const bool staged = n >= staged_min_n && p.c >= 9;
     if (staged) {
         if ((rc = g.part.ensure(entries * 8 + 8))) return rc;
@@ -75,10 +75,10 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size
         const uint32_t CB = p.B >> fine_bits;                                       // <= 256 coarse bins per window
         LAUNCH(k_stage_cursors, ceil_div((uint64_t)p.Wt * CB, 256), 256, 0, st, reinterpret_cast<const uint32_t *>(g.offsets.p), p.Wt * CB, fine_bits,
                reinterpret_cast<uint32_t *>(g.coarse_offsets.p));
-        LAUNCH_BARRIER_FLEX((k_stage1<int16_t, false>), dim3(ceil_div(n, STAGE_TILE), p.Wt), 1024, (size_t)STAGE_TILE * 8, st, reinterpret_cast<const int16_t *>(g.digits.p),
+        LAUNCH_BARRIER((k_stage1<int16_t, false>), dim3(ceil_div(n, STAGE_TILE), p.Wt), 1024, (size_t)STAGE_TILE * 8, st, reinterpret_cast<const int16_t *>(g.digits.p),
                             (uint32_t)n, p.B, fine_bits, CB, 0u, 0u, reinterpret_cast<uint32_t *>(g.coarse_offsets.p), reinterpret_cast<U2 *>(g.part.p));
         tm_mark("sort_level1");
-        LAUNCH_BARRIER_FLEX(k_stage2, ceil_div(entries, STAGE_TILE), 1024, (size_t)STAGE_TILE * 6, st, reinterpret_cast<const U2 *>(g.part.p),
+        LAUNCH_BARRIER(k_stage2, ceil_div(entries, STAGE_TILE), 1024, (size_t)STAGE_TILE * 6, st, reinterpret_cast<const U2 *>(g.part.p),
                             reinterpret_cast<const uint32_t *>(g.offsets.p) + p.NB, fine_bits, reinterpret_cast<uint32_t *>(g.cursor.p),
                             reinterpret_cast<uint32_t *>(g.sorted_idx.p));
     } else
@@ -241,7 +241,7 @@ static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars
     tm_mark("scan");
     // level 1 by coarse bin (top 9 bits), bucket counts from its output, scan, level 2 by bucket
     const uint32_t *coarse_total = reinterpret_cast<const uint32_t *>(g.coarse_offsets.p) + TABLE_CB;
-    LAUNCH_BARRIER_FLEX((k_stage1<int32_t, true>), dim3(ceil_div(n, STAGE_TILE), TABLE_W), 1024, (size_t)STAGE_TILE * 8, st,
+    LAUNCH_BARRIER((k_stage1<int32_t, true>), dim3(ceil_div(n, STAGE_TILE), TABLE_W), 1024, (size_t)STAGE_TILE * 8, st,
                         reinterpret_cast<const int32_t *>(g.digits.p), (uint32_t)n, TABLE_B, TABLE_FINE_BITS, TABLE_CB, (uint32_t)bs.n, (uint32_t)first,
                         reinterpret_cast<uint32_t *>(g.cursor.p), reinterpret_cast<U2 *>(g.part.p));
     tm_mark("sort_level1");
@@ -254,7 +254,7 @@ static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars
     LAUNCH_BARRIER(k_scan_c, fscan, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.fine_counts.p), TABLE_B,
                    reinterpret_cast<const uint32_t *>(g.block_sums.p), reinterpret_cast<uint32_t *>(g.offsets.p), reinterpret_cast<uint32_t *>(g.fine_cursor.p));
     tm_mark("bucket_count_scan");
-    LAUNCH_BARRIER_FLEX(k_stage2, ceil_div(entries, STAGE_TILE), 1024, (size_t)STAGE_TILE * 6, st, reinterpret_cast<const U2 *>(g.part.p), coarse_total,
+    LAUNCH_BARRIER(k_stage2, ceil_div(entries, STAGE_TILE), 1024, (size_t)STAGE_TILE * 6, st, reinterpret_cast<const U2 *>(g.part.p), coarse_total,
                         TABLE_FINE_BITS, reinterpret_cast<uint32_t *>(g.fine_cursor.p), reinterpret_cast<uint32_t *>(g.sorted_idx.p));
     tm_mark("sort_level2");
     const uint32_t *total_ptr = reinterpret_cast<const uint32_t *>(g.offsets.p) + TABLE_B;

@@ -33,11 +33,10 @@ struct NttTables {
     uint32_t passes, m[3], h[2];
     size_t off_tw[3], off_lo[2], off_hi[2];
 };
-// test-only knob: a smaller maximum line makes the two- and three-pass schedules reachable at sizes
-// the CPU emulation can run
+// MIRA_TUNE_NTT_MAX_LOG_LINE: a smaller maximum line makes the two- and three-pass schedules
+// reachable at sizes the CPU emulation can run
 static uint32_t ntt_max_log_line() {
-    const char *e = getenv("MIRA_NTT_MAX_LOG_LINE");
-    const int v = e ? atoi(e) : NTT_MAX_LOG_LINE;
+    const int v = (int)tuned(MIRA_TUNE_NTT_MAX_LOG_LINE, NTT_MAX_LOG_LINE);
     return (uint32_t)std::min(std::max(v, 1), NTT_MAX_LOG_LINE);
 }
 static int ntt_prepare_tables(uint32_t log_n, const uint64_t omega[4], NttTables &t) {

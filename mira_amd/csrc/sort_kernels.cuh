@@ -63,8 +63,7 @@ KERNEL void __launch_bounds__(1024) k_stage1(const DIGIT *__restrict__ digits, u
     const uint32_t key_base = TABLE ? 0u : w * B, cur_base = TABLE ? 0u : w * CB, idx_base = TABLE ? w * N + first : 0u;
     for (uint32_t b = threadIdx.x; b < CB; b += blockDim.x) cnt[b] = 0;
     __syncthreads();
-    constexpr int PER = STAGE_TILE / 1024;               // 16 points per lane at blockDim 1024
-#ifndef MIRA_CPU_EMU
+    constexpr int PER = STAGE_TILE / 1024;               // 16 points per lane: blockDim.x must be 1024 (the test emulation runs these kernels with all 1024 lanes too)
     DIGIT dreg[PER];                                     // the tile's digits stay in registers between the two passes
 #pragma unroll
     for (int k = 0; k < PER; k++) {
@@ -76,12 +75,6 @@ KERNEL void __launch_bounds__(1024) k_stage1(const DIGIT *__restrict__ digits, u
         int32_t d = dreg[k];
         if (d != 0) atomicAdd(&cnt[((uint32_t)(d < 0 ? -d : d) - 1) >> fine_bits], 1u);
     }
-#else
-    for (uint32_t i = base + threadIdx.x; i < end; i += blockDim.x) {
-        int32_t d = dw[i];
-        if (d != 0) atomicAdd(&cnt[((uint32_t)(d < 0 ? -d : d) - 1) >> fine_bits], 1u);
-    }
-#endif
     __syncthreads();
     block_excl_scan(cnt, lofs, tmp, CB, &total_s);
     for (uint32_t b = threadIdx.x; b < CB; b += blockDim.x) {
@@ -90,7 +83,6 @@ KERNEL void __launch_bounds__(1024) k_stage1(const DIGIT *__restrict__ digits, u
         cnt[b] = lofs[b];                                // cnt[] becomes the running LDS cursor
     }
     __syncthreads();
-#ifndef MIRA_CPU_EMU
 #pragma unroll
     for (int k = 0; k < PER; k++) {
         int32_t d = dreg[k];
@@ -101,16 +93,6 @@ KERNEL void __launch_bounds__(1024) k_stage1(const DIGIT *__restrict__ digits, u
             stage[p] = U2{(idx_base + i) | (d < 0 ? 0x80000000u : 0u), key_base + b};
         }
     }
-#else
-    for (uint32_t i = base + threadIdx.x; i < end; i += blockDim.x) {
-        int32_t d = dw[i];
-        if (d != 0) {
-            uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1;
-            uint32_t p = atomicAdd(&cnt[b >> fine_bits], 1u);
-            stage[p] = U2{(idx_base + i) | (d < 0 ? 0x80000000u : 0u), key_base + b};
-        }
-    }
-#endif
     __syncthreads();
     const uint32_t total = total_s;
     for (uint32_t p = threadIdx.x; p < total; p += blockDim.x) {     // consecutive p: consecutive addresses within a bin's run
@@ -160,7 +142,6 @@ KERNEL void __launch_bounds__(1024) k_stage2(const U2 *__restrict__ part, const 
     const uint32_t key_lo = (part[base].y >> fine_bits) << fine_bits;
     for (uint32_t b = threadIdx.x; b < STAGE_MAX_KEYS2; b += blockDim.x) cnt[b] = 0;
     __syncthreads();
-#ifndef MIRA_CPU_EMU
     constexpr int PER = STAGE_TILE / 1024;
     U2 ereg[PER];                                        // the tile's entries stay in registers between the two passes
 #pragma unroll
@@ -173,12 +154,6 @@ KERNEL void __launch_bounds__(1024) k_stage2(const U2 *__restrict__ part, const 
         uint32_t k = ereg[j].y - key_lo;
         if (ereg[j].y != 0xFFFFFFFFu && k < STAGE_MAX_KEYS2) atomicAdd(&cnt[k], 1u);
     }
-#else
-    for (uint32_t p = base + threadIdx.x; p < end; p += blockDim.x) {
-        uint32_t k = part[p].y - key_lo;
-        if (k < STAGE_MAX_KEYS2) atomicAdd(&cnt[k], 1u);
-    }
-#endif
     __syncthreads();
     block_excl_scan(cnt, lofs, tmp, STAGE_MAX_KEYS2, &total_s);
     for (uint32_t b = threadIdx.x; b < STAGE_MAX_KEYS2; b += blockDim.x) {
@@ -187,7 +162,6 @@ KERNEL void __launch_bounds__(1024) k_stage2(const U2 *__restrict__ part, const 
         cnt[b] = lofs[b];
     }
     __syncthreads();
-#ifndef MIRA_CPU_EMU
 #pragma unroll
     for (int j = 0; j < PER; j++) {
         U2 e = ereg[j];
@@ -201,19 +175,6 @@ KERNEL void __launch_bounds__(1024) k_stage2(const U2 *__restrict__ part, const 
             sorted[atomicAdd(&cursor2[e.y], 1u)] = e.x;             // out-of-range key: direct placement
         }
     }
-#else
-    for (uint32_t p = base + threadIdx.x; p < end; p += blockDim.x) {
-        U2 e = part[p];
-        uint32_t k = e.y - key_lo;
-        if (k < STAGE_MAX_KEYS2) {
-            uint32_t q = atomicAdd(&cnt[k], 1u);
-            stage_x[q] = e.x;
-            stage_k[q] = (uint16_t)k;
-        } else {
-            sorted[atomicAdd(&cursor2[e.y], 1u)] = e.x;             // out-of-range key: direct placement
-        }
-    }
-#endif
     __syncthreads();
     const uint32_t staged = total_s;
     for (uint32_t q = threadIdx.x; q < staged; q += blockDim.x) {

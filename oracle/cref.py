@@ -48,6 +48,11 @@ def num_threads():
     return lib().oracle_num_threads()
 
 
+def set_threads(n):
+    """Default pool size of the `threads=0` entry points (the reference's rayon pool)."""
+    lib().oracle_set_num_threads(int(n))
+
+
 def to_mont(field, a):
     a = _u64(a).reshape(-1, 4); out = np.empty_like(a)
     lib().oracle_f_to_mont(field, _p(a), _p(out), ctypes.c_size_t(len(a)))

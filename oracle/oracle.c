@@ -695,3 +695,12 @@ int oracle_num_threads(void) {
     return 1;
 #endif
 }
+/* Size of the default thread pool of every `threads <= 0` entry point (rayon's global pool in the
+ * reference; RAYON_NUM_THREADS / available_parallelism there). */
+void oracle_set_num_threads(int threads) {
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#else
+    (void)threads;
+#endif
+}

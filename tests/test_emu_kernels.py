@@ -14,6 +14,20 @@ from oracle import cref as C
 from oracle import pyref as P
 
 
+
+@pytest.fixture
+def tune(emu_lib):
+    """mira_set_tuning for the duration of one test."""
+    used = []
+
+    def set_knob(knob, value):
+        used.append(knob)
+        emu_lib.tune(knob, value)
+    yield set_knob
+    for knob in used:
+        emu_lib.tune(knob, -1)
+
+
 def test_emu_synth_matches_oracle(emu_lib):
     for cid in (0, 1):
         p = cm.synth_scalars_device(cid, 70, seed=3, kind=1, lib=emu_lib)
@@ -101,19 +115,22 @@ def test_emu_ntt_four_step(emu_lib):
 
 
 @pytest.mark.parametrize("max_line,ks", [(3, (4, 5, 6, 7, 8, 9)), (4, (9, 11, 12)), (2, (5, 6))])
-def test_emu_ntt_pass_schedules(emu_lib, monkeypatch, max_line, ks):
+def test_emu_ntt_pass_schedules(emu_lib, max_line, ks):
     """Two- and three-pass schedules (the latter serves log_n 25..28 on the GPU) at emulation sizes:
-    the test-only MIRA_NTT_MAX_LOG_LINE shortens the lines so that every split is exercised."""
-    monkeypatch.setenv("MIRA_NTT_MAX_LOG_LINE", str(max_line))
-    for k in ks:
-        a = C.synth_scalars(0, 1 << k, seed=2000 + k)
-        assert (F.fft(a, k, lib=emu_lib) == C.fft(a, k)).all(), k
-        assert (F.ifft(a, k, lib=emu_lib) == C.ifft(a, k)).all(), k
-    w = C.get_omega_or_inv(ks[-1], True)
-    a = C.synth_scalars(0, 1 << ks[-1], seed=7)
-    assert (F.best_fft(a, w, ks[-1], lib=emu_lib) == C.best_fft(a, w, ks[-1])).all()
-    with pytest.raises(_lib.MiraError):
-        F.fft(C.synth_scalars(0, 1 << (3 * max_line + 1), seed=1), 3 * max_line + 1, lib=emu_lib)
+    MIRA_TUNE_NTT_MAX_LOG_LINE shortens the lines so that every split is exercised."""
+    emu_lib.tune(_lib.TUNE_NTT_MAX_LOG_LINE, max_line)
+    try:
+        for k in ks:
+            a = C.synth_scalars(0, 1 << k, seed=2000 + k)
+            assert (F.fft(a, k, lib=emu_lib) == C.fft(a, k)).all(), k
+            assert (F.ifft(a, k, lib=emu_lib) == C.ifft(a, k)).all(), k
+        w = C.get_omega_or_inv(ks[-1], True)
+        a = C.synth_scalars(0, 1 << ks[-1], seed=7)
+        assert (F.best_fft(a, w, ks[-1], lib=emu_lib) == C.best_fft(a, w, ks[-1])).all()
+        with pytest.raises(_lib.MiraError):
+            F.fft(C.synth_scalars(0, 1 << (3 * max_line + 1), seed=1), 3 * max_line + 1, lib=emu_lib)
+    finally:
+        emu_lib.tune(_lib.TUNE_NTT_MAX_LOG_LINE, -1)
 
 
 def test_emu_omega(emu_lib):
@@ -138,12 +155,12 @@ def test_emu_commit_batch(emu_lib):
             key.commit_batch([C.synth_scalars(cid, n + 21)])
 
 
-def test_emu_fixed_base_tables(emu_lib, monkeypatch):
+def test_emu_fixed_base_tables(emu_lib, tune):
     """mira_msm_precompute: window tables 2^(20 w) P_i, one shared set of 2^19 buckets, staged
     sort.  Same points as the per-window path and the oracle, with an identity base, a heavy
     bucket and chunk partials.  (One curve only: 2^19 emulated buckets are slow; the GPU suite
     covers both.)"""
-    monkeypatch.setenv("MIRA_TABLE_MIN_N", "1")
+    tune(_lib.TUNE_TABLE_MIN_N, 1)
     cid, n = 1, 200
     bs = C.synth_bases(cid, n, seed=40)
     bs[7] = 0
@@ -160,10 +177,10 @@ def test_emu_fixed_base_tables(emu_lib, monkeypatch):
     assert (cm.combine_partials(cid, np.stack([pa, pb]), ca, wa, lib=emu_lib) == before).all()
 
 
-def test_emu_data_dependent_planning(emu_lib, monkeypatch):
+def test_emu_data_dependent_planning(emu_lib, tune):
     """The bit-length statistics of one commit plan the next one of the same length over the key:
     they change only the window width, never the result."""
-    monkeypatch.setenv("MIRA_PLAN_HIST_MIN_N", "1")
+    tune(_lib.TUNE_PLAN_HIST_MIN_N, 1)
     cid, n = 0, 300
     bs = C.synth_bases(cid, n, seed=50)
     key = cm.CommitmentKey(cid, bs, lib=emu_lib)
@@ -176,9 +193,9 @@ def test_emu_data_dependent_planning(emu_lib, monkeypatch):
     assert (key.commit(sc) == want).all()
 
 
-def test_emu_staged_sort(emu_lib, monkeypatch):
+def test_emu_staged_sort(emu_lib, tune):
     """LDS-staged two-level sort (sort_kernels.cuh), forced on at a small size: same commitments."""
-    monkeypatch.setenv("MIRA_STAGED_MIN_N", "1")
+    tune(_lib.TUNE_STAGED_MIN_N, 1)
     for cid, c in ((1, 11),):
         n = 500
         bs = C.synth_bases(cid, n, seed=60)

@@ -238,3 +238,9 @@ def test_staged_sort_under_skew(gpu_lib, cid):
     key.precompute()
     for v, w in zip(cases, want):
         assert (key.commit(v) == w).all()
+
+
+def test_abi_from_two_threads(gpu_lib):
+    """Two caller threads, two keys, interleaved mira_msm + mira_fft_bn256_fr (include/mira_gpu.h: re-entrant)."""
+    from test_host_logic import _two_thread_abi
+    _two_thread_abi(gpu_lib, n=20000, log_n=14, rounds=6)

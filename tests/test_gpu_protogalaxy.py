@@ -76,3 +76,11 @@ def test_tree_reduce_2p22_properties(gpu_lib):
                 want = want * wi[p][j] % MOD
         assert mont_to_ints(out[p:p + 1], MOD) == [want]
     gpu_lib.free(d)
+
+
+def test_basic_lagrange_kat(gpu_lib):
+    """basic_lagrange_test (src/polynomial/lagrange.rs:115-127): the reference's four constants
+    through the GPU library's get_omega_or_inv."""
+    from helpers import load_golden
+    kat = load_golden("ref_kats.json")["basic_lagrange_test"]
+    assert PG.eval_lagrange_poly_for_cyclic_group(kat["X"], kat["log_n"], gpu_lib) == [int(v) for v in kat["output_decimal"]]

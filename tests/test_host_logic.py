@@ -78,3 +78,40 @@ def test_unknown_handle_and_bad_args(emu_lib):
     assert emu_lib.c.mira_msm_set_window_bits(17) == MIRA_E_BAD_ARG
     h = ctypes.c_uint64()
     assert emu_lib.c.mira_msm_register_bases(7, None, 0, ctypes.byref(h)) == MIRA_E_BAD_ARG
+
+
+def _two_thread_abi(lib, n, log_n, rounds):
+    """Two caller threads, each with its own key (one per curve), interleaving mira_msm and
+    mira_fft_bn256_fr through the same library: the ABI promises re-entrancy (include/mira_gpu.h),
+    as `cargo test` calls commit from parallel test threads holding only &CommitmentKey."""
+    import threading
+    errors, results = [], {}
+
+    def worker(cid):
+        try:
+            bs = C.synth_bases(cid, n, seed=70 + cid)
+            key = cm.CommitmentKey(cid, bs, lib=lib)
+            a = C.synth_scalars(0, 1 << log_n, seed=80 + cid)
+            want_fft = C.fft(a, log_n)
+            out = []
+            for r in range(rounds):
+                sc = C.synth_scalars(cid, n - r, seed=90 + 10 * cid + r, kind=r % 2)
+                out.append((key.commit(sc), C.commit(cid, bs, sc)))
+                assert (F.fft(a, log_n, lib=lib) == want_fft).all()
+            results[cid] = out
+        except Exception as e:      # surfaced in the main thread
+            errors.append(repr(e))
+    th = [threading.Thread(target=worker, args=(cid,)) for cid in (0, 1)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    for cid in (0, 1):
+        assert len(results[cid]) == rounds
+        for got, want in results[cid]:
+            assert (got == want).all()
+
+
+def test_abi_from_two_threads(emu_lib):
+    _two_thread_abi(emu_lib, n=40, log_n=5, rounds=3)

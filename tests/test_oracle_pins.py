@@ -57,6 +57,12 @@ def test_fft_random_input_roundtrip():
             assert b == lst
 
 
+def test_basic_lagrange_kat():
+    # src/polynomial/lagrange.rs:115-127 basic_lagrange_test: L_i(2) over the 4-element cyclic subgroup
+    k = KATS["basic_lagrange_test"]
+    assert P.pg_lagrange(k["X"], k["log_n"]) == [int(v) for v in k["output_decimal"]]
+
+
 def test_g1_scalar_mul_kat():
     # src/digest.rs:98-113: into_curve_from_bits(MODULUS-1) == -G1Affine::generator()
     cv = P.BN256

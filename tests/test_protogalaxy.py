@@ -8,7 +8,7 @@ import random
 import numpy as np
 import pytest
 
-from helpers import ints_to_mont, mont_to_ints
+from helpers import ints_to_mont, load_golden, mont_to_ints
 from mira_amd import _lib
 from mira_amd import graph_evaluator as G
 from mira_amd import protogalaxy as PG
@@ -63,9 +63,12 @@ def test_lagrange_helpers_match_oracle(emu_lib):
         for X in (P.pg_cyclic_subgroup(log_n)[1], 12345, P.FR_ZETA):
             assert PG.eval_lagrange_poly_for_cyclic_group(X, log_n, emu_lib) == P.pg_lagrange(X, log_n)
             assert PG.eval_vanish_polynomial(log_n, X) == P.pg_vanish(log_n, X)
-    # basic_lagrange_test (lagrange.rs:115-127): on a domain element exactly one polynomial is 1
+    # correctness_for_cyclic_element (lagrange.rs:92-112): on a domain element exactly one polynomial is 1
     w = P.pg_cyclic_subgroup(2)
     assert PG.eval_lagrange_poly_for_cyclic_group(w[3], 2, emu_lib) == [0, 0, 0, 1]
+    # basic_lagrange_test (lagrange.rs:115-127): the reference's four constants
+    kat = load_golden("ref_kats.json")["basic_lagrange_test"]
+    assert PG.eval_lagrange_poly_for_cyclic_group(kat["X"], kat["log_n"], emu_lib) == [int(v) for v in kat["output_decimal"]]
 
 
 def test_tree_reduce_and_lincomb_kernels(emu_lib):

@@ -3,12 +3,12 @@ distributions, forced and planned window widths, window tables, batches, chunk p
 usage: python tools/fuzz_msm.py [seconds] [seed]"""
 import os, sys, time, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["MIRA_TABLE_MIN_N"] = "1"
 import numpy as np
 from mira_amd import _lib, commitment as cm
 from oracle import cref as C
 from oracle import pyref as P
 lib = _lib.load()
+lib.tune(_lib.TUNE_TABLE_MIN_N, 1)
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 MOD = {0: P.R_MOD, 1: P.P_MOD}                      # scalar field of each curve

@@ -107,11 +107,13 @@ int mira_msm_set_window_bits(int32_t c);
  * result): the smallest MSM that takes the LDS-staged two-level sort, the smallest MSM that uses a
  * handle's window tables, the smallest commit whose scalar-length statistics plan the next one, and
  * the longest NTT line (log2) -- shorter lines make the two- and three-pass schedules reachable at
- * small sizes.  value < 0 restores the default. */
+ * small sizes -- and whether lines of up to 256 points take the wave-level kernel (1, default) or
+ * the workgroup-level one (0).  value < 0 restores the default. */
 #define MIRA_TUNE_STAGED_MIN_N 0
 #define MIRA_TUNE_TABLE_MIN_N 1
 #define MIRA_TUNE_PLAN_HIST_MIN_N 2
 #define MIRA_TUNE_NTT_MAX_LOG_LINE 3
+#define MIRA_TUNE_NTT_WAVE 4
 int mira_set_tuning(int knob, int64_t value);
 
 /* Read a range of the registered key back in the reference layout (cache file writing,

@@ -28,7 +28,7 @@ SYMBOLS = [
     "mira_dev_alloc", "mira_dev_free", "mira_dev_upload", "mira_dev_download", "mira_dev_sync",
     "mira_set_timing", "mira_get_timings", "mira_set_tuning",
 ]
-TUNE_STAGED_MIN_N, TUNE_TABLE_MIN_N, TUNE_PLAN_HIST_MIN_N, TUNE_NTT_MAX_LOG_LINE = 0, 1, 2, 3
+TUNE_STAGED_MIN_N, TUNE_TABLE_MIN_N, TUNE_PLAN_HIST_MIN_N, TUNE_NTT_MAX_LOG_LINE, TUNE_NTT_WAVE = 0, 1, 2, 3, 4
 
 
 def _preload_hip_runtime():

@@ -78,7 +78,7 @@ struct Ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int32_t forced_c = 0;
-    int64_t tune[4] = {-1, -1, -1, -1};   // mira_set_tuning overrides, < 0 = default
+    int64_t tune[5] = {-1, -1, -1, -1, -1};   // mira_set_tuning overrides, < 0 = default
     Timing tm;
     // MSM workspace (grow-only, shared by all handles: calls are serialised by the ABI lock)
     DevBuf digits, counts, offsets, cursor, block_sums, sorted_idx, bucket_sums, part, coarse_offsets, fine_counts, fine_cursor;

@@ -6,7 +6,8 @@
 // ------------------------------------------------------------------------------------------
 // NTT host side
 using HFr = hostf::HFe<FrP>;
-static constexpr uint32_t NTT_PERSISTENT_GRID = 256;   // workgroups per resident round: one per CU times what fits a CU
+static constexpr uint32_t NTT_PERSISTENT_GRID = 256;
+static constexpr uint32_t NTT_SINGLE_TW_LOG = 16;      // post-twiddle exponents below 2^16: one 3 MiB table instead of a two-table product   // workgroups per resident round: one per CU times what fits a CU
 static HFr fr_root_of_unity(bool inverse) {
     // ROOT_OF_UNITY = 7^((r-1) >> 28); multiplicative generator 7, S = 28 (halo2curves bn256::Fr)
     uint64_t e[4];
@@ -30,17 +31,24 @@ static HFr get_omega_or_inv_h(uint32_t k, bool inverse) {   // src/fft.rs:12-23
 //   line_tw[p]   omega_N^j, j < N/2, for the line length N of pass p (shared when lengths repeat)
 //   lo[s], hi[s] the two halves of the post-twiddle exponent of pass s < passes - 1
 struct NttTables {
-    uint32_t passes, m[3], h[2];
+    uint32_t passes, m[3], h[2], single[2];
     size_t off_tw[3], off_lo[2], off_hi[2];
 };
+// Longest line of a transform of 2^log_n points.  Lines of up to 256 points run on the wave-level
+// kernel (k_ntt_wave: no barriers, two layers per LDS trip), so sizes that split into two or three
+// such passes (2^13 .. 2^24) use it; 2^9 .. 2^12 stay one launch of the workgroup-level kernel, and
+// 2^25 .. 2^28 need its longer lines to fit three passes.
 // MIRA_TUNE_NTT_MAX_LOG_LINE: a smaller maximum line makes the two- and three-pass schedules
-// reachable at sizes the CPU emulation can run
-static uint32_t ntt_max_log_line() {
-    const int v = (int)tuned(MIRA_TUNE_NTT_MAX_LOG_LINE, NTT_MAX_LOG_LINE);
+// reachable at sizes the CPU emulation can run; MIRA_TUNE_NTT_WAVE = 0 keeps every line on k_ntt_lines.
+static bool ntt_wave_enabled() { return tuned(MIRA_TUNE_NTT_WAVE, 1) != 0; }
+static uint32_t ntt_max_log_line(uint32_t log_n) {
+    if (g.tune[MIRA_TUNE_NTT_MAX_LOG_LINE] < 0)
+        return (ntt_wave_enabled() && (log_n <= NTTW_LOG || (log_n > NTT_MAX_LOG_LINE && log_n <= 3 * NTTW_LOG))) ? NTTW_LOG : NTT_MAX_LOG_LINE;
+    const int v = (int)g.tune[MIRA_TUNE_NTT_MAX_LOG_LINE];
     return (uint32_t)std::min(std::max(v, 1), NTT_MAX_LOG_LINE);
 }
 static int ntt_prepare_tables(uint32_t log_n, const uint64_t omega[4], NttTables &t) {
-    const uint32_t max_line = ntt_max_log_line();
+    const uint32_t max_line = ntt_max_log_line(log_n);
     t.passes = log_n <= max_line ? 1 : log_n <= 2 * max_line ? 2 : 3;
     uint32_t rest = log_n;
     for (uint32_t p = 0; p < 3; p++) {                        // balanced split, larger factors first
@@ -57,7 +65,8 @@ static int ntt_prepare_tables(uint32_t log_n, const uint64_t omega[4], NttTables
         t.off_tw[p] = off; off += n_tw[p] * TW_BYTES;
     }
     for (uint32_t q = 0; q + 1 < t.passes; q++) {
-        t.h[q] = (range[q] + 1) / 2;
+        t.single[q] = range[q] <= NTT_SINGLE_TW_LOG;                               // small ranges: one table, no product per element
+        t.h[q] = t.single[q] ? range[q] : (range[q] + 1) / 2;
         n_lo[q] = (size_t)1 << t.h[q]; n_hi[q] = (size_t)1 << (range[q] - t.h[q]);
         t.off_lo[q] = off; off += n_lo[q] * TW_BYTES;
         t.off_hi[q] = off; off += n_hi[q] * TW_BYTES;
@@ -101,7 +110,7 @@ static int ntt_device_locked(void *d_a, uint32_t log_n, const uint64_t omega[4],
     int rc;
     if (!d_a || !omega) { set_error("null argument"); return MIRA_E_BAD_ARG; }
     if (log_n > 28) { set_error("k=" + std::to_string(log_n) + " should no larger than F::S=28"); return MIRA_E_BAD_ARG; }
-    if (log_n > 3 * ntt_max_log_line()) { set_error("log_n exceeds three passes of the configured line length"); return MIRA_E_UNSUPPORTED; }
+    if (log_n > 3 * ntt_max_log_line(log_n)) { set_error("log_n exceeds three passes of the configured line length"); return MIRA_E_UNSUPPORTED; }
     NttTables t;
     tm_begin();
     if ((rc = ntt_prepare_tables(log_n, omega, t))) return rc;
@@ -128,9 +137,32 @@ static int ntt_device_locked(void *d_a, uint32_t log_n, const uint64_t omega[4],
     const unsigned char *cnull = nullptr;
     auto threads_for = [](uint32_t m) { return std::min<uint32_t>(1024, std::max<uint32_t>(64, (1u << m) / 2)); };
     auto lds_for = [](uint32_t m) { return ((size_t)NTT_LDS_BYTES_PER_ELEM << m) + 16 + ((size_t)NTT_LDS_BYTES_PER_ELEM << NTT_LDS_TW_LOG); };
-    auto run = [&](const NttPass &ps, const unsigned char *src, unsigned char *dst, uint32_t p, int tw, const char *name) {
+    auto run = [&](NttPass ps, const unsigned char *src, unsigned char *dst, uint32_t p, int tw, const char *name) {
         // persistent grid: as many workgroups per CU as LDS and the 2048-lane limit allow (one for
         // 4096-point lines, eight for the 512-point lines of the three-pass schedule)
+        if (ntt_wave_enabled() && ps.log_len <= (uint32_t)NTTW_LOG) {
+            // one wave per 256 points, four waves per workgroup, three workgroups (12 waves) per CU
+            const uint32_t lpw = 1u << (NTTW_LOG - ps.log_len);
+            const uint32_t nbg = ceil_div(ceil_div(ps.nlines, lpw), NTTW_WAVES);
+            // the NTTW_WAVES * lpw lines of a workgroup form a tile when they are adjacent in memory
+            // (line l starts at (l >> split) * hi + (l & mask) * lo) and the pass has only whole tiles
+            const uint64_t tl = (uint64_t)NTTW_WAVES * lpw;
+            auto adjacent = [&](uint64_t hi, uint64_t lo) { return ps.split == 0 ? hi == 1 : (lo == 1 && tl <= ((uint64_t)1 << ps.split)); };
+            if (NTTW_WAVES == 4 && ps.nlines % tl == 0)
+                ps.coop = (adjacent(ps.in_hi, ps.in_lo) ? 1u : 0u) | (adjacent(ps.out_hi, ps.out_lo) ? 2u : 0u);
+#define NTTW_LAUNCH(COOP)                                                                                                                                  \
+    LAUNCH_BARRIER((k_ntt_wave<Fr29, COOP>), std::min<uint32_t>(nbg, NTT_PERSISTENT_GRID * 3), 64 * NTTW_WAVES, NTTW_LDS_BYTES, g.stream, src, dst, ps,       \
+                   tab + t.off_tw[p], tw >= 0 ? tab + t.off_lo[tw] : cnull, tw >= 0 ? tab + t.off_hi[tw] : cnull, tw >= 0 ? cnull : (const unsigned char *)scale_d)
+            switch (ps.coop) {
+                case 0: NTTW_LAUNCH(0); break;
+                case 1: NTTW_LAUNCH(1); break;
+                case 2: NTTW_LAUNCH(2); break;
+                default: NTTW_LAUNCH(3); break;
+            }
+#undef NTTW_LAUNCH
+            tm_mark(name);
+            return;
+        }
         const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(8, (160 * 1024) / lds_for(ps.log_len)), 2048 / threads_for(ps.log_len)));
         LAUNCH_BARRIER(k_ntt_lines<Fr29>, std::min<uint32_t>(ps.nlines, NTT_PERSISTENT_GRID * per_cu), threads_for(ps.log_len), lds_for(ps.log_len), g.stream, src, dst, ps,
                        tab + t.off_tw[p], tw >= 0 ? tab + t.off_lo[tw] : cnull, tw >= 0 ? tab + t.off_hi[tw] : cnull,
@@ -140,18 +172,18 @@ static int ntt_device_locked(void *d_a, uint32_t log_n, const uint64_t omega[4],
     const uint64_t n1 = (uint64_t)1 << t.m[0], n2 = (uint64_t)1 << t.m[1], n3 = (uint64_t)1 << t.m[2];
     const uint32_t NONE = 0xFFFFFFFFu;
     if (t.passes == 1) {
-        run(NttPass{t.m[0], 1, 0, 0, 0, 0, 1, 0, 0, 1, NONE, 0u}, a, a, 0, -1, "ntt_single");
+        run(NttPass{t.m[0], 1, 0, 0, 0, 0, 1, 0, 0, 1, NONE, 0u, 0u, 0u}, a, a, 0, -1, "ntt_single");
     } else {
         if ((rc = g.ntt_tmp.ensure(((size_t)32) << log_n))) return rc;
         unsigned char *tmp = reinterpret_cast<unsigned char *>(g.ntt_tmp.p);
         if (t.passes == 2) {
-            run(NttPass{t.m[0], (uint32_t)n2, 0, 0, 1, 0, n2, n1, 0, 1, t.h[0], 0u}, a, tmp, 0, 0, "ntt_pass1");
-            run(NttPass{t.m[1], (uint32_t)n1, 0, 0, 1, 0, n1, 1, 0, n1, NONE, 0u}, tmp, a, 1, -1, "ntt_pass2");
+            run(NttPass{t.m[0], (uint32_t)n2, 0, 0, 1, 0, n2, n1, 0, 1, t.h[0], t.single[0], 0u, 0u}, a, tmp, 0, 0, "ntt_pass1");
+            run(NttPass{t.m[1], (uint32_t)n1, 0, 0, 1, 0, n1, 1, 0, n1, NONE, 0u, 0u, 0u}, tmp, a, 1, -1, "ntt_pass2");
         } else {
             const uint64_t m = n2 * n3;
-            run(NttPass{t.m[0], (uint32_t)m, 0, 0, 1, 0, m, n1, 0, 1, t.h[0], 0u}, a, tmp, 0, 0, "ntt_pass1");
-            run(NttPass{t.m[1], (uint32_t)(n1 * n3), t.m[0], t.m[0], n1, 1, n3 * n1, n1 * n2, 1, n1, t.h[1], 0u}, tmp, a, 1, 1, "ntt_pass2");
-            run(NttPass{t.m[2], (uint32_t)(n1 * n2), 0, 0, 1, 0, n1 * n2, 1, 0, n1 * n2, NONE, 0u}, a, a, 2, -1, "ntt_pass3");
+            run(NttPass{t.m[0], (uint32_t)m, 0, 0, 1, 0, m, n1, 0, 1, t.h[0], t.single[0], 0u, 0u}, a, tmp, 0, 0, "ntt_pass1");
+            run(NttPass{t.m[1], (uint32_t)(n1 * n3), t.m[0], t.m[0], n1, 1, n3 * n1, n1 * n2, 1, n1, t.h[1], t.single[1], 0u, 0u}, tmp, a, 1, 1, "ntt_pass2");
+            run(NttPass{t.m[2], (uint32_t)(n1 * n2), 0, 0, 1, 0, n1 * n2, 1, 0, n1 * n2, NONE, 0u, 0u, 0u}, a, a, 2, -1, "ntt_pass3");
         }
     }
     RT_CHECK(rt_last());
@@ -201,6 +233,10 @@ int ntt_init() {
 #ifndef MIRA_CPU_EMU
     // a 4096-point line is 128 KiB of LDS, above the 64 KiB default
     RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_lines<Fr29>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_wave<Fr29, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTTW_LDS_BYTES));
+    RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_wave<Fr29, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTTW_LDS_BYTES));
+    RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_wave<Fr29, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTTW_LDS_BYTES));
+    RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_wave<Fr29, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTTW_LDS_BYTES));
 #endif
     return MIRA_OK;
 }

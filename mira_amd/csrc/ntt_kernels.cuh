@@ -57,6 +57,8 @@ struct NttPass {
     uint64_t in_hi, in_lo, in_elem_stride;
     uint64_t out_hi, out_lo, out_elem_stride;
     uint32_t tw_shift;         // post-twiddle w^e = T_hi[e >> tw_shift] * T_lo[e & mask]; 0xFFFFFFFF = none
+    uint32_t tw_single;        // 1: the exponent range fits T_lo alone (w^e = T_lo[e], no product)
+    uint32_t coop;             // k_ntt_wave: bit 0 / bit 1 = the lines of a workgroup are adjacent in the input / output
     uint32_t reserved;
 };
 
@@ -167,7 +169,8 @@ KERNEL void __launch_bounds__(1024) k_ntt_lines(const unsigned char *__restrict_
             Fe29<F> v = L.load(k, bound);
             if (ps.tw_shift != 0xFFFFFFFFu) {
                 uint64_t e = (uint64_t)(line >> ps.tw_line_shift) * k;
-                Fe29<F> tw = f29_mul(tw_load<F>(t_hi + (size_t)(e >> ps.tw_shift) * TW_BYTES), tw_load<F>(t_lo + (size_t)(e & lo_mask) * TW_BYTES));
+                Fe29<F> tw = ps.tw_single ? tw_load<F>(t_lo + (size_t)e * TW_BYTES)
+                                          : f29_mul(tw_load<F>(t_hi + (size_t)(e >> ps.tw_shift) * TW_BYTES), tw_load<F>(t_lo + (size_t)(e & lo_mask) * TW_BYTES));
                 v = f29_mul(v, tw);
             } else {
                 v = f29_mul(v, tw_load<F>(scale));
@@ -175,6 +178,225 @@ KERNEL void __launch_bounds__(1024) k_ntt_lines(const unsigned char *__restrict_
             fe_store(out + (size_t)k * ps.out_elem_stride * 32, f29_canonical(v));
         }
         __syncthreads();                                 // LDS is rewritten by the next line
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_ntt_wave: lines of up to 256 points, one WAVE per 256 points, no workgroup barrier.
+//
+// k_ntt_lines above walks one layer at a time through LDS: 12 barriers per 4096-point line, every
+// value through LDS twice per layer (measured: 47 % of wave cycles waiting, 59 % of LDS cycles bank
+// conflicts).  Here a wave keeps 4 points per lane in registers and runs TWO layers per trip: the
+// two index bits being paired are register bits, so both layers are plain register arithmetic; then
+// the wave transposes its 256 points through a private LDS region (9 limb planes of 256 dwords) to
+// bring the next two index bits into register position.  A 256-point line costs 3 transposes and no
+// barrier; waves are independent, so three per SIMD hide each other's memory latency without a
+// software prefetch.  Lines shorter than 256 points share a wave (2^(8-m) lines per wave).
+//
+// Position algebra (DIT on bit-reversed input): p in [0, 256) = (line-in-wave << m) | position.
+// Round t owns layers 2t and 2t+1; its layout puts bits 2t, 2t+1 of p in the register index r:
+//     p_t(lane, r) = (lane >> 2t) << (2t + 2) | r << 2t | lane & (4^t - 1)
+// The LDS slot of p is p with bits 5 and 6 folded into the low five bits (slot = p ^ 5 p5 ^ 26 p6):
+// for each of the four layouts the 32 lanes of a half-wave then hit 32 different banks, both when
+// a round's results are written and when the next round's operands are read.
+static constexpr int NTTW_LOG = 8;                       // 256 points per wave
+static constexpr int NTTW_WAVES = 4;                     // waves per workgroup; three workgroups per CU (41 KiB of LDS each)
+static constexpr int NTTW_PLANE = 256;                   // dwords per limb plane
+static constexpr size_t NTTW_LDS_BYTES = (size_t)NTTW_WAVES * 9 * NTTW_PLANE * 4 + 128 * 9 * 4;   // exchange planes + N/2 twiddles
+
+// Strided lines: element q of a line is in_elem_stride elements away from element q - 1, but the
+// same element of the NEXT line is adjacent.  A lone wave reading its own line therefore issues 64
+// separate 16-byte requests per instruction (measured: the loads and stores cost 0.17 ms of a 0.9 ms
+// pass although the HBM traffic is ideal).  Where the 4 * 2^(8-m) lines of a workgroup are adjacent
+// (NttPass::coop), the workgroup moves them as ONE tile: every 8 consecutive lanes read or write 128
+// contiguous bytes, and the tile goes through LDS (aliasing the exchange planes, hence the
+// barriers) to hand each wave its own lines.
+// 16-byte slot of column `pos` of tile row i (second half at + 1); the XOR spreads the columns a
+// half-wave reads (pos = 4 lane + r) over all banks
+HD uint32_t nttw_tslot(uint32_t i, uint32_t pos, uint32_t m) { return ((((i << m) | pos) ^ ((pos >> 3) & 7u)) << 1); }
+HD uint32_t nttw_slot(uint32_t p) { return p ^ (((p >> 5) & 1u) * 0x05u) ^ (((p >> 6) & 1u) * 0x1Au); }
+HD uint32_t nttw_pos(uint32_t lane, uint32_t r, uint32_t t) {
+    const uint32_t sh = 2 * t;
+    return ((lane >> sh) << (sh + 2)) | (r << sh) | (lane & ((1u << sh) - 1u));
+}
+// one DIT butterfly: (u, v) -> (u + w v, u - w v); bound(u), bound(v) <= b on entry, <= b + 3 on exit
+template <class F> DEV void nttw_bfly(Fe29<F> &u, Fe29<F> &v, const uint32_t *tw9) {
+    Fe29<F> w;
+#pragma unroll
+    for (int k = 0; k < 9; k++) w.l[k] = tw9[k];
+    F29_SET(w, 1.0);
+    const Fe29<F> t = f29_mul(v, w);
+    v = f29_sub<3>(u, t);
+    u = f29_add(u, t);
+}
+template <class F> DEV void nttw_bfly_one(Fe29<F> &u, Fe29<F> &v) {    // w = 1 (layer 0 of every line)
+    const Fe29<F> t = v;
+    v = f29_sub<3>(u, t);
+    u = f29_add(u, t);
+}
+
+// the four points of a lane are four named values (never an indexed array: a dynamically indexed
+// register array would be demoted to scratch memory)
+template <class F> DEV void nttw_put(uint32_t *X, const Fe29<F> &v, uint32_t slot) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) X[k * NTTW_PLANE + slot] = v.l[k];
+}
+template <class F> DEV void nttw_get(const uint32_t *X, Fe29<F> &v, uint32_t slot, double bound) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) v.l[k] = X[k * NTTW_PLANE + slot];
+    F29_SET(v, bound);
+    (void)bound;
+}
+template <class F> struct NttwIo {
+    const unsigned char *src;
+    unsigned char *dst;
+    const unsigned char *t_lo, *t_hi, *scale;
+    NttPass ps;
+    uint32_t lo_mask, split_mask, m, N;
+    // DIT position p of this wave (round-0 layout) -> the canonical input element, or zero past the last line
+    DEV Fe<typename F::Sat> fetch(uint32_t line0, uint32_t p) const {
+        using S = typename F::Sat;
+        const uint32_t pos = p & (N - 1), line = line0 + (p >> m);
+        const uint32_t q = m ? (__brev(pos) >> (32 - m)) : 0;      // natural input index of DIT position pos
+        if (line >= ps.nlines) return fe_zero<S>();
+        return fe_load<S>(src + (in_start(line) + (size_t)q * ps.in_elem_stride) * 32);
+    }
+    DEV size_t in_start(uint32_t line) const { return (size_t)(line >> ps.split) * ps.in_hi + (size_t)(line & split_mask) * ps.in_lo; }
+    DEV size_t out_start(uint32_t line) const { return (size_t)(line >> ps.split) * ps.out_hi + (size_t)(line & split_mask) * ps.out_lo; }
+    // output k of its line: times the four-step twiddle (or the final scale), canonical
+    DEV Fe<typename F::Sat> finish(uint32_t line, uint32_t k, const Fe29<F> &x) const {
+        Fe29<F> v;
+        if (ps.tw_shift != 0xFFFFFFFFu) {
+            const uint64_t e = (uint64_t)(line >> ps.tw_line_shift) * k;
+            const Fe29<F> tw = ps.tw_single ? tw_load<F>(t_lo + (size_t)e * TW_BYTES)
+                                            : f29_mul(tw_load<F>(t_hi + (size_t)(e >> ps.tw_shift) * TW_BYTES), tw_load<F>(t_lo + (size_t)(e & lo_mask) * TW_BYTES));
+            v = f29_mul(x, tw);
+        } else {
+            v = f29_mul(x, tw_load<F>(scale));
+        }
+        return f29_canonical(v);
+    }
+    DEV void store(uint32_t line0, uint32_t p, const Fe29<F> &x) const {
+        const uint32_t k = p & (N - 1), line = line0 + (p >> m);
+        if (line >= ps.nlines) return;
+        fe_store(dst + (out_start(line) + (size_t)k * ps.out_elem_stride) * 32, finish(line, k, x));
+    }
+    // ---- workgroup tiles (NttPass::coop): 1024 elements = TL adjacent lines x N points -------------
+    // global -> LDS tile, column q of every row stored at its DIT position brev(q); 8 x 16 bytes per lane
+    DEV void tile_fill(U4 *tile, uint32_t line_blk0) const {
+        const uint32_t log_tl = 10 - m, tl_mask = (1u << log_tl) - 1u;
+        const unsigned char *base = src + in_start(line_blk0) * 32;
+#pragma unroll
+        for (int it = 0; it < 8; it++) {                           // (the compiler hoists the eight loads above the LDS stores)
+            const uint32_t c = it * 256 + threadIdx.x, e = c >> 1, q = e >> log_tl, i = e & tl_mask;
+            const U4 v = *reinterpret_cast<const U4 *>(base + ((size_t)i + (size_t)q * ps.in_elem_stride) * 32 + (c & 1u) * 16);
+            tile[nttw_tslot(i, m ? (__brev(q) >> (32 - m)) : 0, m) + (c & 1u)] = v;
+        }
+    }
+    DEV Fe29<F> tile_take(const U4 *tile, uint32_t row0, uint32_t p) const {
+        using S = typename F::Sat;
+        const uint32_t sl = nttw_tslot(row0 + (p >> m), p & (N - 1), m);
+        const U4 a = tile[sl], b = tile[sl + 1];
+        Fe<S> s;
+        s.l[0] = a.x; s.l[1] = a.y; s.l[2] = a.z; s.l[3] = a.w; s.l[4] = b.x; s.l[5] = b.y; s.l[6] = b.z; s.l[7] = b.w;
+        return f29_unpack_canonical<F>(s);
+    }
+    DEV void tile_give(U4 *tile, uint32_t line0, uint32_t row0, uint32_t p, const Fe29<F> &x) const {
+        const uint32_t k = p & (N - 1);
+        const Fe<typename F::Sat> s = finish(line0 + (p >> m), k, x);
+        const uint32_t sl = nttw_tslot(row0 + (p >> m), k, m);
+        tile[sl] = U4{s.l[0], s.l[1], s.l[2], s.l[3]};
+        tile[sl + 1] = U4{s.l[4], s.l[5], s.l[6], s.l[7]};
+    }
+    DEV void tile_drain(const U4 *tile, uint32_t line_blk0) const {
+        const uint32_t log_tl = 10 - m, tl_mask = (1u << log_tl) - 1u;
+        unsigned char *base = dst + out_start(line_blk0) * 32;
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const uint32_t c = it * 256 + threadIdx.x, e = c >> 1, k = e >> log_tl, i = e & tl_mask;
+            *reinterpret_cast<U4 *>(base + ((size_t)i + (size_t)k * ps.out_elem_stride) * 32 + (c & 1u) * 16) = tile[nttw_tslot(i, k, m) + (c & 1u)];
+        }
+    }
+};
+
+// COOP: bit 0 / bit 1 = the input / output lines of a workgroup move as one tile (NttPass::coop);
+// a compile-time choice so that neither path's registers burden the other
+template <class F, int COOP>
+KERNEL void __launch_bounds__(64 * NTTW_WAVES) __attribute__((amdgpu_waves_per_eu(3, 3))) k_ntt_wave(const unsigned char *__restrict__ src, unsigned char *__restrict__ dst, NttPass ps,
+                        const unsigned char *__restrict__ line_tw,   // omega_N^j, j < N/2, TW_BYTES each
+                        const unsigned char *__restrict__ t_lo, const unsigned char *__restrict__ t_hi,
+                        const unsigned char *__restrict__ scale) {   // multiplier-form scale, or one, for the last pass
+    DYN_SHARED(uint32_t, lds);
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint32_t *X = lds + (size_t)wv * 9 * NTTW_PLANE;              // this wave's exchange planes
+    uint32_t *TW = lds + (size_t)NTTW_WAVES * 9 * NTTW_PLANE;     // the line's twiddles, 9 dwords each, shared
+    const uint32_t m = ps.log_len, N = 1u << m;
+    for (uint32_t i = threadIdx.x; i < (N / 2) * 9; i += blockDim.x)
+        TW[i] = reinterpret_cast<const uint32_t *>(line_tw + (size_t)(i / 9) * TW_BYTES)[i % 9];
+    __syncthreads();
+    const NttwIo<F> io{src, dst, t_lo, t_hi, scale, ps, ps.tw_shift == 0xFFFFFFFFu ? 0 : ((1u << ps.tw_shift) - 1u), (1u << ps.split) - 1u, m, N};
+    const uint32_t log_lpw = NTTW_LOG - m, lpw = 1u << log_lpw;    // lines per wave
+    const uint32_t rounds = (m + 1) / 2;
+    // block-groups of NTTW_WAVES consecutive wave-groups (4 * lpw consecutive lines: their strided
+    // elements share 128-byte lines); XCD-aware order as in k_ntt_lines
+    const uint32_t ngroups = (ps.nlines + lpw - 1) >> log_lpw, nbg = (ngroups + NTTW_WAVES - 1) / NTTW_WAVES;
+    auto first_line = [&](uint32_t idx) {
+        const uint32_t bg = ((nbg & 7u) == 0) ? (idx & 7u) * (nbg >> 3) + (idx >> 3) : idx;
+        return (bg * NTTW_WAVES + wv) << log_lpw;                   // first line of this wave
+    };
+    // (a register prefetch of the next group's elements was measured: no gain -- the other waves of
+    // the SIMD already cover the strided loads; nor did a fourth wave per SIMD, eight-wave workgroups at 128 VGPRs)
+    U4 *tile = reinterpret_cast<U4 *>(lds);                        // 32 KiB, aliases the exchange planes
+    const uint32_t row0 = wv << log_lpw;                           // this wave's first row of the tile
+    for (uint32_t idx = blockIdx.x; idx < nbg; idx += gridDim.x) {
+        const uint32_t line0 = first_line(idx), line_blk0 = line0 - row0;
+        Fe29<F> x0, x1, x2, x3;
+        if (COOP & 1) {
+            io.tile_fill(tile, line_blk0);
+            __syncthreads();
+            x0 = io.tile_take(tile, row0, nttw_pos(lane, 0, 0)); x1 = io.tile_take(tile, row0, nttw_pos(lane, 1, 0));
+            x2 = io.tile_take(tile, row0, nttw_pos(lane, 2, 0)); x3 = io.tile_take(tile, row0, nttw_pos(lane, 3, 0));
+            __syncthreads();                                       // the exchange planes overwrite the tile
+        } else {
+            x0 = f29_unpack_canonical<F>(io.fetch(line0, nttw_pos(lane, 0, 0))); x1 = f29_unpack_canonical<F>(io.fetch(line0, nttw_pos(lane, 1, 0)));
+            x2 = f29_unpack_canonical<F>(io.fetch(line0, nttw_pos(lane, 2, 0))); x3 = f29_unpack_canonical<F>(io.fetch(line0, nttw_pos(lane, 3, 0)));
+        }
+        for (uint32_t t = 0; t < rounds; t++) {
+            if (t) {                                               // transpose: layout t-1 -> layout t
+                nttw_put(X, x0, nttw_slot(nttw_pos(lane, 0, t - 1))); nttw_put(X, x1, nttw_slot(nttw_pos(lane, 1, t - 1)));
+                nttw_put(X, x2, nttw_slot(nttw_pos(lane, 2, t - 1))); nttw_put(X, x3, nttw_slot(nttw_pos(lane, 3, t - 1)));
+                WAVE_SYNC();
+                const double bound = 1.0 + 6.0 * t;
+                nttw_get(X, x0, nttw_slot(nttw_pos(lane, 0, t)), bound); nttw_get(X, x1, nttw_slot(nttw_pos(lane, 1, t)), bound);
+                nttw_get(X, x2, nttw_slot(nttw_pos(lane, 2, t)), bound); nttw_get(X, x3, nttw_slot(nttw_pos(lane, 3, t)), bound);
+                WAVE_SYNC();
+            }
+            const uint32_t s = 2 * t, j = lane & ((1u << s) - 1u);  // j = p mod 2^s
+            if (s == 0) {
+                nttw_bfly_one(x0, x1);
+                nttw_bfly_one(x2, x3);
+            } else {
+                const uint32_t *tw = TW + (size_t)(j << (m - 1 - s)) * 9;
+                nttw_bfly(x0, x1, tw);
+                nttw_bfly(x2, x3, tw);
+            }
+            if (s + 1 < m) {                                       // layer s + 1: p mod 2^(s+1) = j + (r & 1) 2^s
+                nttw_bfly(x0, x2, TW + (size_t)(j << (m - 2 - s)) * 9);
+                nttw_bfly(x1, x3, TW + (size_t)((j + (1u << s)) << (m - 2 - s)) * 9);
+            }
+        }
+        const uint32_t tl = rounds ? rounds - 1 : 0;
+        if (COOP & 2) {
+            __syncthreads();                                       // every wave is done with its exchange planes
+            io.tile_give(tile, line0, row0, nttw_pos(lane, 0, tl), x0); io.tile_give(tile, line0, row0, nttw_pos(lane, 1, tl), x1);
+            io.tile_give(tile, line0, row0, nttw_pos(lane, 2, tl), x2); io.tile_give(tile, line0, row0, nttw_pos(lane, 3, tl), x3);
+            __syncthreads();
+            io.tile_drain(tile, line_blk0);
+            __syncthreads();                                       // the next group's tile or exchange planes reuse the space
+        } else {
+            io.store(line0, nttw_pos(lane, 0, tl), x0); io.store(line0, nttw_pos(lane, 1, tl), x1);
+            io.store(line0, nttw_pos(lane, 2, tl), x2); io.store(line0, nttw_pos(lane, 3, tl), x3);
+        }
     }
 }
 

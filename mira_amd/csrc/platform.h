@@ -21,6 +21,9 @@
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), (shmem), (stream), __VA_ARGS__)
 #define LAUNCH_BARRIER LAUNCH
 #define LAUNCH_BARRIER_FLEX LAUNCH   // kernel is correct for any blockDim (strided loops)
+// lanes of one wave exchange data through LDS without a workgroup barrier: the DS unit serves a
+// wave's instructions in order; the fence keeps the compiler from moving LDS accesses across it
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 #define DYN_SHARED(type, name) extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw[]; type *name = reinterpret_cast<type *>(name##_raw)
 #else
 #include "../../tests/emu/emu.h"

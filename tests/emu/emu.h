@@ -34,6 +34,7 @@ template <class T> inline T atomicMax(T *p, T v) {
     while (o < v && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
     return o;
 }
+#define WAVE_SYNC() __syncthreads()   /* emulated lanes are OS threads: a wave-level exchange needs the block barrier (control flow is block-uniform wherever it is used) */
 inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 inline unsigned __brev(unsigned x) {
     unsigned r = 0;

@@ -114,11 +114,14 @@ def test_emu_ntt_four_step(emu_lib):
     assert (F.best_fft(a, w, k, lib=emu_lib) == C.best_fft(a, w, k)).all()
 
 
+@pytest.mark.parametrize("wave", [1, 0])
 @pytest.mark.parametrize("max_line,ks", [(3, (4, 5, 6, 7, 8, 9)), (4, (9, 11, 12)), (2, (5, 6))])
-def test_emu_ntt_pass_schedules(emu_lib, max_line, ks):
-    """Two- and three-pass schedules (the latter serves log_n 25..28 on the GPU) at emulation sizes:
-    MIRA_TUNE_NTT_MAX_LOG_LINE shortens the lines so that every split is exercised."""
+def test_emu_ntt_pass_schedules(emu_lib, max_line, ks, wave):
+    """Two- and three-pass schedules at emulation sizes: MIRA_TUNE_NTT_MAX_LOG_LINE shortens the
+    lines so that every split is exercised, on the wave-level kernel (k_ntt_wave: 2^13 .. 2^24 on the
+    GPU) and on the workgroup-level one (k_ntt_lines: 2^25 .. 2^28)."""
     emu_lib.tune(_lib.TUNE_NTT_MAX_LOG_LINE, max_line)
+    emu_lib.tune(_lib.TUNE_NTT_WAVE, wave)
     try:
         for k in ks:
             a = C.synth_scalars(0, 1 << k, seed=2000 + k)
@@ -131,6 +134,21 @@ def test_emu_ntt_pass_schedules(emu_lib, max_line, ks):
             F.fft(C.synth_scalars(0, 1 << (3 * max_line + 1), seed=1), 3 * max_line + 1, lib=emu_lib)
     finally:
         emu_lib.tune(_lib.TUNE_NTT_MAX_LOG_LINE, -1)
+        emu_lib.tune(_lib.TUNE_NTT_WAVE, -1)
+
+
+@pytest.mark.parametrize("k", [6, 7, 8])
+def test_emu_ntt_wave_full_lines(emu_lib, k):
+    """k_ntt_wave with lines of 64, 128 and 256 points (one to three register/LDS transposes), as a
+    single pass and as the first pass of a split."""
+    for kk in (k, k + 3):
+        emu_lib.tune(_lib.TUNE_NTT_MAX_LOG_LINE, k)
+        try:
+            a = C.synth_scalars(0, 1 << kk, seed=3000 + kk)
+            assert (F.fft(a, kk, lib=emu_lib) == C.fft(a, kk)).all(), kk
+            assert (F.ifft(a, kk, lib=emu_lib) == C.ifft(a, kk)).all(), kk
+        finally:
+            emu_lib.tune(_lib.TUNE_NTT_MAX_LOG_LINE, -1)
 
 
 def test_emu_omega(emu_lib):

@@ -74,3 +74,18 @@ def test_three_pass_2p25_vs_oracle(gpu_lib):
     fa = F.fft(a, k)
     assert (fa == C.fft(a, k)).all()
     assert (F.ifft(fa, k) == a).all()
+
+
+@pytest.mark.parametrize("k", [3, 8, 13, 15, 18, 21])
+def test_wave_and_workgroup_kernels_agree(gpu_lib, k):
+    """The wave-level kernel (default for these sizes) and the workgroup-level kernel give the same
+    transform, both equal to the oracle."""
+    from mira_amd import _lib
+    a = C.synth_scalars(0, 1 << k, seed=500 + k)
+    want = C.fft(a, k)
+    assert (F.fft(a, k) == want).all()
+    gpu_lib.tune(_lib.TUNE_NTT_WAVE, 0)
+    try:
+        assert (F.fft(a, k) == want).all()
+    finally:
+        gpu_lib.tune(_lib.TUNE_NTT_WAVE, -1)

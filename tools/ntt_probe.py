@@ -6,6 +6,8 @@ if os.environ.get("MIRA_PROBE_LIB"):
     _lib.LIB_PATH = os.path.abspath(os.environ["MIRA_PROBE_LIB"])   # development: a variant build
 from mira_amd import commitment as cm, fft as F
 lib = _lib.load()
+if os.environ.get("MIRA_PROBE_WAVE"):
+    lib.tune(_lib.TUNE_NTT_WAVE, int(os.environ["MIRA_PROBE_WAVE"]))
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 d = cm.synth_scalars_device(0, 1 << k, seed=5)
 F.fft_device(d, k)

@@ -82,7 +82,7 @@ struct Ctx {
     Timing tm;
     // MSM workspace (grow-only, shared by all handles: calls are serialised by the ABI lock)
     DevBuf digits, counts, offsets, cursor, block_sums, sorted_idx, bucket_sums, part, coarse_offsets, fine_counts, fine_cursor;
-    DevBuf head_part, tail_part, head_key, tail_key, heavy, heavy_out, chunks, window_sums, scalars_stage, consts;
+    DevBuf head_part, tail_part, tail_key, heavy, heavy_out, chunks, window_sums, scalars_stage, consts;
     // NTT workspace
     DevBuf ntt_tmp, ntt_stage, ntt_tables, ntt_consts;
     DevBuf fold_consts;

@@ -12,6 +12,10 @@ static constexpr uint32_t FIXUP_HEAVY_GRID = 4;     // emulated lanes are OS thr
 static constexpr uint32_t FIXUP_HEAVY_GRID = 4096;   // waves; idle ones leave at once
 #endif
 
+// quads for the bucket reduction while its work items number less than ~1.5 waves per SIMD (the
+// chain of dependent additions is what takes the time there); single lanes beyond (throughput)
+static inline bool reduce_with_quads(uint64_t work_items) { return work_items * 4 <= 98304; }
+
 template <class F, class FS>
 static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size_t n, const MsmPlan &p,
                       uint64_t *host_windows /* count * W * 16 u64 */) {
@@ -34,7 +38,6 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size
     if ((rc = g.bucket_sums.ensure((size_t)p.NB * XYZZ29_BYTES))) return rc;
     if ((rc = g.head_part.ensure((size_t)p.T * XYZZ29_BYTES))) return rc;
     if ((rc = g.tail_part.ensure((size_t)p.T * XYZZ29_BYTES))) return rc;
-    if ((rc = g.head_key.ensure((size_t)p.T * 4))) return rc;
     if ((rc = g.tail_key.ensure((size_t)p.T * 4))) return rc;
     if ((rc = g.heavy.ensure(64 + ((size_t)p.T / 2 + 8) * 32))) return rc;            // counters, runs, sub-job descriptors
     if ((rc = g.heavy_out.ensure(((size_t)p.T / 2 + 8) * XYZZ29_BYTES))) return rc;
@@ -46,35 +49,32 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size
     uint32_t *heavy_count = reinterpret_cast<uint32_t *>(g.heavy.p);          // [0] runs, [1] sub-jobs, [2..3] plan
     U4 *heavy_runs = reinterpret_cast<U4 *>(heavy_count + 16);
     U4 *heavy_subs = heavy_runs + ((size_t)p.T / 4 + 4);
+    uint32_t *plan = heavy_count + 2;
+    uint32_t *no_u32 = nullptr;
 
+    // No clearing passes: k_digits zeroes the bucket counters, k_scan_c the heavy-run counters and the
+    // identity marker of every bucket without entries, every segment of k_accumulate writes its tail key.
     tm_begin();
-    RT_CHECK(rt_memset(g.counts.p, 0, ((size_t)p.NB + 1) * 4, st));
-    RT_CHECK(rt_memset(g.bucket_sums.p, 0, (size_t)p.NB * XYZZ29_BYTES, st));
-    RT_CHECK(rt_memset(g.head_key.p, 0xFF, (size_t)p.T * 4, st));
-    RT_CHECK(rt_memset(g.tail_key.p, 0xFF, (size_t)p.T * 4, st));
-    RT_CHECK(rt_memset(heavy_count, 0, 64, st));
-    tm_mark("memset");
-
     LAUNCH(k_digits<FS>, dim3(ceil_div(n, 256), p.count), 256, 0, st, reinterpret_cast<const unsigned char *>(d_scalars), (uint32_t)n, (uint64_t)p.stride, p.c, p.W,
-           reinterpret_cast<int16_t *>(g.digits.p));
+           reinterpret_cast<int16_t *>(g.digits.p), reinterpret_cast<uint32_t *>(g.counts.p), p.NB + 1);
     tm_mark("digits");
     LAUNCH_BARRIER_FLEX(k_hist, dim3(p.ntiles, p.Wt), 1024, (size_t)p.B * 4, st, reinterpret_cast<const int16_t *>(g.digits.p), (uint32_t)n,
                    p.B, p.tile, reinterpret_cast<uint32_t *>(g.counts.p));
     tm_mark("hist");
+    // coarse bin of the staged sort = top 8 bits of the bucket id (6..9 measured equal)
+    const uint32_t fine_bits = (p.c - 1) - std::min<uint32_t>(p.c - 1, 8);
+    const uint32_t CB = p.B >> fine_bits;                                       // <= 256 coarse bins per window
     LAUNCH_BARRIER(k_scan_a, scan_blocks, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.counts.p), p.NB,
                    reinterpret_cast<uint32_t *>(g.block_sums.p));
     LAUNCH_BARRIER(k_scan_b, 1, 1024, 0, st, reinterpret_cast<uint32_t *>(g.block_sums.p), scan_blocks);
     LAUNCH_BARRIER(k_scan_c, scan_blocks, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.counts.p), p.NB,
                    reinterpret_cast<const uint32_t *>(g.block_sums.p), reinterpret_cast<uint32_t *>(g.offsets.p),
-                   reinterpret_cast<uint32_t *>(g.cursor.p));
+                   reinterpret_cast<uint32_t *>(g.cursor.p), staged ? reinterpret_cast<uint32_t *>(g.coarse_offsets.p) : no_u32, fine_bits,
+                   plan, p.lanes, p.L, heavy_count, reinterpret_cast<unsigned char *>(g.bucket_sums.p));
     tm_mark("scan");
     // sort: LDS-staged two-level partition for large inputs (bursts of consecutive entries), the
     // single-level scatter otherwise (small inputs: the tile structure buys nothing there)
     if (staged) {
-        const uint32_t fine_bits = (p.c - 1) - std::min<uint32_t>(p.c - 1, 8);      // coarse bin = top 8 bits of the bucket id (6..9 measured equal)
-        const uint32_t CB = p.B >> fine_bits;                                       // <= 256 coarse bins per window
-        LAUNCH(k_stage_cursors, ceil_div((uint64_t)p.Wt * CB, 256), 256, 0, st, reinterpret_cast<const uint32_t *>(g.offsets.p), p.Wt * CB, fine_bits,
-               reinterpret_cast<uint32_t *>(g.coarse_offsets.p));
         LAUNCH_BARRIER((k_stage1<int16_t, false>), dim3(ceil_div(n, STAGE_TILE), p.Wt), 1024, (size_t)STAGE_TILE * 8, st, reinterpret_cast<const int16_t *>(g.digits.p),
                             (uint32_t)n, p.B, fine_bits, CB, 0u, 0u, reinterpret_cast<uint32_t *>(g.coarse_offsets.p), reinterpret_cast<U2 *>(g.part.p));
         tm_mark("sort_level1");
@@ -85,30 +85,39 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size
         LAUNCH_BARRIER_FLEX(k_scatter, dim3(p.ntiles, p.Wt), 1024, (size_t)p.B * 4, st, reinterpret_cast<const int16_t *>(g.digits.p),
                    (uint32_t)n, p.B, p.tile, reinterpret_cast<uint32_t *>(g.cursor.p), reinterpret_cast<uint32_t *>(g.sorted_idx.p));
     tm_mark("scatter");
-    const uint32_t *total_ptr = reinterpret_cast<const uint32_t *>(g.offsets.p) + p.NB;
-    uint32_t *plan = heavy_count + 2;
-    LAUNCH(k_plan, 1, 64, 0, st, total_ptr, p.lanes, p.L, plan);
     LAUNCH(k_accumulate<F>, ceil_div(p.T, 128), 128, 0, st, reinterpret_cast<const uint32_t *>(g.sorted_idx.p),
            reinterpret_cast<const uint32_t *>(g.offsets.p), p.NB, bases, (const uint32_t *)plan,
            reinterpret_cast<unsigned char *>(g.bucket_sums.p), reinterpret_cast<unsigned char *>(g.head_part.p),
-           reinterpret_cast<uint32_t *>(g.head_key.p), reinterpret_cast<unsigned char *>(g.tail_part.p),
-           reinterpret_cast<uint32_t *>(g.tail_key.p));
+           reinterpret_cast<unsigned char *>(g.tail_part.p), reinterpret_cast<uint32_t *>(g.tail_key.p));
     tm_mark("accumulate");
     const uint32_t fix_by_bucket = p.NB < p.T ? p.NB : 0u;   // fewer buckets than segments: index the fix-up by bucket
-    LAUNCH(k_fixup<F>, ceil_div(fix_by_bucket ? fix_by_bucket : p.T, 128), 128, 0, st, (const uint32_t *)plan, reinterpret_cast<const uint32_t *>(g.offsets.p),
+    LAUNCH(k_fixup<F>, ceil_div((uint64_t)(fix_by_bucket ? fix_by_bucket : p.T) * 4, 128), 128, 0, st, (const uint32_t *)plan, reinterpret_cast<const uint32_t *>(g.offsets.p),
            reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
            reinterpret_cast<const uint32_t *>(g.tail_key.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p), heavy_count, heavy_runs, heavy_subs, fix_by_bucket);
-    LAUNCH_BARRIER(k_fixup_heavy_a<F>, FIXUP_HEAVY_GRID, HEAVY_BLOCK, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_subs,
-                   reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<unsigned char *>(g.heavy_out.p));
+    LAUNCH_BARRIER(k_fixup_heavy_a<F>, FIXUP_HEAVY_GRID, HEAVY_BLOCK, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_subs, (const U4 *)heavy_runs,
+                   reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
+                   reinterpret_cast<unsigned char *>(g.heavy_out.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p));
     LAUNCH_BARRIER(k_fixup_heavy_b<F>, FIXUP_HEAVY_GRID, HEAVY_BLOCK, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_runs,
                    reinterpret_cast<const unsigned char *>(g.heavy_out.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
                    reinterpret_cast<unsigned char *>(g.bucket_sums.p));
     tm_mark("fixup");
-    LAUNCH(k_reduce_chunks<F>, ceil_div((uint64_t)p.Wt * p.nchunks, 64), 64, 0, st,
-           reinterpret_cast<const unsigned char *>(g.bucket_sums.p), p.B, p.m, p.Wt, reinterpret_cast<unsigned char *>(g.chunks.p));
-    tm_mark("reduce_chunks");
-    LAUNCH_BARRIER(k_window_sum<F>, p.Wt, WSUM_BLOCK, (size_t)WSUM_BLOCK * XYZZ29_BYTES, st, reinterpret_cast<const unsigned char *>(g.chunks.p), p.nchunks,
-                   reinterpret_cast<unsigned char *>(g.window_sums.p));
+    const uint64_t items = (uint64_t)p.Wt * p.nchunks;
+    if (reduce_with_quads(items)) {
+        const uint32_t rb = getenv("MIRA_DBG_RB") ? atoi(getenv("MIRA_DBG_RB")) : 64;
+        LAUNCH((k_reduce_chunks<F, true>), ceil_div(items * 4, rb), rb, 0, st, reinterpret_cast<const unsigned char *>(g.bucket_sums.p),
+               p.B, p.m, p.Wt, reinterpret_cast<unsigned char *>(g.chunks.p));
+        tm_mark("reduce_chunks");
+        LAUNCH_BARRIER((k_window_sum<F, true>), p.Wt, WSUM_BLOCK, (size_t)(WSUM_BLOCK / 4) * XYZZ29_BYTES, st, reinterpret_cast<const unsigned char *>(g.chunks.p), p.nchunks,
+                       reinterpret_cast<unsigned char *>(g.window_sums.p));
+    } else {
+        // 256-lane workgroups: with 64-lane ones the dispatcher was seen to pack the 1024 waves of a 2^22
+        // MSM onto part of the CUs (0.43 ms instead of 0.27)
+        LAUNCH((k_reduce_chunks<F, false>), ceil_div(items, 256), 256, 0, st, reinterpret_cast<const unsigned char *>(g.bucket_sums.p),
+               p.B, p.m, p.Wt, reinterpret_cast<unsigned char *>(g.chunks.p));
+        tm_mark("reduce_chunks");
+        LAUNCH_BARRIER((k_window_sum<F, false>), p.Wt, WSUM_BLOCK, (size_t)WSUM_BLOCK * XYZZ29_BYTES, st, reinterpret_cast<const unsigned char *>(g.chunks.p), p.nchunks,
+                       reinterpret_cast<unsigned char *>(g.window_sums.p));
+    }
     tm_mark("window_sum");
     RT_CHECK(rt_last());
     RT_CHECK(rt_d2h(host_windows, g.window_sums.p, (size_t)p.Wt * 128, st));
@@ -120,7 +129,7 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size
 
 template <class F, class FS> static int curve_init() {
 #ifndef MIRA_CPU_EMU
-    RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_sum<F>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_sum<F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     // the LDS-staged histogram needs more than the 64 KiB default (128 KiB at c = 16)
     RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -206,7 +215,6 @@ static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars
     if ((rc = g.bucket_sums.ensure((size_t)TABLE_B * XYZZ29_BYTES))) return rc;
     if ((rc = g.head_part.ensure((size_t)T * XYZZ29_BYTES))) return rc;
     if ((rc = g.tail_part.ensure((size_t)T * XYZZ29_BYTES))) return rc;
-    if ((rc = g.head_key.ensure((size_t)T * 4))) return rc;
     if ((rc = g.tail_key.ensure((size_t)T * 4))) return rc;
     if ((rc = g.heavy.ensure(64 + ((size_t)T / 2 + 8) * 32))) return rc;
     if ((rc = g.heavy_out.ensure(((size_t)T / 2 + 8) * XYZZ29_BYTES))) return rc;
@@ -221,11 +229,9 @@ static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars
     // level-1 tiles of 32k points: runs of ~64 entries per (workgroup, coarse bin)
     const uint32_t tile = 32768, ntiles = ceil_div(n, tile);
     tm_begin();
+    uint32_t *no_u32 = nullptr;
+    unsigned char *no_u8 = nullptr;
     RT_CHECK(rt_memset(g.counts.p, 0, ((size_t)TABLE_CB + 1) * 4, st));
-    RT_CHECK(rt_memset(g.bucket_sums.p, 0, (size_t)TABLE_B * XYZZ29_BYTES, st));
-    RT_CHECK(rt_memset(g.head_key.p, 0xFF, (size_t)T * 4, st));
-    RT_CHECK(rt_memset(g.tail_key.p, 0xFF, (size_t)T * 4, st));
-    RT_CHECK(rt_memset(heavy_count, 0, 64, st));
     tm_mark("memset");
     LAUNCH(k_digits32<FS>, ceil_div(n, 256), 256, 0, st, reinterpret_cast<const unsigned char *>(d_scalars), (uint32_t)n,
            reinterpret_cast<int32_t *>(g.digits.p));
@@ -237,7 +243,7 @@ static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars
     LAUNCH_BARRIER(k_scan_b, 1, 1024, 0, st, reinterpret_cast<uint32_t *>(g.block_sums.p), 1u);
     LAUNCH_BARRIER(k_scan_c, 1, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.counts.p), TABLE_CB,
                    reinterpret_cast<const uint32_t *>(g.block_sums.p), reinterpret_cast<uint32_t *>(g.coarse_offsets.p),
-                   reinterpret_cast<uint32_t *>(g.cursor.p));
+                   reinterpret_cast<uint32_t *>(g.cursor.p), no_u32, 0u, no_u32, 0u, 0u, no_u32, no_u8);
     tm_mark("scan");
     // level 1 by coarse bin (top 9 bits), bucket counts from its output, scan, level 2 by bucket
     const uint32_t *coarse_total = reinterpret_cast<const uint32_t *>(g.coarse_offsets.p) + TABLE_CB;
@@ -252,32 +258,31 @@ static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars
     LAUNCH_BARRIER(k_scan_a, fscan, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.fine_counts.p), TABLE_B, reinterpret_cast<uint32_t *>(g.block_sums.p));
     LAUNCH_BARRIER(k_scan_b, 1, 1024, 0, st, reinterpret_cast<uint32_t *>(g.block_sums.p), fscan);
     LAUNCH_BARRIER(k_scan_c, fscan, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.fine_counts.p), TABLE_B,
-                   reinterpret_cast<const uint32_t *>(g.block_sums.p), reinterpret_cast<uint32_t *>(g.offsets.p), reinterpret_cast<uint32_t *>(g.fine_cursor.p));
+                   reinterpret_cast<const uint32_t *>(g.block_sums.p), reinterpret_cast<uint32_t *>(g.offsets.p), reinterpret_cast<uint32_t *>(g.fine_cursor.p),
+                   no_u32, 0u, plan, lanes, Lmin, heavy_count, reinterpret_cast<unsigned char *>(g.bucket_sums.p));
     tm_mark("bucket_count_scan");
     LAUNCH_BARRIER(k_stage2, ceil_div(entries, STAGE_TILE), 1024, (size_t)STAGE_TILE * 6, st, reinterpret_cast<const U2 *>(g.part.p), coarse_total,
                         TABLE_FINE_BITS, reinterpret_cast<uint32_t *>(g.fine_cursor.p), reinterpret_cast<uint32_t *>(g.sorted_idx.p));
     tm_mark("sort_level2");
-    const uint32_t *total_ptr = reinterpret_cast<const uint32_t *>(g.offsets.p) + TABLE_B;
-    LAUNCH(k_plan, 1, 64, 0, st, total_ptr, lanes, Lmin, plan);
     LAUNCH(k_accumulate<F>, ceil_div(T, 128), 128, 0, st, reinterpret_cast<const uint32_t *>(g.sorted_idx.p),
            reinterpret_cast<const uint32_t *>(g.offsets.p), TABLE_B, reinterpret_cast<const unsigned char *>(bs.tables), (const uint32_t *)plan,
            reinterpret_cast<unsigned char *>(g.bucket_sums.p), reinterpret_cast<unsigned char *>(g.head_part.p),
-           reinterpret_cast<uint32_t *>(g.head_key.p), reinterpret_cast<unsigned char *>(g.tail_part.p),
-           reinterpret_cast<uint32_t *>(g.tail_key.p));
+           reinterpret_cast<unsigned char *>(g.tail_part.p), reinterpret_cast<uint32_t *>(g.tail_key.p));
     tm_mark("accumulate");
-    LAUNCH(k_fixup<F>, ceil_div(T, 128), 128, 0, st, (const uint32_t *)plan, reinterpret_cast<const uint32_t *>(g.offsets.p),
+    LAUNCH(k_fixup<F>, ceil_div((uint64_t)T * 4, 128), 128, 0, st, (const uint32_t *)plan, reinterpret_cast<const uint32_t *>(g.offsets.p),
            reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
            reinterpret_cast<const uint32_t *>(g.tail_key.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p), heavy_count, heavy_runs, heavy_subs, 0u);
-    LAUNCH_BARRIER(k_fixup_heavy_a<F>, FIXUP_HEAVY_GRID, HEAVY_BLOCK, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_subs,
-                   reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<unsigned char *>(g.heavy_out.p));
+    LAUNCH_BARRIER(k_fixup_heavy_a<F>, FIXUP_HEAVY_GRID, HEAVY_BLOCK, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_subs, (const U4 *)heavy_runs,
+                   reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
+                   reinterpret_cast<unsigned char *>(g.heavy_out.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p));
     LAUNCH_BARRIER(k_fixup_heavy_b<F>, FIXUP_HEAVY_GRID, HEAVY_BLOCK, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_runs,
                    reinterpret_cast<const unsigned char *>(g.heavy_out.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
                    reinterpret_cast<unsigned char *>(g.bucket_sums.p));
     tm_mark("fixup");
-    LAUNCH(k_reduce_chunks<F>, ceil_div(nchunks, 64), 64, 0, st, reinterpret_cast<const unsigned char *>(g.bucket_sums.p), TABLE_B, m, 1u,
-           reinterpret_cast<unsigned char *>(g.chunks.p));
+    LAUNCH((k_reduce_chunks<F, false>), ceil_div(nchunks, 256), 256, 0, st, reinterpret_cast<const unsigned char *>(g.bucket_sums.p),
+           TABLE_B, m, 1u, reinterpret_cast<unsigned char *>(g.chunks.p));
     tm_mark("reduce_chunks");
-    LAUNCH_BARRIER(k_window_sum<F>, TABLE_SUMS, WSUM_BLOCK, (size_t)WSUM_BLOCK * XYZZ29_BYTES, st,
+    LAUNCH_BARRIER((k_window_sum<F, false>), TABLE_SUMS, WSUM_BLOCK, (size_t)WSUM_BLOCK * XYZZ29_BYTES, st,
                    reinterpret_cast<const unsigned char *>(g.chunks.p), nchunks / TABLE_SUMS, reinterpret_cast<unsigned char *>(g.window_sums.p));
     tm_mark("window_sum");
     RT_CHECK(rt_last());

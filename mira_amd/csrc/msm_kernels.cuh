@@ -21,11 +21,11 @@
 #pragma once
 #include "curve.cuh"
 #include "curve29.cuh"
+#include "quad29.cuh"
 
 static constexpr uint32_t KEY_NONE = 0xFFFFFFFFu;
 static constexpr int HEAVY_SPAN = 6;        // chains longer than this go to k_fixup_heavy (a lane adds ~6.6 us per link)
-static constexpr int FIXUP_BLOCK = 256;
-static constexpr int WSUM_BLOCK = 512;       // k_window_sum: 512 lanes x 144 B = 72 KiB of LDS (1024 lanes would cap VGPRs at 128 and spill)
+static constexpr int WSUM_BLOCK = 512;       // k_window_sum: 128 quads
 
 // ------------------------------------------------------------------------------------------
 // Planning pre-pass: histogram of the bit lengths of the canonical scalars (hist[0] = zeros,
@@ -52,10 +52,12 @@ KERNEL void k_bitlen_hist(const unsigned char *__restrict__ scalars, uint32_t n,
 }
 
 // ------------------------------------------------------------------------------------------
+// (also clears the ncounts bucket counters the histogram that follows adds into: one launch less)
 template <class FS>
 KERNEL void k_digits(const unsigned char *__restrict__ scalars, uint32_t n, uint64_t stride, uint32_t c, uint32_t W,
-                     int16_t *__restrict__ digits) {
+                     int16_t *__restrict__ digits, uint32_t *__restrict__ counts, uint32_t ncounts) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t k = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; k < ncounts; k += gridDim.x * gridDim.y * blockDim.x) counts[k] = 0;
     if (i >= n) return;
     const uint32_t b = blockIdx.y;                       // MSM of the batch: its windows are b*W .. b*W + W-1
     scalars += (size_t)b * stride * 32;
@@ -127,9 +129,18 @@ KERNEL void k_scan_b(uint32_t *__restrict__ block_sums, uint32_t nblocks) {
     }
     if (threadIdx.x < nblocks) block_sums[threadIdx.x] = buf[threadIdx.x] - v;   // exclusive
 }
-// offsets[NB] = total number of sorted entries; cursor = copy of offsets for k_scatter
+// offsets[NB] = total number of sorted entries; cursor = copy of offsets for k_scatter.
+// Optional by-products (null = skip), each of which used to be a launch of its own:
+//   cursor1  coarse cursors of the staged sort, cursor1[g] = offsets[g << fine_bits]
+//   bucket_sums  the identity marker (ZZ = 0) of every bucket without entries: k_accumulate and the
+//            fix-up only write buckets that have some, and the bucket reduction reads them all
+//   plan     {L, T} of k_accumulate -- segment length chosen once the number of non-zero digits is
+//            known: exactly one segment per resident lane (every SIMD slot busy for the whole kernel
+//            and all lanes finishing together), never shorter than min_L -- and heavy_ctr cleared
 KERNEL void k_scan_c(const uint32_t *__restrict__ counts, uint32_t NB, const uint32_t *__restrict__ block_sums,
-                     uint32_t *__restrict__ offsets, uint32_t *__restrict__ cursor) {
+                     uint32_t *__restrict__ offsets, uint32_t *__restrict__ cursor, uint32_t *__restrict__ cursor1, uint32_t fine_bits,
+                     uint32_t *__restrict__ plan, uint32_t resident_lanes, uint32_t min_L, uint32_t *__restrict__ heavy_ctr,
+                     unsigned char *__restrict__ bucket_sums) {
     __shared__ uint32_t buf[SCAN_BLOCK];
     uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     uint32_t loc[SCAN_ITEMS], s = 0;
@@ -147,9 +158,26 @@ KERNEL void k_scan_c(const uint32_t *__restrict__ counts, uint32_t NB, const uin
     }
     uint32_t run = block_sums[blockIdx.x] + buf[threadIdx.x] - s;
     for (int k = 0; k < SCAN_ITEMS; k++) {
-        if (base + k < NB) { offsets[base + k] = run; cursor[base + k] = run; }
+        if (base + k < NB) {
+            offsets[base + k] = run; cursor[base + k] = run;
+            if (cursor1 && ((base + k) & ((1u << fine_bits) - 1u)) == 0) cursor1[(base + k) >> fine_bits] = run;
+            if (bucket_sums && loc[k] == 0) {
+                uint32_t *zz = reinterpret_cast<uint32_t *>(bucket_sums + (size_t)(base + k) * XYZZ29_BYTES) + 18;
+#pragma unroll
+                for (int q = 0; q < 9; q++) zz[q] = 0;
+            }
+        }
         run += loc[k];
-        if (base + k == NB - 1) offsets[NB] = run;
+        if (base + k == NB - 1) {
+            offsets[NB] = run;
+            if (plan) {
+                uint32_t L = (uint32_t)(((uint64_t)run + resident_lanes - 1) / resident_lanes);
+                if (L < min_L) L = min_L;
+                plan[0] = L;
+                plan[1] = (uint32_t)(((uint64_t)run + L - 1) / L);
+                heavy_ctr[0] = 0; heavy_ctr[1] = 0;
+            }
+        }
     }
 }
 
@@ -232,18 +260,6 @@ KERNEL void k_check_on_curve(const unsigned char *__restrict__ bases, uint64_t n
 }
 
 // ------------------------------------------------------------------------------------------
-// Segment length for k_accumulate, chosen on the device once the number of non-zero digits is
-// known: exactly one segment per resident lane (every SIMD slot busy for the whole kernel and all
-// lanes finishing together), never shorter than min_L.  plan = {L, T}.
-KERNEL void k_plan(const uint32_t *__restrict__ total_ptr, uint32_t resident_lanes, uint32_t min_L, uint32_t *__restrict__ plan) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    const uint32_t total = *total_ptr;
-    uint32_t L = (uint32_t)(((uint64_t)total + resident_lanes - 1) / resident_lanes);
-    if (L < min_L) L = min_L;
-    plan[0] = L;
-    plan[1] = (uint32_t)(((uint64_t)total + L - 1) / L);
-}
-
 // largest b in [lo, NB) with offsets[b] <= pos  (offsets non-decreasing, offsets[NB] = total > pos)
 DEV uint32_t bucket_of(const uint32_t *__restrict__ offsets, uint32_t lo, uint32_t NB, uint32_t pos) {
     uint32_t hi = NB;           // invariant: offsets[lo] <= pos < offsets[hi]
@@ -258,8 +274,7 @@ template <class F>
 KERNEL void __launch_bounds__(128) k_accumulate(const uint32_t *__restrict__ sorted, const uint32_t *__restrict__ offsets, uint32_t NB,
                          const unsigned char *__restrict__ bases,
                          const uint32_t *__restrict__ plan, unsigned char *__restrict__ bucket_sums,
-                         unsigned char *__restrict__ head_part, uint32_t *__restrict__ head_key,
-                         unsigned char *__restrict__ tail_part, uint32_t *__restrict__ tail_key) {
+                         unsigned char *__restrict__ head_part, unsigned char *__restrict__ tail_part, uint32_t *__restrict__ tail_key) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total = offsets[NB];
     const uint32_t L = plan[0];
@@ -293,7 +308,7 @@ KERNEL void __launch_bounds__(128) k_accumulate(const uint32_t *__restrict__ sor
         ent0 = ent1;
         if (j + 2 < end) ent1 = sorted[j + 2];
         if (j == run_end) {                                  // the run of `cur` is complete
-            if (first && cont_prev) { xyzz29_store(head_part + (size_t)t * XYZZ29_BYTES, acc); head_key[t] = cur; }
+            if (first && cont_prev) xyzz29_store(head_part + (size_t)t * XYZZ29_BYTES, acc);
             else xyzz29_store(bucket_sums + (size_t)cur * XYZZ29_BYTES, acc);
             first = false;
             acc = xyzz29_identity<F>();
@@ -308,15 +323,22 @@ KERNEL void __launch_bounds__(128) k_accumulate(const uint32_t *__restrict__ sor
         xyzz29_add_affine(acc, aff29_from_raw<F>(c0, c1, c2, c3, (e >> 31) != 0));
     }
     const bool cont_next = end < run_end;                    // the run continues in the next lane
-    if (first && cont_prev) { xyzz29_store(head_part + (size_t)t * XYZZ29_BYTES, acc); head_key[t] = cur; }
-    else if (cont_next) { xyzz29_store(tail_part + (size_t)t * XYZZ29_BYTES, acc); tail_key[t] = cur; }
+    const bool is_head = first && cont_prev;
+    if (is_head) xyzz29_store(head_part + (size_t)t * XYZZ29_BYTES, acc);
+    else if (cont_next) xyzz29_store(tail_part + (size_t)t * XYZZ29_BYTES, acc);
     else xyzz29_store(bucket_sums + (size_t)cur * XYZZ29_BYTES, acc);
+    tail_key[t] = (!is_head && cont_next) ? cur : KEY_NONE;   // every segment of the plan writes its key: no clearing pass
 }
 
-// One lane per k_accumulate lane that owns the start of a cut run.  Short chains are summed here;
-// a chain longer than HEAVY_SPAN partials (a heavy bucket: the carry bucket of small witness
-// values, a column of ones, the sparse top window) is cut into sub-jobs of HEAVY_SUB partials for
-// the two workgroup-parallel kernels below, so its cost is two LDS trees whatever its length.
+// The tail kernels below are chains of dependent general additions on few waves.  Every work item
+// is owned by a QUAD of lanes (quad29.cuh): the four lanes load the same operands and share the
+// multiplications of each addition, which cuts the latency of a link from ~6.8 us to ~2 us.
+DEV uint32_t quad_gid() { return (blockIdx.x * blockDim.x + threadIdx.x) >> 2; }
+
+// One quad per cut run.  Short chains are summed here; a chain longer than HEAVY_SPAN partials (a
+// heavy bucket: the carry bucket of small witness values, a column of ones, the sparse top window)
+// is cut into sub-jobs of HEAVY_SUB partials for the two workgroup-parallel kernels below, so its
+// cost is two LDS trees whatever its length.
 // heavy_ctr = {runs, sub-jobs}; runs[h] = {lane, span, bucket, first sub-job}; subs[s] = {first
 // partial, count, run, -}.
 static constexpr uint32_t HEAVY_SUB = 256;
@@ -325,9 +347,9 @@ KERNEL void __launch_bounds__(128) k_fixup(const uint32_t *__restrict__ plan, co
                     const unsigned char *__restrict__ head_part, const unsigned char *__restrict__ tail_part,
                     const uint32_t *__restrict__ tail_key, unsigned char *__restrict__ bucket_sums,
                     uint32_t *__restrict__ heavy_ctr, U4 *__restrict__ runs, U4 *__restrict__ subs, uint32_t num_buckets) {
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t gid = quad_gid();
     const uint32_t L = plan[0], T = plan[1];
-    // One lane per cut run.  Indexed by segment (the lane that holds the run's tail partial) when
+    // One quad per cut run.  Indexed by segment (the lane that holds the run's tail partial) when
     // segments are fewer than buckets; by bucket (num_buckets != 0) when buckets are fewer -- small
     // MSMs, where every bucket is cut several times and only one segment in four holds a tail.
     uint32_t t, key, run_end;
@@ -348,6 +370,7 @@ KERNEL void __launch_bounds__(128) k_fixup(const uint32_t *__restrict__ plan, co
     }
     const uint32_t span = (run_end - 1) / L - t;   // lanes t+1 .. t+span hold head partials of this run
     if (span > (uint32_t)HEAVY_SPAN) {
+        if (quad_lane() != 0) return;
         const uint32_t nsub = (span + HEAVY_SUB - 1) / HEAVY_SUB;
         const uint32_t h = atomicAdd(&heavy_ctr[0], 1u);
         const uint32_t base = atomicAdd(&heavy_ctr[1], nsub);
@@ -360,108 +383,138 @@ KERNEL void __launch_bounds__(128) k_fixup(const uint32_t *__restrict__ plan, co
         return;
     }
     Xyzz29<F> acc = xyzz29_load<F>(tail_part + (size_t)t * XYZZ29_BYTES);
-    for (uint32_t q = 1; q <= span; q++) xyzz29_add(acc, xyzz29_load<F>(head_part + (size_t)(t + q) * XYZZ29_BYTES));
-    xyzz29_store(bucket_sums + (size_t)key * XYZZ29_BYTES, acc);
+    for (uint32_t q = 1; q <= span; q++) xyzz29_add_quad(acc, xyzz29_load<F>(head_part + (size_t)(t + q) * XYZZ29_BYTES));
+    if (quad_lane() == 0) xyzz29_store(bucket_sums + (size_t)key * XYZZ29_BYTES, acc);
 }
 
-// LDS tree over the first `cnt` lanes' values (cnt <= blockDim.x = HEAVY_BLOCK); result in lane 0
-static constexpr uint32_t HEAVY_BLOCK = 64;      // one wave per sub-job: most heavy chains are 7..64 partials long
-template <class F> DEV void block_tree_sum(Xyzz29<F> &acc, unsigned char *red, uint32_t cnt) {
-    xyzz29_store(red + threadIdx.x * XYZZ29_BYTES, acc);
+// LDS tree over the values of the first `cnt` quads of the workgroup (cnt <= blockDim.x / 4);
+// result in quad 0.  red: blockDim.x / 4 entries of XYZZ29_BYTES.
+template <class F> DEV void block_tree_sum_quad(Xyzz29<F> &acc, unsigned char *red, uint32_t cnt) {
+    const uint32_t qi = threadIdx.x >> 2;
+    if (quad_lane() == 0) xyzz29_store(red + qi * XYZZ29_BYTES, acc);
     __syncthreads();
     uint32_t width = 1;
     while (width < cnt) width <<= 1;
     for (uint32_t st = width >> 1; st > 0; st >>= 1) {
-        if (threadIdx.x < st && threadIdx.x + st < cnt) {
-            xyzz29_add(acc, xyzz29_load<F>(red + (threadIdx.x + st) * XYZZ29_BYTES));
-            xyzz29_store(red + threadIdx.x * XYZZ29_BYTES, acc);
+        if (qi < st && qi + st < cnt) {
+            xyzz29_add_quad(acc, xyzz29_load<F>(red + (qi + st) * XYZZ29_BYTES));
+            if (quad_lane() == 0) xyzz29_store(red + qi * XYZZ29_BYTES, acc);
         }
         __syncthreads();
     }
 }
-// stage A: one wave per sub-job (grid-stride): sub_out[s] = sum of its <= 256 head partials
-// (each lane first adds up to 4 of them, then a 6-level LDS tree)
+// stage A: one workgroup of 64 quads per sub-job (grid-stride): sub_out[s] = sum of its <= 256 head
+// partials (each quad first adds up to 4 of them, then a 6-level LDS tree)
+static constexpr uint32_t HEAVY_BLOCK = 256;
+// A run that is one sub-job (<= HEAVY_SUB partials: the usual case) is finished here -- tail partial
+// added, bucket written -- and stage B skips it.
 template <class F>
-KERNEL void __launch_bounds__(64) k_fixup_heavy_a(const uint32_t *__restrict__ heavy_ctr, const U4 *__restrict__ subs,
-                          const unsigned char *__restrict__ head_part, unsigned char *__restrict__ sub_out) {
-    __shared__ __attribute__((aligned(16))) unsigned char red[HEAVY_BLOCK * XYZZ29_BYTES];
-    const uint32_t nsubs = heavy_ctr[1];
+KERNEL void __launch_bounds__(256) k_fixup_heavy_a(const uint32_t *__restrict__ heavy_ctr, const U4 *__restrict__ subs, const U4 *__restrict__ runs,
+                          const unsigned char *__restrict__ head_part, const unsigned char *__restrict__ tail_part,
+                          unsigned char *__restrict__ sub_out, unsigned char *__restrict__ bucket_sums) {
+    __shared__ __attribute__((aligned(16))) unsigned char red[(HEAVY_BLOCK / 4) * XYZZ29_BYTES];
+    const uint32_t nsubs = heavy_ctr[1], qi = threadIdx.x >> 2, nq = blockDim.x >> 2;
     for (uint32_t s = blockIdx.x; s < nsubs; s += gridDim.x) {
         const U4 d = subs[s];
         Xyzz29<F> acc = xyzz29_identity<F>();
-        for (uint32_t q = threadIdx.x; q < d.y; q += blockDim.x)
-            xyzz29_add(acc, xyzz29_load<F>(head_part + (size_t)(d.x + q) * XYZZ29_BYTES));
-        block_tree_sum(acc, red, d.y < blockDim.x ? d.y : blockDim.x);
-        if (threadIdx.x == 0) xyzz29_store(sub_out + (size_t)s * XYZZ29_BYTES, acc);
+        for (uint32_t q = qi; q < d.y; q += nq)
+            xyzz29_add_quad(acc, xyzz29_load<F>(head_part + (size_t)(d.x + q) * XYZZ29_BYTES));
+        block_tree_sum_quad(acc, red, d.y < nq ? d.y : nq);
+        if (qi == 0) {
+            const U4 r = runs[d.z];                                // {lane, span, bucket, first sub-job}
+            if (r.y <= HEAVY_SUB) {
+                xyzz29_add_quad(acc, xyzz29_load<F>(tail_part + (size_t)r.x * XYZZ29_BYTES));
+                if (threadIdx.x == 0) xyzz29_store(bucket_sums + (size_t)r.z * XYZZ29_BYTES, acc);
+            } else if (threadIdx.x == 0) {
+                xyzz29_store(sub_out + (size_t)s * XYZZ29_BYTES, acc);
+            }
+        }
         __syncthreads();
     }
 }
-// stage B: one wave per heavy run: bucket = tail partial + sum of its sub-job results
+// stage B: one workgroup per heavy run: bucket = tail partial + sum of its sub-job results
 template <class F>
-KERNEL void __launch_bounds__(64) k_fixup_heavy_b(const uint32_t *__restrict__ heavy_ctr, const U4 *__restrict__ runs,
+KERNEL void __launch_bounds__(256) k_fixup_heavy_b(const uint32_t *__restrict__ heavy_ctr, const U4 *__restrict__ runs,
                           const unsigned char *__restrict__ sub_out, const unsigned char *__restrict__ tail_part,
                           unsigned char *__restrict__ bucket_sums) {
-    __shared__ __attribute__((aligned(16))) unsigned char red[HEAVY_BLOCK * XYZZ29_BYTES];
-    const uint32_t nruns = heavy_ctr[0];
+    __shared__ __attribute__((aligned(16))) unsigned char red[(HEAVY_BLOCK / 4) * XYZZ29_BYTES];
+    const uint32_t nruns = heavy_ctr[0], qi = threadIdx.x >> 2, nq = blockDim.x >> 2;
     for (uint32_t h = blockIdx.x; h < nruns; h += gridDim.x) {
         const U4 r = runs[h];                                      // {lane, span, bucket, first sub-job}
         const uint32_t nsub = (r.y + HEAVY_SUB - 1) / HEAVY_SUB;
+        if (nsub == 1) continue;                                   // finished by stage A
         Xyzz29<F> acc = xyzz29_identity<F>();
-        for (uint32_t q = threadIdx.x; q < nsub; q += blockDim.x)
-            xyzz29_add(acc, xyzz29_load<F>(sub_out + (size_t)(r.w + q) * XYZZ29_BYTES));
-        if (threadIdx.x == 0) xyzz29_add(acc, xyzz29_load<F>(tail_part + (size_t)r.x * XYZZ29_BYTES));
-        block_tree_sum(acc, red, nsub < blockDim.x ? nsub : blockDim.x);
+        for (uint32_t q = qi; q < nsub; q += nq)
+            xyzz29_add_quad(acc, xyzz29_load<F>(sub_out + (size_t)(r.w + q) * XYZZ29_BYTES));
+        if (qi == 0) xyzz29_add_quad(acc, xyzz29_load<F>(tail_part + (size_t)r.x * XYZZ29_BYTES));
+        block_tree_sum_quad(acc, red, nsub < nq ? nsub : nq);
         if (threadIdx.x == 0) xyzz29_store(bucket_sums + (size_t)r.z * XYZZ29_BYTES, acc);
         __syncthreads();
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// Lane (w, j) folds buckets [j*m, (j+1)*m) of window w:
+// Bucket reduction.  QUAD = true: every work item is a quad of lanes (latency-bound sizes: few
+// buckets, the chain of dependent additions is what takes the time); QUAD = false: one lane per work
+// item (2^19 buckets at c = 16: throughput-bound, four times fewer lanes do the same work).
+template <bool QUAD, class F> DEV void xyzz29_add_sel(Xyzz29<F> &acc, const Xyzz29<F> &q) {
+    if constexpr (QUAD) xyzz29_add_quad(acc, q); else xyzz29_add(acc, q);
+}
+template <bool QUAD, class F> DEV Xyzz29<F> xyzz29_double_sel(const Xyzz29<F> &p) {
+    if constexpr (QUAD) return xyzz29_double_quad(p); else return xyzz29_double(p);
+}
+// Work item (w, j) folds buckets [j*m, (j+1)*m) of window w:
 //   R[w][j] = sum_i (j*m + i + 1) * S[w][j*m + i]
-template <class F>
-KERNEL void __launch_bounds__(64) k_reduce_chunks(const unsigned char *__restrict__ bucket_sums, uint32_t B, uint32_t m, uint32_t W,
+template <class F, bool QUAD>
+KERNEL void __launch_bounds__(256) k_reduce_chunks(const unsigned char *__restrict__ bucket_sums, uint32_t B, uint32_t m, uint32_t W,
                             unsigned char *__restrict__ R) {
     const uint32_t nchunks = B / m;
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t g = QUAD ? quad_gid() : blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nchunks * W) return;
     const uint32_t w = g / nchunks, j = g % nchunks;
-    const unsigned char *S = bucket_sums + ((size_t)w * B + (size_t)j * m) * XYZZ29_BYTES;
+    const size_t b0 = (size_t)w * B + (size_t)j * m;
+    const unsigned char *S = bucket_sums + b0 * XYZZ29_BYTES;
     Xyzz29<F> running = xyzz29_identity<F>(), ws = xyzz29_identity<F>();
     for (int i = (int)m - 1; i >= 0; i--) {
-        xyzz29_add(running, xyzz29_load<F>(S + (size_t)i * XYZZ29_BYTES));
-        xyzz29_add(ws, running);
+        xyzz29_add_sel<QUAD>(running, xyzz29_load<F>(S + (size_t)i * XYZZ29_BYTES));
+        xyzz29_add_sel<QUAD>(ws, running);
     }
     // + (j*m) * running, MSB-first double-and-add on the (<= 15-bit) chunk offset
     const uint32_t k = j * m;
     if (k != 0 && !xyzz29_is_identity(running)) {
         Xyzz29<F> acc = xyzz29_identity<F>();
         for (int bit = 31 - __builtin_clz(k); bit >= 0; bit--) {
-            acc = xyzz29_double(acc);
-            if ((k >> bit) & 1) xyzz29_add(acc, running);
+            acc = xyzz29_double_sel<QUAD>(acc);
+            if ((k >> bit) & 1) xyzz29_add_sel<QUAD>(acc, running);
         }
-        xyzz29_add(ws, acc);
+        xyzz29_add_sel<QUAD>(ws, acc);
     }
-    xyzz29_store(R + (size_t)g * XYZZ29_BYTES, ws);
+    if (!QUAD || quad_lane() == 0) xyzz29_store(R + (size_t)g * XYZZ29_BYTES, ws);
 }
 
 // Workgroup per window: window_sums[w] = sum_j R[w][j], exported as X, Y, ZZ, ZZZ in the
-// reference's canonical R = 2^256 form (128 B) for the host epilogue.  blockDim.x == WSUM_BLOCK.
-template <class F>
+// reference's canonical R = 2^256 form (128 B) for the host epilogue.  blockDim.x == WSUM_BLOCK:
+// 128 quads, or 512 single lanes (72 KiB of LDS).
+template <class F, bool QUAD>
 KERNEL void __launch_bounds__(512) k_window_sum(const unsigned char *__restrict__ R, uint32_t nchunks, unsigned char *__restrict__ window_sums) {
     DYN_SHARED(unsigned char, red);
     const uint32_t w = blockIdx.x;
+    const uint32_t qi = QUAD ? threadIdx.x >> 2 : threadIdx.x, nq = QUAD ? blockDim.x >> 2 : blockDim.x;
     Xyzz29<F> acc = xyzz29_identity<F>();
-    for (uint32_t q = threadIdx.x; q < nchunks; q += blockDim.x)
-        xyzz29_add(acc, xyzz29_load<F>(R + ((size_t)w * nchunks + q) * XYZZ29_BYTES));
-    xyzz29_store(red + threadIdx.x * XYZZ29_BYTES, acc);
-    __syncthreads();
-    for (uint32_t st = WSUM_BLOCK / 2; st > 0; st >>= 1) {
-        if (threadIdx.x < st && threadIdx.x + st < nchunks) {      // lanes beyond nchunks hold the identity
-            xyzz29_add(acc, xyzz29_load<F>(red + (threadIdx.x + st) * XYZZ29_BYTES));
-            xyzz29_store(red + threadIdx.x * XYZZ29_BYTES, acc);
-        }
+    for (uint32_t q = qi; q < nchunks; q += nq)
+        xyzz29_add_sel<QUAD>(acc, xyzz29_load<F>(R + ((size_t)w * nchunks + q) * XYZZ29_BYTES));
+    if constexpr (QUAD) {
+        block_tree_sum_quad(acc, red, nchunks < nq ? nchunks : nq);
+    } else {
+        xyzz29_store(red + threadIdx.x * XYZZ29_BYTES, acc);
         __syncthreads();
+        for (uint32_t st = WSUM_BLOCK / 2; st > 0; st >>= 1) {
+            if (threadIdx.x < st && threadIdx.x + st < nchunks) {      // lanes beyond nchunks hold the identity
+                xyzz29_add(acc, xyzz29_load<F>(red + (threadIdx.x + st) * XYZZ29_BYTES));
+                xyzz29_store(red + threadIdx.x * XYZZ29_BYTES, acc);
+            }
+            __syncthreads();
+        }
     }
     if (threadIdx.x == 0) xyzz29_export_r256(window_sums + (size_t)w * 128, acc);
 }

@@ -24,6 +24,12 @@
 // lanes of one wave exchange data through LDS without a workgroup barrier: the DS unit serves a
 // wave's instructions in order; the fence keeps the compiler from moving LDS accesses across it
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+// DPP quads (quad29.cuh): lanes 4 i .. 4 i + 3 of a wave; quad_bcast<K> = every lane reads lane K of its quad
+static constexpr bool QUAD_COOPERATIVE = true;
+static __device__ __forceinline__ uint32_t quad_lane() { return threadIdx.x & 3u; }
+template <int K> static __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, K * 0x55, 0xF, 0xF, true);   // quad_perm:[K,K,K,K]
+}
 #define DYN_SHARED(type, name) extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw[]; type *name = reinterpret_cast<type *>(name##_raw)
 #else
 #include "../../tests/emu/emu.h"

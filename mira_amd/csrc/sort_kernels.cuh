@@ -40,11 +40,7 @@ DEV void block_excl_scan(const uint32_t *cnt, uint32_t *ofs, uint32_t *tmp /* bl
     __syncthreads();
 }
 
-// init coarse cursors from the bucket offsets: cursor1[g] = offsets[g << fine_bits]
-KERNEL void k_stage_cursors(const uint32_t *__restrict__ offsets, uint32_t ncoarse, uint32_t fine_bits, uint32_t *__restrict__ cursor1) {
-    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < ncoarse) cursor1[g] = offsets[(size_t)g << fine_bits];
-}
+// (the coarse cursors, cursor1[g] = offsets[g << fine_bits], are a by-product of k_scan_c)
 
 // level 1.  grid = (ntiles, W_total); digits int16 window-major; B buckets per window, CB = B >> fine_bits
 // coarse bins per window (<= STAGE_MAX_BINS1).  part entries: x = index | sign << 31, y = w * B + bucket.

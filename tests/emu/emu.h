@@ -42,6 +42,12 @@ inline unsigned __brev(unsigned x) {
     return r;
 }
 
+// quad29.cuh: emulated lanes are not in lockstep, so a lane cannot read its neighbours' registers;
+// every lane computes all four products of a quad step itself (same values: the four lanes of a
+// quad hold identical operands by contract)
+static constexpr bool QUAD_COOPERATIVE = false;
+inline unsigned quad_lane() { return threadIdx.x & 3u; }
+template <int K> inline uint32_t quad_bcast(uint32_t v) { return v; }
 #define DYN_SHARED(type, name) type *name = reinterpret_cast<type *>(emu_dyn_shared)
 
 typedef void *hipStream_t;

@@ -108,12 +108,14 @@ int mira_msm_set_window_bits(int32_t c);
  * handle's window tables, the smallest commit whose scalar-length statistics plan the next one, and
  * the longest NTT line (log2) -- shorter lines make the two- and three-pass schedules reachable at
  * small sizes -- and whether lines of up to 256 points take the wave-level kernel (1, default) or
- * the workgroup-level one (0).  value < 0 restores the default. */
+ * the workgroup-level one (0); the smallest commit of HOST scalars that is cut into point chunks so
+ * that the copy of one chunk overlaps the kernels of the previous one.  value < 0 restores the default. */
 #define MIRA_TUNE_STAGED_MIN_N 0
 #define MIRA_TUNE_TABLE_MIN_N 1
 #define MIRA_TUNE_PLAN_HIST_MIN_N 2
 #define MIRA_TUNE_NTT_MAX_LOG_LINE 3
 #define MIRA_TUNE_NTT_WAVE 4
+#define MIRA_TUNE_HOST_CHUNK_MIN_N 5
 int mira_set_tuning(int knob, int64_t value);
 
 /* Read a range of the registered key back in the reference layout (cache file writing,

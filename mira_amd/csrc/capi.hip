@@ -55,7 +55,7 @@ void tm_begin() {
 #ifndef MIRA_CPU_EMU
     if (g.tm.enabled) {
         if (g.tm.ev.empty()) {
-            g.tm.ev.resize(32);
+            g.tm.ev.resize(128);
             for (auto &e : g.tm.ev) hipEventCreate(&e);
         }
         hipEventRecord(g.tm.ev[0], g.stream);
@@ -122,7 +122,7 @@ static int upload_consts() {
 //                 5 800 buckets per microsecond
 // bitlen_hist: lengths of the actual scalars, summed over the batch; null = uniform field elements.
 static double plan_cost_us(uint32_t c, double n, uint32_t count, const uint32_t *bitlen_hist) {
-    static const double base_us[17] = {0, 0, 0, 0, 309, 328, 393, 409, 464, 497, 518, 551, 563, 664, 753, 797, 895};
+    static const double base_us[17] = {0, 0, 0, 0, 248, 260, 296, 312, 364, 381, 393, 444, 469, 540, 584, 911, 908};   // tools/plan_calibrate.py, n = 64
     const double W = std::ceil(256.0 / c), B = (double)(1u << (c - 1));
     double h[256] = {0};                                     // scalars per length, per MSM
     if (bitlen_hist) {
@@ -131,13 +131,15 @@ static double plan_cost_us(uint32_t c, double n, uint32_t count, const uint32_t 
         h[254] = 0.339 * n;
         for (int len = 253; len > 200; len--) h[len] = 0.661 * n * std::exp2((double)len - 254.0);
     }
-    double adds = 0, load = 0;
+    double adds = 0, load = 0, nonzero = 0;
     for (uint32_t len = 1; len < 256; len++) {
         if (h[len] == 0) continue;
+        nonzero += h[len];
         adds += h[len] * std::ceil((double)len / c);
         load = std::max(load, h[len] / std::exp2((double)((len - 1) % c)));
         if (len % c == 0) load = std::max(load, h[len]);
     }
+    load = std::max(load, nonzero / B);                      // narrow windows: every bucket of the low windows is that long
     const double total_adds = adds * count;
     const double acc = std::max(0.0, total_adds / 12000.0 - 240.0);
     const double seg = std::max(16.0, total_adds / (256.0 * 4 * 3 * 64));
@@ -148,9 +150,10 @@ static double plan_cost_us(uint32_t c, double n, uint32_t count, const uint32_t 
 
 static MsmPlan make_plan(size_t n, int32_t forced_c, uint32_t count = 1, uint64_t stride = 0, const uint32_t *bitlen_hist = nullptr) {
     MsmPlan p;
-    // Candidate widths: narrow ones for latency-bound sizes, 13 / 15 / 16 beyond.  12 and 14 leave
-    // full-length scalars a two-bit top window and never win; 6..11 were not worth calibrating.
-    static const uint32_t candidates[] = {4, 5, 13, 15, 16};
+    // Candidate widths: narrow ones for latency-bound sizes, 12 / 13 around 2^17 .. 2^19, 15 / 16
+    // beyond (tools/plan_calibrate.py).  7, 8, 10, 11 and 14 never won a size; 11 leaves full-length
+    // scalars a one-bit top window (one bucket holding every point).
+    static const uint32_t candidates[] = {4, 5, 6, 9, 12, 13, 15, 16};
     uint32_t best_c = 13;
     double best = 1e300;
     for (uint32_t c : candidates) {
@@ -210,7 +213,7 @@ static void sum_partials(const uint64_t *partials, size_t nparts, uint32_t W, ui
 // kind of partial, so the choice between table and per-window mode then depends only on whether
 // the handle has tables (and on the forced width), never on this rank's chunk length.
 static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scalars, size_t n, uint64_t *out_partial,
-                              uint32_t *c_out, uint32_t *W_out, bool sharded = false, int32_t requested_c = 0) {
+                              uint32_t *c_out, uint32_t *W_out, bool sharded = false, int32_t requested_c = 0, const void *h_scalars = nullptr) {
     int rc = ensure_ctx();
     if (rc) return rc;
     auto it = g_bases.find(handle);
@@ -241,15 +244,13 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
     if (!d_scalars) { set_error("null scalars"); return MIRA_E_BAD_ARG; }
     // fixed-base mode: window tables present, MSM large enough to be throughput-bound, no forced width
     if (table_mode) {
+        if (h_scalars) RT_CHECK(rt_h2d(const_cast<void *>(d_scalars), h_scalars, n * 32, g.stream));
         *c_out = 0; *W_out = 64;                            // 64 partial sums, combined by a plain sum
         return bs.curve == MIRA_CURVE_BN256 ? msm_launch_table_bn256(bs, first, d_scalars, n, out_partial)
                                              : msm_launch_table_grumpkin(bs, first, d_scalars, n, out_partial);
     }
-    if (use_hist) {
-        int rc2 = bs.curve == MIRA_CURVE_BN256 ? scalar_bitlen_hist_bn256(d_scalars, n, 1, n) : scalar_bitlen_hist_grumpkin(d_scalars, n, 1, n);
-        if (rc2) return rc2;
-    }
-    rc = bs.curve == MIRA_CURVE_BN256 ? msm_launch_bn256(bs, first, d_scalars, n, p, out_partial) : msm_launch_grumpkin(bs, first, d_scalars, n, p, out_partial);
+    p.stats = use_hist;
+    rc = bs.curve == MIRA_CURVE_BN256 ? msm_launch_bn256(bs, first, d_scalars, h_scalars, n, p, out_partial) : msm_launch_grumpkin(bs, first, d_scalars, h_scalars, n, p, out_partial);
     if (rc == MIRA_OK && use_hist) {                         // msm_launch ends with a stream synchronisation
         memcpy(bs.stat_hist, g.hist_host, sizeof bs.stat_hist);
         bs.stat_n = n;
@@ -292,7 +293,7 @@ static int msm_batch_device_locked(uint64_t handle, const void *d_scalars, size_
         MsmPlan p = make_plan(n, g.forced_c, (uint32_t)cnt, stride);
         win.assign((size_t)p.Wt * 16, 0);
         const unsigned char *sc = reinterpret_cast<const unsigned char *>(d_scalars) + done * stride * 32;
-        rc = bs.curve == MIRA_CURVE_BN256 ? msm_launch_bn256(bs, 0, sc, n, p, win.data()) : msm_launch_grumpkin(bs, 0, sc, n, p, win.data());
+        rc = bs.curve == MIRA_CURVE_BN256 ? msm_launch_bn256(bs, 0, sc, nullptr, n, p, win.data()) : msm_launch_grumpkin(bs, 0, sc, nullptr, n, p, win.data());
         if (rc) return rc;
         for (size_t b = 0; b < cnt; b++) {
             const uint64_t *w = win.data() + b * p.W * 16;
@@ -451,11 +452,11 @@ int mira_msm_check_bases(uint64_t handle) {
     return MIRA_OK;
 }
 
-static int msm_device_locked(uint64_t handle, const void *d_scalars, size_t n, uint64_t out_affine[8]) {
+static int msm_device_locked(uint64_t handle, const void *d_scalars, size_t n, uint64_t out_affine[8], const void *h_scalars = nullptr) {
     if (!out_affine) { set_error("null output"); return MIRA_E_BAD_ARG; }
     uint64_t part[MIRA_PARTIAL_U64];
     uint32_t c, W;
-    int rc = msm_partial_locked(handle, 0, d_scalars, n, part, &c, &W);
+    int rc = msm_partial_locked(handle, 0, d_scalars, n, part, &c, &W, false, 0, h_scalars);
     if (rc) return rc;
     return combine_locked(g_bases[handle].curve, part, 1, c, W, out_affine);
 }
@@ -474,11 +475,9 @@ int mira_msm(uint64_t handle, const uint64_t *scalars, size_t n, uint64_t out_af
         set_error("Can't commit too long input: input len: " + std::to_string(n) + ", but limit is " + std::to_string(it->second.n));
         return MIRA_E_TOO_LONG;
     }
-    if (n) {
-        if ((rc = g.scalars_stage.ensure(n * 32))) return rc;
-        RT_CHECK(rt_h2d(g.scalars_stage.p, scalars, n * 32, g.stream));
-    }
-    return msm_device_locked(handle, g.scalars_stage.p, n, out_affine);
+    // the scalars cross PCIe inside the launch sequence, chunk by chunk beside the kernels (msm_host.cuh)
+    if (n && (rc = g.scalars_stage.ensure(n * 32))) return rc;
+    return msm_device_locked(handle, g.scalars_stage.p, n, out_affine, n ? scalars : nullptr);
 }
 int mira_msm_batch_device(uint64_t handle, const void *d_scalars, size_t n, size_t count, size_t stride_elems, uint64_t *out_affine) {
     std::lock_guard<std::mutex> lk(g_lock);
@@ -520,7 +519,7 @@ int mira_msm_combine(int curve, const uint64_t *partials, size_t nparts, int32_t
 }
 int mira_set_tuning(int knob, int64_t value) {
     std::lock_guard<std::mutex> lk(g_lock);
-    if (knob < 0 || knob > MIRA_TUNE_NTT_WAVE) { set_error("unknown tuning knob"); return MIRA_E_BAD_ARG; }
+    if (knob < 0 || knob > MIRA_TUNE_HOST_CHUNK_MIN_N) { set_error("unknown tuning knob"); return MIRA_E_BAD_ARG; }
     g.tune[knob] = value;
     return MIRA_OK;
 }

@@ -32,7 +32,14 @@ static inline hipError_t rt_d2d(void *d, const void *s_, size_t n, hipStream_t s
 static inline hipError_t rt_sync(hipStream_t s) { return hipStreamSynchronize(s); }
 static inline hipError_t rt_last() { return hipGetLastError(); }
 static inline hipError_t rt_host_alloc(void **p, size_t n) { return hipHostMalloc(p, n, hipHostMallocDefault); }
+// `waiter` does not start work enqueued after this call before everything enqueued on `done` so far has finished
+static inline hipError_t rt_stream_wait(hipStream_t waiter, hipStream_t done, hipEvent_t ev) {
+    hipError_t e = hipEventRecord(ev, done);
+    return e != hipSuccess ? e : hipStreamWaitEvent(waiter, ev, 0);
+}
 #else
+typedef int hipEvent_t;
+static inline int rt_stream_wait(hipStream_t, hipStream_t, hipEvent_t) { return 0; }
 #define RT_CHECK(expr) do { (void)(expr); } while (0)
 static inline int rt_malloc(void **p, size_t n) { *p = aligned_alloc(64, (n + 63) / 64 * 64); return *p ? 0 : 1; }
 static inline int rt_free(void *p) { free(p); return 0; }
@@ -77,8 +84,10 @@ struct Ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t copy_stream = nullptr;   // host scalars travel here, chunk by chunk, beside the kernels of earlier chunks
+    std::vector<hipEvent_t> copy_events;
     int32_t forced_c = 0;
-    int64_t tune[5] = {-1, -1, -1, -1, -1};   // mira_set_tuning overrides, < 0 = default
+    int64_t tune[6] = {-1, -1, -1, -1, -1, -1};   // mira_set_tuning overrides, < 0 = default
     Timing tm;
     // MSM workspace (grow-only, shared by all handles: calls are serialised by the ABI lock)
     DevBuf digits, counts, offsets, cursor, block_sums, sorted_idx, bucket_sums, part, coarse_offsets, fine_counts, fine_cursor;
@@ -120,17 +129,17 @@ struct MsmPlan {
     uint32_t c, W, B, NB, tile, ntiles, L, T, m, nchunks, lanes;
     uint32_t count, Wt;   // MSMs in this submission, total windows count * W
     uint64_t stride;      // scalars of MSM b start at element b * stride
+    bool stats = false;   // also histogram the bit lengths of the scalars (planning input of the next commit of this shape)
 };
 
 // per-curve translation units (msm_bn256.hip / msm_grumpkin.hip)
-int msm_launch_bn256(const Bases &bs, size_t first, const void *d_scalars, size_t n, const MsmPlan &p, uint64_t *host_windows);
-int msm_launch_grumpkin(const Bases &bs, size_t first, const void *d_scalars, size_t n, const MsmPlan &p, uint64_t *host_windows);
+// h_scalars != null: the scalars are still in host memory; d_scalars is then the device staging buffer they are copied to
+int msm_launch_bn256(const Bases &bs, size_t first, const void *d_scalars, const void *h_scalars, size_t n, const MsmPlan &p, uint64_t *host_windows);
+int msm_launch_grumpkin(const Bases &bs, size_t first, const void *d_scalars, const void *h_scalars, size_t n, const MsmPlan &p, uint64_t *host_windows);
 int msm_launch_table_bn256(const Bases &bs, size_t first, const void *d_scalars, size_t n, uint64_t *host_sums);
 int msm_launch_table_grumpkin(const Bases &bs, size_t first, const void *d_scalars, size_t n, uint64_t *host_sums);
 int build_tables_bn256(Bases &bs);
 int build_tables_grumpkin(Bases &bs);
-int scalar_bitlen_hist_bn256(const void *d_scalars, size_t n, size_t count, size_t stride);
-int scalar_bitlen_hist_grumpkin(const void *d_scalars, size_t n, size_t count, size_t stride);
 int curve_init_bn256();
 int convert_bases_bn256(const void *d_src, void *d_dst, size_t n);
 int convert_bases_grumpkin(const void *d_src, void *d_dst, size_t n);

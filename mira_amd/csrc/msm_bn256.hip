@@ -1,8 +1,8 @@
 // bn256: instantiates the MSM pipeline for this curve (coordinates Fq29 / FqP, scalars FrP).
 #include "msm_host.cuh"
 
-int msm_launch_bn256(const Bases &bs, size_t first, const void *d_scalars, size_t n, const MsmPlan &p, uint64_t *host_windows) {
-    return msm_launch<Fq29, FrP>(bs, first, d_scalars, n, p, host_windows);
+int msm_launch_bn256(const Bases &bs, size_t first, const void *d_scalars, const void *h_scalars, size_t n, const MsmPlan &p, uint64_t *host_windows) {
+    return msm_launch<Fq29, FrP>(bs, first, d_scalars, h_scalars, n, p, host_windows);
 }
 int curve_init_bn256() { return curve_init<Fq29, FrP>(); }
 int convert_bases_bn256(const void *d_src, void *d_dst, size_t n) { return convert_bases<Fq29>(d_src, d_dst, n); }
@@ -18,4 +18,3 @@ int msm_launch_table_bn256(const Bases &bs, size_t first, const void *d_scalars,
     return msm_launch_table<Fq29, FrP>(bs, first, d_scalars, n, host_sums);
 }
 int build_tables_bn256(Bases &bs) { return build_tables<Fq29>(bs); }
-int scalar_bitlen_hist_bn256(const void *d_scalars, size_t n, size_t count, size_t stride) { return scalar_bitlen_hist<FrP>(d_scalars, n, count, stride); }

@@ -1,8 +1,8 @@
 // grumpkin: instantiates the MSM pipeline for this curve (coordinates Fr29 / FrP, scalars FqP).
 #include "msm_host.cuh"
 
-int msm_launch_grumpkin(const Bases &bs, size_t first, const void *d_scalars, size_t n, const MsmPlan &p, uint64_t *host_windows) {
-    return msm_launch<Fr29, FqP>(bs, first, d_scalars, n, p, host_windows);
+int msm_launch_grumpkin(const Bases &bs, size_t first, const void *d_scalars, const void *h_scalars, size_t n, const MsmPlan &p, uint64_t *host_windows) {
+    return msm_launch<Fr29, FqP>(bs, first, d_scalars, h_scalars, n, p, host_windows);
 }
 int curve_init_grumpkin() { return curve_init<Fr29, FqP>(); }
 int convert_bases_grumpkin(const void *d_src, void *d_dst, size_t n) { return convert_bases<Fr29>(d_src, d_dst, n); }
@@ -18,4 +18,3 @@ int msm_launch_table_grumpkin(const Bases &bs, size_t first, const void *d_scala
     return msm_launch_table<Fr29, FqP>(bs, first, d_scalars, n, host_sums);
 }
 int build_tables_grumpkin(Bases &bs) { return build_tables<Fr29>(bs); }
-int scalar_bitlen_hist_grumpkin(const void *d_scalars, size_t n, size_t count, size_t stride) { return scalar_bitlen_hist<FqP>(d_scalars, n, count, stride); }

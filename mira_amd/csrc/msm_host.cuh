@@ -16,23 +16,45 @@ static constexpr uint32_t FIXUP_HEAVY_GRID = 4096;   // waves; idle ones leave a
 // chain of dependent additions is what takes the time there); single lanes beyond (throughput)
 static inline bool reduce_with_quads(uint64_t work_items) { return work_items * 4 <= 98304; }
 
+// Host scalars (commit(&self, v: &[C::Scalar]) hands over host memory, src/commitment.rs:78) are
+// cut into point chunks: chunk k + 1 crosses PCIe on the copy stream while the kernels of chunk k
+// run.  Every chunk goes through digits .. fix-up on its own, its bucket runs starting from the sums
+// of the chunks before (k_accumulate<F, true>); bucket reduction and window sums run once.  The first chunk is small (its
+// copy is the only one nothing hides), the following ones double up to 2^20 pairs.
+static inline std::vector<size_t> host_chunks(size_t n, size_t min_n) {
+    std::vector<size_t> ends;
+    if (n < min_n) { ends.push_back(n); return ends; }
+    size_t done = 0, step = std::max<size_t>(1, min_n / 2);         // 2^18 by default
+    while (done < n) {
+        size_t len = std::min(step, n - done);
+        if (n - done - len < step / 2) len = n - done;             // a short tail joins the last chunk
+        done += len;
+        ends.push_back(done);
+        if (step < 4 * std::max<size_t>(1, min_n / 2)) step <<= 1;   // up to 2^20
+    }
+    return ends;
+}
+
 template <class F, class FS>
-static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size_t n, const MsmPlan &p,
+static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, const void *h_scalars, size_t n, const MsmPlan &p,
                       uint64_t *host_windows /* count * W * 16 u64 */) {
     int rc;
-    const size_t entries = (size_t)n * p.Wt;
-    if ((rc = g.digits.ensure(entries * 2))) return rc;
+    // chunks: [0, ends[0]), [ends[0], ends[1]), ...  (one chunk unless the scalars are in host memory)
+    const std::vector<size_t> ends = (h_scalars && p.count == 1) ? host_chunks(n, tuned(MIRA_TUNE_HOST_CHUNK_MIN_N, (size_t)1 << 19)) : std::vector<size_t>{n};
+    size_t nmax = 0;
+    for (size_t k = 0, lo = 0; k < ends.size(); lo = ends[k++]) nmax = std::max(nmax, ends[k] - lo);
+    const size_t entries_max = nmax * p.Wt;
+    if ((rc = g.digits.ensure(entries_max * 2))) return rc;
     if ((rc = g.counts.ensure(((size_t)p.NB + 1) * 4))) return rc;
     if ((rc = g.offsets.ensure(((size_t)p.NB + 1) * 4))) return rc;
     if ((rc = g.cursor.ensure(((size_t)p.NB + 1) * 4))) return rc;
     const uint32_t scan_blocks = ceil_div(p.NB, SCAN_TILE);
     if (scan_blocks > 1024) { set_error("window configuration exceeds the scan capacity"); return MIRA_E_UNSUPPORTED; }
     if ((rc = g.block_sums.ensure(1024 * 4))) return rc;
-    if ((rc = g.sorted_idx.ensure(entries * 4 + 8))) return rc;
+    if ((rc = g.sorted_idx.ensure(entries_max * 4 + 8))) return rc;
     const size_t staged_min_n = tuned(MIRA_TUNE_STAGED_MIN_N, (size_t)1 << 19);
-    const bool staged = n >= staged_min_n && p.c >= 9;
-    if (staged) {
-        if ((rc = g.part.ensure(entries * 8 + 8))) return rc;
+    if (nmax >= staged_min_n && p.c >= 9) {
+        if ((rc = g.part.ensure(entries_max * 8 + 8))) return rc;
         if ((rc = g.coarse_offsets.ensure(((size_t)p.Wt * 512 + 1) * 4))) return rc;
     }
     if ((rc = g.bucket_sums.ensure((size_t)p.NB * XYZZ29_BYTES))) return rc;
@@ -43,68 +65,106 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size
     if ((rc = g.heavy_out.ensure(((size_t)p.T / 2 + 8) * XYZZ29_BYTES))) return rc;
     if ((rc = g.chunks.ensure((size_t)p.Wt * p.nchunks * XYZZ29_BYTES))) return rc;
     if ((rc = g.window_sums.ensure((size_t)p.Wt * 128))) return rc;
+#ifndef MIRA_CPU_EMU
+    if (h_scalars) {
+        if (!g.copy_stream) RT_CHECK(hipStreamCreateWithFlags(&g.copy_stream, hipStreamNonBlocking));
+        while (g.copy_events.size() < ends.size()) {
+            hipEvent_t e;
+            RT_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            g.copy_events.push_back(e);
+        }
+    }
+#endif
 
     hipStream_t st = g.stream;
-    const unsigned char *bases = reinterpret_cast<const unsigned char *>(bs.d) + first * 64;
     uint32_t *heavy_count = reinterpret_cast<uint32_t *>(g.heavy.p);          // [0] runs, [1] sub-jobs, [2..3] plan
     U4 *heavy_runs = reinterpret_cast<U4 *>(heavy_count + 16);
     U4 *heavy_subs = heavy_runs + ((size_t)p.T / 4 + 4);
     uint32_t *plan = heavy_count + 2;
     uint32_t *no_u32 = nullptr;
-
-    // No clearing passes: k_digits zeroes the bucket counters, k_scan_c the heavy-run counters and the
-    // identity marker of every bucket without entries, every segment of k_accumulate writes its tail key.
-    tm_begin();
-    LAUNCH(k_digits<FS>, dim3(ceil_div(n, 256), p.count), 256, 0, st, reinterpret_cast<const unsigned char *>(d_scalars), (uint32_t)n, (uint64_t)p.stride, p.c, p.W,
-           reinterpret_cast<int16_t *>(g.digits.p), reinterpret_cast<uint32_t *>(g.counts.p), p.NB + 1);
-    tm_mark("digits");
-    LAUNCH_BARRIER_FLEX(k_hist, dim3(p.ntiles, p.Wt), 1024, (size_t)p.B * 4, st, reinterpret_cast<const int16_t *>(g.digits.p), (uint32_t)n,
-                   p.B, p.tile, reinterpret_cast<uint32_t *>(g.counts.p));
-    tm_mark("hist");
+    unsigned char *no_u8 = nullptr;
     // coarse bin of the staged sort = top 8 bits of the bucket id (6..9 measured equal)
     const uint32_t fine_bits = (p.c - 1) - std::min<uint32_t>(p.c - 1, 8);
     const uint32_t CB = p.B >> fine_bits;                                       // <= 256 coarse bins per window
-    LAUNCH_BARRIER(k_scan_a, scan_blocks, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.counts.p), p.NB,
-                   reinterpret_cast<uint32_t *>(g.block_sums.p));
-    LAUNCH_BARRIER(k_scan_b, 1, 1024, 0, st, reinterpret_cast<uint32_t *>(g.block_sums.p), scan_blocks);
-    LAUNCH_BARRIER(k_scan_c, scan_blocks, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.counts.p), p.NB,
-                   reinterpret_cast<const uint32_t *>(g.block_sums.p), reinterpret_cast<uint32_t *>(g.offsets.p),
-                   reinterpret_cast<uint32_t *>(g.cursor.p), staged ? reinterpret_cast<uint32_t *>(g.coarse_offsets.p) : no_u32, fine_bits,
-                   plan, p.lanes, p.L, heavy_count, reinterpret_cast<unsigned char *>(g.bucket_sums.p));
-    tm_mark("scan");
-    // sort: LDS-staged two-level partition for large inputs (bursts of consecutive entries), the
-    // single-level scatter otherwise (small inputs: the tile structure buys nothing there)
-    if (staged) {
-        LAUNCH_BARRIER((k_stage1<int16_t, false>), dim3(ceil_div(n, STAGE_TILE), p.Wt), 1024, (size_t)STAGE_TILE * 8, st, reinterpret_cast<const int16_t *>(g.digits.p),
-                            (uint32_t)n, p.B, fine_bits, CB, 0u, 0u, reinterpret_cast<uint32_t *>(g.coarse_offsets.p), reinterpret_cast<U2 *>(g.part.p));
-        tm_mark("sort_level1");
-        LAUNCH_BARRIER(k_stage2, ceil_div(entries, STAGE_TILE), 1024, (size_t)STAGE_TILE * 6, st, reinterpret_cast<const U2 *>(g.part.p),
-                            reinterpret_cast<const uint32_t *>(g.offsets.p) + p.NB, fine_bits, reinterpret_cast<uint32_t *>(g.cursor.p),
-                            reinterpret_cast<uint32_t *>(g.sorted_idx.p));
-    } else
-        LAUNCH_BARRIER_FLEX(k_scatter, dim3(p.ntiles, p.Wt), 1024, (size_t)p.B * 4, st, reinterpret_cast<const int16_t *>(g.digits.p),
-                   (uint32_t)n, p.B, p.tile, reinterpret_cast<uint32_t *>(g.cursor.p), reinterpret_cast<uint32_t *>(g.sorted_idx.p));
-    tm_mark("scatter");
-    LAUNCH(k_accumulate<F>, ceil_div(p.T, 128), 128, 0, st, reinterpret_cast<const uint32_t *>(g.sorted_idx.p),
-           reinterpret_cast<const uint32_t *>(g.offsets.p), p.NB, bases, (const uint32_t *)plan,
-           reinterpret_cast<unsigned char *>(g.bucket_sums.p), reinterpret_cast<unsigned char *>(g.head_part.p),
-           reinterpret_cast<unsigned char *>(g.tail_part.p), reinterpret_cast<uint32_t *>(g.tail_key.p));
-    tm_mark("accumulate");
-    const uint32_t fix_by_bucket = p.NB < p.T ? p.NB : 0u;   // fewer buckets than segments: index the fix-up by bucket
-    LAUNCH(k_fixup<F>, ceil_div((uint64_t)(fix_by_bucket ? fix_by_bucket : p.T) * 4, 128), 128, 0, st, (const uint32_t *)plan, reinterpret_cast<const uint32_t *>(g.offsets.p),
-           reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
-           reinterpret_cast<const uint32_t *>(g.tail_key.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p), heavy_count, heavy_runs, heavy_subs, fix_by_bucket);
-    LAUNCH_BARRIER(k_fixup_heavy_a<F>, FIXUP_HEAVY_GRID, HEAVY_BLOCK, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_subs, (const U4 *)heavy_runs,
-                   reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
-                   reinterpret_cast<unsigned char *>(g.heavy_out.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p));
-    LAUNCH_BARRIER(k_fixup_heavy_b<F>, FIXUP_HEAVY_GRID, HEAVY_BLOCK, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_runs,
-                   reinterpret_cast<const unsigned char *>(g.heavy_out.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
-                   reinterpret_cast<unsigned char *>(g.bucket_sums.p));
-    tm_mark("fixup");
+
+    // No clearing passes: k_digits zeroes the bucket counters, k_scan_c the heavy-run counters and (first
+    // chunk) the identity marker of every bucket without entries, every segment of k_accumulate writes its tail key.
+    tm_begin();
+    if (p.stats) {
+        if ((rc = g.hist_dev.ensure(1024))) return rc;
+        if (!g.hist_host) RT_CHECK(rt_host_alloc(reinterpret_cast<void **>(&g.hist_host), 1024));
+        RT_CHECK(rt_memset(g.hist_dev.p, 0, 1024, st));
+    }
+    for (size_t k = 0, lo = 0; k < ends.size(); lo = ends[k++]) {
+        const size_t nc = ends[k] - lo, entries = nc * p.Wt;
+        const unsigned char *sc = reinterpret_cast<const unsigned char *>(d_scalars) + lo * 32;
+        const unsigned char *bases = reinterpret_cast<const unsigned char *>(bs.d) + (first + lo) * 64;
+        const uint32_t add = k ? 1u : 0u;
+        if (h_scalars) {
+            // pageable or pinned, the copy engine moves it beside the kernels of the previous chunk
+            hipStream_t cs = g.copy_stream ? g.copy_stream : st;
+            RT_CHECK(rt_h2d(const_cast<unsigned char *>(sc), reinterpret_cast<const unsigned char *>(h_scalars) + lo * 32, nc * 32, cs));
+            if (cs != st) RT_CHECK(rt_stream_wait(st, cs, g.copy_events[k]));
+        }
+        if (p.stats)      // 20 us ahead of the MSM kernels; its 1 KiB lands in pinned host memory by the time the call ends
+            LAUNCH_BARRIER_FLEX(k_bitlen_hist<FS>, dim3(std::min<uint32_t>(1024, ceil_div(nc, 256)), p.count), 256, 0, st, sc, (uint32_t)nc, (uint64_t)p.stride,
+                                reinterpret_cast<uint32_t *>(g.hist_dev.p));
+        // histogram / scatter tiling of this chunk: about two workgroups per CU, at least 1024 points per tile
+        const uint32_t tile = (std::max<uint32_t>(1024, ceil_div(nc, std::max<uint32_t>(1, 512 / p.Wt))) + 1023) / 1024 * 1024, ntiles = ceil_div(nc, tile);
+        const bool staged = nc >= staged_min_n && p.c >= 9;
+        LAUNCH(k_digits<FS>, dim3(ceil_div(nc, 256), p.count), 256, 0, st, sc, (uint32_t)nc, (uint64_t)p.stride, p.c, p.W,
+               reinterpret_cast<int16_t *>(g.digits.p), reinterpret_cast<uint32_t *>(g.counts.p), p.NB + 1);
+        tm_mark("digits");
+        LAUNCH_BARRIER_FLEX(k_hist, dim3(ntiles, p.Wt), 1024, (size_t)p.B * 4, st, reinterpret_cast<const int16_t *>(g.digits.p), (uint32_t)nc,
+                       p.B, tile, reinterpret_cast<uint32_t *>(g.counts.p));
+        tm_mark("hist");
+        LAUNCH_BARRIER(k_scan_a, scan_blocks, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.counts.p), p.NB,
+                       reinterpret_cast<uint32_t *>(g.block_sums.p));
+        LAUNCH_BARRIER(k_scan_b, 1, 1024, 0, st, reinterpret_cast<uint32_t *>(g.block_sums.p), scan_blocks);
+        LAUNCH_BARRIER(k_scan_c, scan_blocks, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.counts.p), p.NB,
+                       reinterpret_cast<const uint32_t *>(g.block_sums.p), reinterpret_cast<uint32_t *>(g.offsets.p),
+                       reinterpret_cast<uint32_t *>(g.cursor.p), staged ? reinterpret_cast<uint32_t *>(g.coarse_offsets.p) : no_u32, fine_bits,
+                       plan, p.lanes, p.L, heavy_count, add ? no_u8 : reinterpret_cast<unsigned char *>(g.bucket_sums.p));
+        tm_mark("scan");
+        // sort: LDS-staged two-level partition for large inputs (bursts of consecutive entries), the
+        // single-level scatter otherwise (small inputs: the tile structure buys nothing there)
+        if (staged) {
+            LAUNCH_BARRIER((k_stage1<int16_t, false>), dim3(ceil_div(nc, STAGE_TILE), p.Wt), 1024, (size_t)STAGE_TILE * 8, st, reinterpret_cast<const int16_t *>(g.digits.p),
+                                (uint32_t)nc, p.B, fine_bits, CB, 0u, 0u, reinterpret_cast<uint32_t *>(g.coarse_offsets.p), reinterpret_cast<U2 *>(g.part.p));
+            tm_mark("sort_level1");
+            LAUNCH_BARRIER(k_stage2, ceil_div(entries, STAGE_TILE), 1024, (size_t)STAGE_TILE * 6, st, reinterpret_cast<const U2 *>(g.part.p),
+                                reinterpret_cast<const uint32_t *>(g.offsets.p) + p.NB, fine_bits, reinterpret_cast<uint32_t *>(g.cursor.p),
+                                reinterpret_cast<uint32_t *>(g.sorted_idx.p));
+        } else
+            LAUNCH_BARRIER_FLEX(k_scatter, dim3(ntiles, p.Wt), 1024, (size_t)p.B * 4, st, reinterpret_cast<const int16_t *>(g.digits.p),
+                       (uint32_t)nc, p.B, tile, reinterpret_cast<uint32_t *>(g.cursor.p), reinterpret_cast<uint32_t *>(g.sorted_idx.p));
+        tm_mark("scatter");
+        if (add)
+            LAUNCH((k_accumulate<F, true>), ceil_div(p.T, 128), 128, 0, st, reinterpret_cast<const uint32_t *>(g.sorted_idx.p),
+                   reinterpret_cast<const uint32_t *>(g.offsets.p), p.NB, bases, (const uint32_t *)plan,
+                   reinterpret_cast<unsigned char *>(g.bucket_sums.p), reinterpret_cast<unsigned char *>(g.head_part.p),
+                   reinterpret_cast<unsigned char *>(g.tail_part.p), reinterpret_cast<uint32_t *>(g.tail_key.p));
+        else
+            LAUNCH((k_accumulate<F, false>), ceil_div(p.T, 128), 128, 0, st, reinterpret_cast<const uint32_t *>(g.sorted_idx.p),
+                   reinterpret_cast<const uint32_t *>(g.offsets.p), p.NB, bases, (const uint32_t *)plan,
+                   reinterpret_cast<unsigned char *>(g.bucket_sums.p), reinterpret_cast<unsigned char *>(g.head_part.p),
+                   reinterpret_cast<unsigned char *>(g.tail_part.p), reinterpret_cast<uint32_t *>(g.tail_key.p));
+        tm_mark("accumulate");
+        const uint32_t fix_by_bucket = p.NB < p.T ? p.NB : 0u;   // fewer buckets than segments: index the fix-up by bucket
+        LAUNCH(k_fixup<F>, ceil_div((uint64_t)(fix_by_bucket ? fix_by_bucket : p.T) * 4, 128), 128, 0, st, (const uint32_t *)plan, reinterpret_cast<const uint32_t *>(g.offsets.p),
+               reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
+               reinterpret_cast<const uint32_t *>(g.tail_key.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p), heavy_count, heavy_runs, heavy_subs, fix_by_bucket);
+        LAUNCH_BARRIER(k_fixup_heavy_a<F>, FIXUP_HEAVY_GRID, HEAVY_BLOCK, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_subs, (const U4 *)heavy_runs,
+                       reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
+                       reinterpret_cast<unsigned char *>(g.heavy_out.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p));
+        LAUNCH_BARRIER(k_fixup_heavy_b<F>, FIXUP_HEAVY_GRID, HEAVY_BLOCK, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_runs,
+                       reinterpret_cast<const unsigned char *>(g.heavy_out.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
+                       reinterpret_cast<unsigned char *>(g.bucket_sums.p));
+        tm_mark("fixup");
+    }
     const uint64_t items = (uint64_t)p.Wt * p.nchunks;
     if (reduce_with_quads(items)) {
-        const uint32_t rb = getenv("MIRA_DBG_RB") ? atoi(getenv("MIRA_DBG_RB")) : 64;
-        LAUNCH((k_reduce_chunks<F, true>), ceil_div(items * 4, rb), rb, 0, st, reinterpret_cast<const unsigned char *>(g.bucket_sums.p),
+        LAUNCH((k_reduce_chunks<F, true>), ceil_div(items * 4, 64), 64, 0, st, reinterpret_cast<const unsigned char *>(g.bucket_sums.p),
                p.B, p.m, p.Wt, reinterpret_cast<unsigned char *>(g.chunks.p));
         tm_mark("reduce_chunks");
         LAUNCH_BARRIER((k_window_sum<F, true>), p.Wt, WSUM_BLOCK, (size_t)(WSUM_BLOCK / 4) * XYZZ29_BYTES, st, reinterpret_cast<const unsigned char *>(g.chunks.p), p.nchunks,
@@ -120,6 +180,7 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, size
     }
     tm_mark("window_sum");
     RT_CHECK(rt_last());
+    if (p.stats) RT_CHECK(rt_d2h(g.hist_host, g.hist_dev.p, 1024, st));
     RT_CHECK(rt_d2h(host_windows, g.window_sums.p, (size_t)p.Wt * 128, st));
     RT_CHECK(rt_sync(st));
     tm_end();
@@ -264,7 +325,7 @@ static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars
     LAUNCH_BARRIER(k_stage2, ceil_div(entries, STAGE_TILE), 1024, (size_t)STAGE_TILE * 6, st, reinterpret_cast<const U2 *>(g.part.p), coarse_total,
                         TABLE_FINE_BITS, reinterpret_cast<uint32_t *>(g.fine_cursor.p), reinterpret_cast<uint32_t *>(g.sorted_idx.p));
     tm_mark("sort_level2");
-    LAUNCH(k_accumulate<F>, ceil_div(T, 128), 128, 0, st, reinterpret_cast<const uint32_t *>(g.sorted_idx.p),
+    LAUNCH((k_accumulate<F, false>), ceil_div(T, 128), 128, 0, st, reinterpret_cast<const uint32_t *>(g.sorted_idx.p),
            reinterpret_cast<const uint32_t *>(g.offsets.p), TABLE_B, reinterpret_cast<const unsigned char *>(bs.tables), (const uint32_t *)plan,
            reinterpret_cast<unsigned char *>(g.bucket_sums.p), reinterpret_cast<unsigned char *>(g.head_part.p),
            reinterpret_cast<unsigned char *>(g.tail_part.p), reinterpret_cast<uint32_t *>(g.tail_key.p));
@@ -292,17 +353,3 @@ static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars
     return MIRA_OK;
 }
 
-// bit-length histogram of `count` scalar vectors, enqueued on the work stream: the 1 KiB result
-// lands in g.hist_host (pinned) by the time the stream is next synchronised
-template <class FS> static int scalar_bitlen_hist(const void *d_scalars, size_t n, size_t count, size_t stride) {
-    int rc;
-    if ((rc = g.hist_dev.ensure(1024))) return rc;
-    if (!g.hist_host) RT_CHECK(rt_host_alloc(reinterpret_cast<void **>(&g.hist_host), 1024));
-    RT_CHECK(rt_memset(g.hist_dev.p, 0, 1024, g.stream));
-    const uint32_t blocks = std::min<uint32_t>(1024, ceil_div(n, 256));
-    LAUNCH_BARRIER_FLEX(k_bitlen_hist<FS>, dim3(blocks, (uint32_t)count), 256, 0, g.stream, reinterpret_cast<const unsigned char *>(d_scalars),
-                        (uint32_t)n, (uint64_t)stride, reinterpret_cast<uint32_t *>(g.hist_dev.p));
-    RT_CHECK(rt_last());
-    RT_CHECK(rt_d2h(g.hist_host, g.hist_dev.p, 1024, g.stream));
-    return MIRA_OK;
-}

@@ -270,7 +270,16 @@ DEV uint32_t bucket_of(const uint32_t *__restrict__ offsets, uint32_t lo, uint32
     return lo;
 }
 
-template <class F>
+// ADD: the bucket sums of the earlier point chunks of the same MSM are already in bucket_sums (host
+// scalars arrive chunk by chunk, msm_host.cuh).  The lane in which a run STARTS takes the bucket's
+// current value as the run's initial accumulator instead of the identity -- exactly one lane per
+// run does, so every earlier sum is counted once, at the price of one 144-byte load per run and no
+// extra registers; complete runs, partials and the fix-up then work as for a single chunk.
+template <bool ADD, class F> DEV Xyzz29<F> run_start(const unsigned char *bucket_sums, uint32_t bucket) {
+    if constexpr (ADD) return xyzz29_load<F>(bucket_sums + (size_t)bucket * XYZZ29_BYTES);
+    else return xyzz29_identity<F>();
+}
+template <class F, bool ADD>
 KERNEL void __launch_bounds__(128) k_accumulate(const uint32_t *__restrict__ sorted, const uint32_t *__restrict__ offsets, uint32_t NB,
                          const unsigned char *__restrict__ bases,
                          const uint32_t *__restrict__ plan, unsigned char *__restrict__ bucket_sums,
@@ -291,7 +300,7 @@ KERNEL void __launch_bounds__(128) k_accumulate(const uint32_t *__restrict__ sor
     uint32_t next_end = (cur + 2 <= NB) ? offsets[cur + 2] : total;
     const bool cont_prev = offsets[cur] < start;
     bool first = true;
-    Xyzz29<F> acc = xyzz29_identity<F>();
+    Xyzz29<F> acc = cont_prev ? xyzz29_identity<F>() : run_start<ADD, F>(bucket_sums, cur);
     // two-deep software pipeline: the entry two ahead and the base one ahead are in flight while
     // the current mixed add (about 9k issue cycles per wave) runs
     uint32_t ent0 = sorted[start];
@@ -311,7 +320,6 @@ KERNEL void __launch_bounds__(128) k_accumulate(const uint32_t *__restrict__ sor
             if (first && cont_prev) xyzz29_store(head_part + (size_t)t * XYZZ29_BYTES, acc);
             else xyzz29_store(bucket_sums + (size_t)cur * XYZZ29_BYTES, acc);
             first = false;
-            acc = xyzz29_identity<F>();
             cur++;
             run_end = next_end;
             if (run_end <= j) {                              // empty buckets in between: search
@@ -319,6 +327,7 @@ KERNEL void __launch_bounds__(128) k_accumulate(const uint32_t *__restrict__ sor
                 run_end = offsets[cur + 1];
             }
             next_end = (cur + 2 <= NB) ? offsets[cur + 2] : total;
+            acc = run_start<ADD, F>(bucket_sums, cur);
         }
         xyzz29_add_affine(acc, aff29_from_raw<F>(c0, c1, c2, c3, (e >> 31) != 0));
     }

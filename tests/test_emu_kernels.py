@@ -226,3 +226,24 @@ def test_emu_staged_sort(emu_lib, tune):
             assert (key.commit(one) == C.msm_pippenger(cid, one, bs)).all()
         finally:
             emu_lib.check(emu_lib.c.mira_msm_set_window_bits(0))
+
+
+def test_emu_host_scalars_in_chunks(emu_lib, tune):
+    """Host scalars cut into point chunks (copy of one chunk beside the kernels of the previous one on
+    the GPU): every chunk adds its bucket sums to those before.  Same commitments as the one-chunk
+    path, with heavy buckets, zeros and an identity base spread over the chunks."""
+    tune(_lib.TUNE_HOST_CHUNK_MIN_N, 64)                     # chunks of 32, 64, 128, 128, ... points
+    for cid, c in ((0, 9), (1, 5)):
+        n = 700
+        bs = C.synth_bases(cid, n, seed=70 + cid)
+        bs[300] = 0
+        key = cm.CommitmentKey(cid, bs, lib=emu_lib)
+        emu_lib.check(emu_lib.c.mira_msm_set_window_bits(c))
+        try:
+            for kind in (0, 1):
+                sc = C.synth_scalars(cid, n, seed=72 + kind, kind=kind)
+                sc[100:160] = sc[0]                            # one bucket per window fed from several chunks
+                assert (key.commit(sc) == C.commit(cid, bs, sc)).all(), (cid, kind)
+            assert (key.commit(sc[:33]) == C.commit(cid, bs[:33], sc[:33])).all()      # below the threshold: one chunk
+        finally:
+            emu_lib.check(emu_lib.c.mira_msm_set_window_bits(0))

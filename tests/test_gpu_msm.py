@@ -244,3 +244,25 @@ def test_abi_from_two_threads(gpu_lib):
     """Two caller threads, two keys, interleaved mira_msm + mira_fft_bn256_fr (include/mira_gpu.h: re-entrant)."""
     from test_host_logic import _two_thread_abi
     _two_thread_abi(gpu_lib, n=20000, log_n=14, rounds=6)
+
+
+@pytest.mark.parametrize("cid,kind", [(0, 0), (1, 1)])
+def test_host_scalars_cross_pcie_in_chunks(gpu_lib, cid, kind):
+    """commit(v) with v in host memory (src/commitment.rs:78) above 2^19 pairs: point chunks whose
+    copies overlap the kernels of the previous chunk, bucket sums added across chunks.  Same point
+    as the device-resident commit and the oracle; a forced small threshold gives many chunks."""
+    from mira_amd import _lib
+    n = (1 << 20) + 12345
+    key = cm.CommitmentKey.synthetic(cid, n, seed=111)
+    sc = C.synth_scalars(cid, n, seed=112, kind=kind)
+    d = gpu_lib.alloc(n * 32); gpu_lib.upload(d, sc)
+    want = key.commit_device(d, n)
+    assert (key.commit(sc) == want).all()
+    assert (want == C.commit(cid, key.bases(), sc)).all()
+    gpu_lib.tune(_lib.TUNE_HOST_CHUNK_MIN_N, 1 << 14)        # 8k, 16k, 32k, 32k, ... pairs per chunk
+    try:
+        assert (key.commit(sc) == want).all()
+        assert (key.commit(sc[: 1 << 15]) == key.commit_device(d, 1 << 15)).all()
+    finally:
+        gpu_lib.tune(_lib.TUNE_HOST_CHUNK_MIN_N, -1)
+    gpu_lib.free(d)

@@ -1,0 +1,22 @@
+"""Development probe: wall time of one commit for every window width, across the sizes the planner
+(plan_cost_us in capi.hip) has to decide for.  Output feeds its base_us table and candidate list."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mira_amd import _lib, commitment as cm
+lib = _lib.load()
+cases = [(64, 0), (1024, 0), (8192, 0), (32768, 0), (65536, 0), (131072, 0), (1 << 18, 0), (1 << 19, 0), (1 << 20, 0), (1 << 21, 0), (14 << 17, 1), (7 << 17, 1), (131072, 1)]
+widths = [0] + list(range(4, 17))
+print("n kind " + " ".join(f"c={c}" for c in widths), flush=True)
+for n, kind in cases:
+    key = cm.CommitmentKey.synthetic(0, n); d = cm.synth_scalars_device(0, n, kind=kind)
+    row = []
+    for c in widths:
+        lib.check(lib.c.mira_msm_set_window_bits(c))
+        key.commit_device(d, n); key.commit_device(d, n)
+        ts = []
+        for _ in range(9):
+            t0 = time.perf_counter(); key.commit_device(d, n); ts.append((time.perf_counter() - t0) * 1e3)
+        row.append(f"{sorted(ts)[4]:.3f}")
+    lib.check(lib.c.mira_msm_set_window_bits(0))
+    print(n, kind, " ".join(row), flush=True)
+    key.close(); lib.free(d)

@@ -364,6 +364,62 @@ def extras(lib, cm, with_cpu):
     except Exception as e:   # extras never take the headline down
         ex["ntt_2p24"] = {"error": repr(e)}
 
+    # ---- the rest of the metric's range, 2^20 / 2^24 / 2^26 pairs, same path as the headline (16-bit
+    # windows, scalars and key resident in HBM), timed here so that the driver's clock is around them
+    try:
+        lib.check(lib.c.mira_msm_set_window_bits(16))
+        sweep = {}
+        for log_n in (20, 24, 26):
+            n = 1 << log_n
+            key = cm.CommitmentKey.synthetic(cm.CURVE_BN256, n)
+            d = cm.synth_scalars_device(cm.CURVE_BN256, n)
+            key.commit_device(d, n)
+            reps = 5 if log_n <= 24 else 3
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                key.commit_device(d, n)
+            dt = (time.perf_counter() - t0) / reps
+            sweep[f"2p{log_n}"] = {"ms": round(dt * 1e3, 3), "M_pairs_per_s": round(n / dt / 1e6, 1), "reps": reps}
+            key.close(); lib.free(d)
+        ex["msm_sweep_16bit_windows"] = sweep
+    except Exception as e:
+        ex["msm_sweep_16bit_windows"] = {"error": repr(e)}
+    finally:
+        lib.check(lib.c.mira_msm_set_window_bits(0))
+
+    # ---- the boundary's real cost: commit(&self, v: &[C::Scalar]) receives HOST memory
+    # (src/commitment.rs:78).  mira_msm cuts the scalars into point chunks whose PCIe copies run beside
+    # the kernels of the previous chunk; beside it the same call with one up-front copy (chunking off)
+    # and the HBM-resident commit of the headline.
+    try:
+        from mira_amd import _lib as L
+        lib.check(lib.c.mira_msm_set_window_bits(16))
+        n = 1 << 22
+        key = cm.CommitmentKey.synthetic(cm.CURVE_BN256, n)
+        d = cm.synth_scalars_device(cm.CURVE_BN256, n)
+        sc = lib.download(d, (n, 4))                           # ordinary pageable host memory
+
+        def med(fn, reps=7):
+            fn()
+            ts = []
+            for _ in range(reps):
+                t0 = time.perf_counter(); out = fn(); ts.append((time.perf_counter() - t0) * 1e3)
+            return sorted(ts)[reps // 2], out
+        t_dev, p_dev = med(lambda: key.commit_device(d, n))
+        t_host, p_host = med(lambda: key.commit(sc))
+        lib.tune(L.TUNE_HOST_CHUNK_MIN_N, 1 << 40)
+        t_one, p_one = med(lambda: key.commit(sc))
+        lib.tune(L.TUNE_HOST_CHUNK_MIN_N, -1)
+        ex["msm_2p22_host_scalars"] = {"hbm_resident_ms": round(t_dev, 3), "host_scalars_ms": round(t_host, 3), "host_scalars_one_copy_ms": round(t_one, 3),
+                                       "pcie_inclusive_over_resident": round(t_host / t_dev, 3), "M_pairs_per_s_pcie_inclusive": round(n / t_host / 1e3, 1),
+                                       "same_point": bool((p_dev == p_host).all() and (p_dev == p_one).all()),
+                                       "note": "128 MiB of pageable host scalars per call; chunks of 2^18, 2^19, 2^20, ... pairs"}
+        key.close(); lib.free(d)
+    except Exception as e:
+        ex["msm_2p22_host_scalars"] = {"error": repr(e)}
+    finally:
+        lib.check(lib.c.mira_msm_set_window_bits(0))
+
     # ---- the same 2^22 MSM over fixed-base window tables (opt-in mode) ----
     try:
         n = 1 << 22
@@ -394,21 +450,32 @@ def extras(lib, cm, with_cpu):
     try:
         from mira_amd import fold as FD
         n = 14 << 17                                           # the primary witness vector of a k = 17 step
-        d1 = cm.synth_scalars_device(cm.CURVE_BN256, n, seed=0x57, kind=1)
-        d2 = cm.synth_scalars_device(cm.CURVE_BN256, n, seed=0x58)
-        do = lib.alloc(n * 32)
+        # eight independent (W1, W2, out) sets = 1.4 GB, visited in turn: every call streams from and to
+        # HBM (one 176 MB set alone would sit in the 256 MiB Infinity Cache)
+        sets = 8
+        d1s = [cm.synth_scalars_device(cm.CURVE_BN256, n, seed=0x57 + 2 * i, kind=1) for i in range(sets)]
+        d2s = [cm.synth_scalars_device(cm.CURVE_BN256, n, seed=0x58 + 2 * i) for i in range(sets)]
+        dos = [lib.alloc(n * 32) for _ in range(sets)]
+        d1, d2, do = d1s[0], d2s[0], dos[0]
         r = lib.download(cm.synth_scalars_device(cm.CURVE_BN256, 1, seed=0x59), (1, 4))[0]
-        FD.fold_witness_device(FD.FIELD_FR, do, d1, d2, r, n)
+        for i in range(sets):
+            FD.fold_witness_device(FD.FIELD_FR, dos[i], d1s[i], d2s[i], r, n)
         lib.check(lib.c.mira_set_timing(1))
-        ms = 0.0
-        for _ in range(5):
+        ms, ms_cached = 0.0, 0.0
+        for rep in range(2):
+            for i in range(sets):
+                FD.fold_witness_device(FD.FIELD_FR, dos[i], d1s[i], d2s[i], r, n)
+                ms += dict(lib.timings())["fold_witness"] / (2 * sets)
+        for _ in range(5):                                     # the same set again and again: cache-resident
             FD.fold_witness_device(FD.FIELD_FR, do, d1, d2, r, n)
-            ms += dict(lib.timings())["fold_witness"] / 5
+            ms_cached += dict(lib.timings())["fold_witness"] / 5
         lib.check(lib.c.mira_set_timing(0))
         gbs = 96 * n / (ms * 1e-3) / 1e9
         ex["fold_witness_14x2p17"] = {"ms": round(ms, 4), "G_elements_per_s": round(n / ms / 1e6, 2),
+                                      "ms_same_buffers_infinity_cache_resident": round(ms_cached, 4),
                                       "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                   "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes": 96 * n}}
+                                                   "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes": 96 * n,
+                                                   "working_set_bytes": 96 * n * sets}}
         if with_cpu:
             from oracle import cref as C
             m = 1 << 20
@@ -417,7 +484,7 @@ def extras(lib, cm, with_cpu):
             ex["fold_witness_14x2p17"]["cpu_baseline"] = {"value": round(m / dtc / 1e9, 4), "unit": "G elements/s", "cores": C.num_threads(), "kind": "port",
                                                           "sample": f"first 2^20 elements, {dtc * 1e3:.1f} ms"}
             ex["fold_witness_14x2p17"]["bit_exact_vs_oracle_2p20"] = bool((lib.download(do, (m, 4)) == want).all())
-        for p in (d1, d2, do):
+        for p in d1s + d2s + dos:
             lib.free(p)
     except Exception as e:
         ex["fold_witness_14x2p17"] = {"error": repr(e)}
@@ -454,12 +521,39 @@ def extras(lib, cm, with_cpu):
             return sorted(ts)[reps // 2], pts
         seq_ms, seq_pts = median_ms(False)
         bat_ms, bat_pts = median_ms(True)
+        # the same schedule as a Rust caller issues it: every vector in HOST memory, through mira_msm /
+        # mira_msm_batch (src/nifs/vanilla/mod.rs:124-127 commits one by one; src/plonk/mod.rs:680-688)
+        h_wit = {c: lib.download(wit[c], (plan[c][0], 4)) for c in plan}
+        h_cross = {c: [lib.download(cross[c] + i * n * 32, (n, 4)) for i in range(plan[c][1])] for c in plan}
+
+        def run_host(batched):
+            pts = []
+            for c, (nw, cnt) in plan.items():
+                pts.append(keys[c].commit(h_wit[c]))
+                if batched:
+                    pts.extend(keys[c].commit_batch(h_cross[c]))
+                else:
+                    pts.extend(keys[c].commit(v) for v in h_cross[c])
+            return pts
+        run_host(False); run_host(True)
+        hs, hb = [], []
+        for _ in range(5):
+            t0 = time.perf_counter(); hseq_pts = run_host(False); hs.append((time.perf_counter() - t0) * 1e3)
+            t0 = time.perf_counter(); hbat_pts = run_host(True); hb.append((time.perf_counter() - t0) * 1e3)
+        single = []
+        for _ in range(9):
+            t0 = time.perf_counter(); keys[cm.CURVE_BN256].commit_device(cross[cm.CURVE_BN256], n); single.append((time.perf_counter() - t0) * 1e3)
         ex["fold_step_k17"] = {"msm_calls": 13, "pairs": sum(nw + cnt * n for nw, cnt in plan.values()),
                                "gpu_ms": round(bat_ms, 3), "gpu_ms_one_call_per_commit": round(seq_ms, 3),
-                               "batched_equals_sequential": bool(all((a == b).all() for a, b in zip(seq_pts, bat_pts))),
+                               "gpu_ms_host_scalars_one_call_per_commit": round(sorted(hs)[2], 3), "gpu_ms_host_scalars_batched": round(sorted(hb)[2], 3),
+                               "one_commit_131072_pairs_ms": round(sorted(single)[4], 3),
+                               "host_scalar_bytes": 32 * sum(nw + cnt * n for nw, cnt in plan.values()),
+                               "batched_equals_sequential": bool(all((a == b).all() for a, b in zip(seq_pts, bat_pts))
+                                                                 and all((a == b).all() for a, b in zip(seq_pts, hseq_pts))
+                                                                 and all((a == b).all() for a, b in zip(seq_pts, hbat_pts))),
                                "note": "MSM schedule of one IVC fold step: per curve 1 witness commit + 6/5 cross-term commits "
-                                       "(gpu_ms: cross terms as one mira_msm_batch per curve); "
-                                       "the Rust driver (examples/groth16) cannot be built here"}
+                                       "(gpu_ms: scalars in HBM, cross terms as one mira_msm_batch per curve; *_host_scalars_*: every vector "
+                                       "handed over in host memory, PCIe included); the Rust driver (examples/groth16) cannot be built here"}
         if with_cpu:
             from oracle import cref as C
             cpu_in = []

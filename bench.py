@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--window-bits", type=int, default=16)
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="REHEARSAL ONLY: all ranks share GPU 0 and exchange over gloo -- the whole multi-rank path with the product library on a one-GPU box; never a measurement")
     ap.add_argument("--emulate", action="store_true",
                     help="REHEARSAL ONLY: gloo + the test-only host emulation of the kernels, to exercise the multi-rank launch on a box without GPUs; never a measurement")
     args = ap.parse_args()
@@ -108,7 +110,7 @@ def main():
     if world > 1 or os.environ.get("MIRA_BENCH_FORCE_DIST"):      # FORCE_DIST: exercise the RCCL path with one rank
         import torch
         import torch.distributed as dist
-        if args.emulate:
+        if args.emulate or args.rehearse_one_gpu:
             dist.init_process_group(backend="gloo")
         else:
             torch.cuda.set_device(local_rank)
@@ -128,7 +130,7 @@ def main():
         _lib._lib = lib                                            # the host mirror's default library for this rehearsal
     else:
         lib = _lib.load()
-    lib.check(lib.c.mira_init(0 if args.emulate else local_rank))
+    lib.check(lib.c.mira_init(0 if (args.emulate or args.rehearse_one_gpu) else local_rank))
     lib.check(lib.c.mira_msm_set_window_bits(args.window_bits))
 
     cid = cm.CURVE_BN256
@@ -158,7 +160,7 @@ def main():
     def sync_all():
         lib.check(lib.c.mira_dev_sync())
         if dist is not None:
-            if not args.emulate:
+            if not (args.emulate or args.rehearse_one_gpu):
                 import torch
                 torch.cuda.synchronize()
             dist.barrier()
@@ -183,7 +185,7 @@ def main():
     lib.check(lib.c.mira_set_timing(0))
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.emulate else "cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if (args.emulate or args.rehearse_one_gpu) else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -198,7 +200,8 @@ def main():
         "metric": "bn256_g1_msm_throughput", "value": round(value, 3), "unit": "M scalar-point pairs/s",
         "n_gpus": n_gpus, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u256 mod p (9 x 29-bit limbs in u32/u64, Montgomery)",
-        "data": "synthetic" if not args.emulate else "synthetic -- CPU EMULATION REHEARSAL of the launch path, not a measurement",
+        "data": ("synthetic -- CPU EMULATION REHEARSAL of the launch path, not a measurement" if args.emulate else
+                 "synthetic -- REHEARSAL: every rank on GPU 0, gloo exchange; not a measurement" if args.rehearse_one_gpu else "synthetic"),
         "config": {"workload": (f"BN256 G1 MSM 2^{total_log_n} pairs point-sharded over {n_gpus} GPU(s)" if strong else f"BN256 G1 MSM 2^{log_n} pairs per GPU")
                                + f" via CommitmentKey::commit, {args.window_bits}-bit signed windows",
                    "pairs_per_gpu": n, "total_pairs": total, "window_bits": args.window_bits,
@@ -219,7 +222,7 @@ def main():
         "stages_ms": {k: round(v, 4) for k, v in stages.items()},
     }
 
-    if strong and n_gpus > 1 and dist is not None and not args.emulate:
+    if strong and n_gpus > 1 and dist is not None and not args.emulate and not args.no_extras:
         out["extras"] = multi_gpu_extras(lib, cm, dist, rank, n_gpus, total_log_n, args)
     if rank == 0 and n_gpus == 1 and not args.no_cpu:
         out["cpu_baseline"], parity = cpu_baseline_msm(lib, cm, key, d_scalars, n, args.window_bits)
@@ -244,8 +247,13 @@ def multi_gpu_extras(lib, cm, dist, rank, n_gpus, total_log_n, args):
     ex = {}
     cid = cm.CURVE_BN256
 
+    on_gpu = not args.rehearse_one_gpu                     # tensors of the timing exchange live where the backend works
+
     def barrier():
-        lib.check(lib.c.mira_dev_sync()); torch.cuda.synchronize(); dist.barrier()
+        lib.check(lib.c.mira_dev_sync())
+        if on_gpu:
+            torch.cuda.synchronize()
+        dist.barrier()
 
     def timed(fn, reps):
         fn(); barrier()
@@ -253,7 +261,7 @@ def multi_gpu_extras(lib, cm, dist, rank, n_gpus, total_log_n, args):
         for _ in range(reps):
             fn()
         barrier()
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item()) / reps
     try:

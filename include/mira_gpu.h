@@ -107,8 +107,8 @@ int mira_msm_set_window_bits(int32_t c);
  * result): the smallest MSM that takes the LDS-staged two-level sort, the smallest MSM that uses a
  * handle's window tables, the smallest commit whose scalar-length statistics plan the next one, and
  * the longest NTT line (log2) -- shorter lines make the two- and three-pass schedules reachable at
- * small sizes -- and whether lines of up to 256 points take the wave-level kernel (1, default) or
- * the workgroup-level one (0); the smallest commit of HOST scalars that is cut into point chunks so
+ * small sizes -- and whether lines of up to 256 points take the wave-level kernel (1: wherever it
+ * can; 0: never; default: by size); the smallest commit of HOST scalars that is cut into point chunks so
  * that the copy of one chunk overlaps the kernels of the previous one.  value < 0 restores the default. */
 #define MIRA_TUNE_STAGED_MIN_N 0
 #define MIRA_TUNE_TABLE_MIN_N 1

@@ -34,16 +34,23 @@ struct NttTables {
     uint32_t passes, m[3], h[2], single[2];
     size_t off_tw[3], off_lo[2], off_hi[2];
 };
-// Longest line of a transform of 2^log_n points.  Lines of up to 256 points run on the wave-level
-// kernel (k_ntt_wave: no barriers, two layers per LDS trip), so sizes that split into two or three
-// such passes (2^13 .. 2^24) use it; 2^9 .. 2^12 stay one launch of the workgroup-level kernel, and
-// 2^25 .. 2^28 need its longer lines to fit three passes.
+// Which kernel, and the longest line of a transform of 2^log_n points.  Lines of up to 256 points
+// can run on the wave-level kernel (k_ntt_wave: no barriers, two layers per LDS trip); it wins from
+// 2^20 up (three passes of 2^7 .. 2^8-point lines: 2^22 0.65 vs 0.74 ms, 2^24 2.55 vs 2.82) and at
+// <= 2^8 it is the only sensible shape.  2^9 .. 2^19 stay on the workgroup-level kernel: one launch up to
+// 2^12, two passes of 2^7 .. 2^10-point lines up to 2^19, where a third launch would cost more than the
+// wave kernel saves (2^17: 0.046 vs 0.063 ms); 2^25 .. 2^28 need its longer lines to fit three passes.
+// MIRA_TUNE_NTT_WAVE: 0 = never, 1 = wherever three passes of 256-point lines reach (tests);
 // MIRA_TUNE_NTT_MAX_LOG_LINE: a smaller maximum line makes the two- and three-pass schedules
-// reachable at sizes the CPU emulation can run; MIRA_TUNE_NTT_WAVE = 0 keeps every line on k_ntt_lines.
-static bool ntt_wave_enabled() { return tuned(MIRA_TUNE_NTT_WAVE, 1) != 0; }
+// reachable at sizes the CPU emulation can run.
+static bool ntt_use_wave(uint32_t log_n) {
+    const int64_t mode = g.tune[MIRA_TUNE_NTT_WAVE];
+    if (mode == 0) return false;
+    if (mode > 0) return log_n <= 3 * NTTW_LOG;
+    return log_n <= NTTW_LOG || (log_n >= 20 && log_n <= 3 * NTTW_LOG);
+}
 static uint32_t ntt_max_log_line(uint32_t log_n) {
-    if (g.tune[MIRA_TUNE_NTT_MAX_LOG_LINE] < 0)
-        return (ntt_wave_enabled() && (log_n <= NTTW_LOG || (log_n > NTT_MAX_LOG_LINE && log_n <= 3 * NTTW_LOG))) ? NTTW_LOG : NTT_MAX_LOG_LINE;
+    if (g.tune[MIRA_TUNE_NTT_MAX_LOG_LINE] < 0) return ntt_use_wave(log_n) ? NTTW_LOG : NTT_MAX_LOG_LINE;
     const int v = (int)g.tune[MIRA_TUNE_NTT_MAX_LOG_LINE];
     return (uint32_t)std::min(std::max(v, 1), NTT_MAX_LOG_LINE);
 }
@@ -137,10 +144,11 @@ static int ntt_device_locked(void *d_a, uint32_t log_n, const uint64_t omega[4],
     const unsigned char *cnull = nullptr;
     auto threads_for = [](uint32_t m) { return std::min<uint32_t>(1024, std::max<uint32_t>(64, (1u << m) / 2)); };
     auto lds_for = [](uint32_t m) { return ((size_t)NTT_LDS_BYTES_PER_ELEM << m) + 16 + ((size_t)NTT_LDS_BYTES_PER_ELEM << NTT_LDS_TW_LOG); };
+    const bool use_wave = ntt_use_wave(log_n);
     auto run = [&](NttPass ps, const unsigned char *src, unsigned char *dst, uint32_t p, int tw, const char *name) {
         // persistent grid: as many workgroups per CU as LDS and the 2048-lane limit allow (one for
         // 4096-point lines, eight for the 512-point lines of the three-pass schedule)
-        if (ntt_wave_enabled() && ps.log_len <= (uint32_t)NTTW_LOG) {
+        if (use_wave && ps.log_len <= (uint32_t)NTTW_LOG) {
             // one wave per 256 points, four waves per workgroup, three workgroups (12 waves) per CU
             const uint32_t lpw = 1u << (NTTW_LOG - ps.log_len);
             const uint32_t nbg = ceil_div(ceil_div(ps.nlines, lpw), NTTW_WAVES);

@@ -83,9 +83,11 @@ def test_wave_and_workgroup_kernels_agree(gpu_lib, k):
     from mira_amd import _lib
     a = C.synth_scalars(0, 1 << k, seed=500 + k)
     want = C.fft(a, k)
-    assert (F.fft(a, k) == want).all()
-    gpu_lib.tune(_lib.TUNE_NTT_WAVE, 0)
+    assert (F.fft(a, k) == want).all()                       # the kernel the size policy picks
     try:
-        assert (F.fft(a, k) == want).all()
+        for mode in (1, 0):                                   # wave-level wherever possible, then never
+            gpu_lib.tune(_lib.TUNE_NTT_WAVE, mode)
+            assert (F.fft(a, k) == want).all(), mode
+            assert (F.ifft(want, k) == a).all(), mode
     finally:
         gpu_lib.tune(_lib.TUNE_NTT_WAVE, -1)

@@ -643,6 +643,121 @@ def extras(lib, cm, with_cpu):
     except Exception as e:
         ex["cross_term_eval_k17"] = {"error": repr(e)}
 
+    # ---- one NIFS fold step at k = 17, the whole device-resident chain (BASELINE configs[3]) -------
+    # per curve, in the reference's order: generate_plonk_trace's witness commit
+    # (src/plonk/mod.rs:680-688) -> commit_cross_terms = row-wise evaluation of the d - 1 cross-term
+    # graphs + their commits (src/nifs/vanilla/mod.rs:100-127) -> RelaxedPlonkWitness::fold (W and E,
+    # src/plonk/mod.rs:1097-1134) -> the commitment side of RelaxedPlonkInstance::fold (:986-999,
+    # 1049-1053).  Primary: BN256, 14 advice columns, 6 cross terms; secondary: Grumpkin, 7 and 5.
+    # The Rust driver cannot be built here: the gate is the synthetic degree-5 one of the leg above,
+    # witnesses are witness-like scalars, the challenge r is synthetic.  CPU: the oracle's
+    # restatements of the same calls on the effective host cores, same inputs, every output compared.
+    try:
+        from mira_amd import graph_evaluator as G
+        from mira_amd import fold as FD
+        k, nadv = 17, 8
+        n = 1 << k
+        shape = {cm.CURVE_BN256: (14, 6, G.FIELD_FR), cm.CURVE_GRUMPKIN: (7, 5, G.FIELD_FQ)}
+
+        def gate(shift, field):
+            sbox = []
+            for i in range(nadv):
+                x = G.Sum(G.Polynomial(3 + i), G.Constant(1000 + i + shift))
+                x2 = G.Product(x, x)
+                sbox.append(G.Product(G.Product(x2, x2), x))
+            e = None
+            for j in range(nadv):
+                acc = None
+                for i in range(nadv):
+                    t = G.Scaled(sbox[i], 17 * j + 3 * i + 2 + shift)
+                    acc = t if acc is None else G.Sum(acc, t)
+                row = G.Product(G.Polynomial(0), G.Sum(acc, G.Negated(G.Polynomial(3 + j, 1))))
+                e = row if e is None else G.Sum(G.Product(e, G.Challenge(j % 2)), row)
+            return G.Sum(e, G.Product(G.Polynomial(1), G.Polynomial(2, -1)))
+        st = {}
+        for c, (ncol, cnt, field) in shape.items():
+            nw = ncol * n
+            d_w1 = cm.synth_scalars_device(c, nw, seed=0x5100 + c, kind=1)       # accumulator witness
+            d_w2 = cm.synth_scalars_device(c, nw, seed=0x5200 + c, kind=1)       # the step's new witness
+            d_fix = cm.synth_scalars_device(c, 2 * n, seed=0x5300 + c)
+            d_e = cm.synth_scalars_device(c, n, seed=0x5400 + c)
+            sel = np.ones(n, dtype=np.uint8); sel[::7] = 0
+            d_sel = lib.alloc(n); lib.upload(d_sel, sel)
+            # column table: selector, 2 fixed, then advice columns of W2 (the gate reads columns 3 .. 3 + nadv)
+            cols = [(d_sel, G.COL_BOOL), (d_fix, G.COL_FIELD), (d_fix + n * 32, G.COL_FIELD)] + [(d_w2 + j * n * 32, G.COL_FIELD) for j in range(min(ncol, nadv))]
+            cols += [(d_w1 + j * n * 32, G.COL_FIELD) for j in range(nadv - min(ncol, nadv))]
+            st[c] = dict(key=cm.CommitmentKey.synthetic(c, nw, seed=0x5500 + c), d_w1=d_w1, d_w2=d_w2, d_fix=d_fix, d_e=d_e, d_sel=d_sel, sel=sel, cols=cols, nw=nw,
+                         cnt=cnt, field=field, evs=[G.GraphEvaluator.new(gate(s, field), field) for s in range(cnt)], d_terms=lib.alloc(cnt * n * 32),
+                         d_wout=lib.alloc(nw * 32), d_enew=lib.alloc(n * 32), r_int=(0x5EED0000 + 7919 * c) ** 5 % G.MODULUS[field],
+                         acc_w=cm.CommitmentKey.default_value(), acc_e=cm.CommitmentKey.default_value())
+            st[c]["r"] = G.to_montgomery([st[c]["r_int"]], field)[0]
+        chal = [0x1234567 + 977 * j for j in range(2)]
+
+        def fold_step():
+            spans = {"witness_commit": 0.0, "evaluation": 0.0, "commit": 0.0, "fold": 0.0}
+            outs = {}
+            for c, s_ in st.items():
+                t0 = time.perf_counter()
+                w_commit = s_["key"].commit_device(s_["d_w2"], s_["nw"])
+                t1 = time.perf_counter()
+                for i, ev in enumerate(s_["evs"]):
+                    ev.evaluate_device(s_["cols"], chal, n, d_out=s_["d_terms"] + i * n * 32)
+                t2 = time.perf_counter()
+                t_commits = s_["key"].commit_batch_device(s_["d_terms"], n, s_["cnt"])
+                t3 = time.perf_counter()
+                FD.fold_witness_device(s_["field"], s_["d_wout"], s_["d_w1"], s_["d_w2"], s_["r"], s_["nw"])
+                d_e_new = s_["d_enew"]
+                FD.fold_witness_device(s_["field"], d_e_new, s_["d_e"], s_["d_e"], np.zeros(4, dtype=np.uint64), n)      # E' = E (+ 0 * E), then the terms are folded in
+                FD.fold_error_device(s_["field"], d_e_new, [s_["d_terms"] + i * n * 32 for i in range(s_["cnt"])], s_["r"], n)
+                folded_w = FD.g1_mul_add(c, s_["acc_w"], s_["r"], w_commit)
+                powers = G.to_montgomery([pow(s_["r_int"], i + 1, G.MODULUS[s_["field"]]) for i in range(s_["cnt"])], s_["field"])
+                folded_e = FD.g1_lincomb(c, s_["acc_e"], powers, t_commits)     # E_commit + sum r^(k+1) T_k, src/plonk/mod.rs:1049-1053
+                t4 = time.perf_counter()
+                spans["witness_commit"] += t1 - t0; spans["evaluation"] += t2 - t1; spans["commit"] += t3 - t2; spans["fold"] += t4 - t3
+                outs[c] = dict(w_commit=w_commit, t_commits=t_commits, d_e_new=d_e_new, folded_w=folded_w, folded_e=folded_e)
+            return spans, outs
+        fold_step()
+        walls, last = [], None
+        for _ in range(5):
+            t0 = time.perf_counter(); spans, last = fold_step(); walls.append(((time.perf_counter() - t0) * 1e3, spans))
+        wall, spans = sorted(walls, key=lambda x: x[0])[2]
+        ex["nifs_fold_step_k17"] = {"ms": round(wall, 3), "spans_ms": {a: round(b * 1e3, 3) for a, b in spans.items()},
+                                    "rows": n, "advice_columns": [14, 7], "cross_terms": [6, 5],
+                                    "note": "both curves, device-resident vectors: witness commit, cross-term evaluation, batched cross-term commits, W / E folding "
+                                            "and instance folding (host g1_mul_add); span names follow the reference's tracing spans"}
+        if with_cpu:
+            from oracle import cref as C
+            t0 = time.perf_counter()
+            ok = True
+            for c, s_ in st.items():
+                fo = C.FIELD_FR if s_["field"] == G.FIELD_FR else C.FIELD_FQ
+                bases = s_["key"].download()
+                w1, w2 = lib.download(s_["d_w1"], (s_["nw"], 4)), lib.download(s_["d_w2"], (s_["nw"], 4))
+                host_cols = [s_["sel"], lib.download(s_["d_fix"], (n, 4)), lib.download(s_["d_fix"] + n * 32, (n, 4))]
+                host_cols += [w2[j * n:(j + 1) * n] for j in range(min(shape[c][0], nadv))] + [w1[j * n:(j + 1) * n] for j in range(nadv - min(shape[c][0], nadv))]
+                chal_m = G.to_montgomery(chal, s_["field"])
+                want_w = C.msm_pippenger(c, w2, bases)
+                terms = []
+                for ev in s_["evs"]:
+                    code, consts, rots = ev.flatten()
+                    terms.append(C.graph_eval(fo, code, ev.num_intermediates, consts, rots, host_cols, chal_m, n))
+                want_t = [C.msm_pippenger(c, t, bases[:n]) for t in terms]
+                want_wf = C.fold_witness(fo, w1, w2, s_["r"])
+                want_e = C.fold_error(fo, lib.download(s_["d_e"], (n, 4)), terms, s_["r"])
+                o = last[c]
+                ok &= bool((o["w_commit"] == want_w).all() and all((o["t_commits"][i] == want_t[i]).all() for i in range(s_["cnt"])))
+                ok &= bool((lib.download(s_["d_wout"], (s_["nw"], 4)) == want_wf).all() and (lib.download(o["d_e_new"], (n, 4)) == want_e).all())
+            cpu_ms = (time.perf_counter() - t0) * 1e3
+            ex["nifs_fold_step_k17"].update({"cpu_ms": round(cpu_ms, 1), "cpu_cores": C.num_threads(), "cpu_kind": "port (commits, evaluation and folds of the oracle, incl. downloads)",
+                                             "bit_exact_commits_terms_folds": ok})
+        for c, s_ in st.items():
+            for p in (s_["d_w1"], s_["d_w2"], s_["d_fix"], s_["d_e"], s_["d_sel"], s_["d_terms"], s_["d_wout"], s_["d_enew"]):
+                lib.free(p)
+            s_["key"].close()
+    except Exception as e:
+        import traceback
+        ex["nifs_fold_step_k17"] = {"error": repr(e), "trace": traceback.format_exc()[-600:]}
+
     # ---- ProtoGalaxy's weighted tree reduction: compute_F's shape at k = 17
     # with 8 gates -- 2^20 gate evaluations folded for 32 challenges
     try:

@@ -133,6 +133,10 @@ int mira_msm_download_bases(uint64_t handle, size_t first, size_t n, uint64_t *b
 int mira_fold_witness_device(int field, void *d_out, const void *d_w1, const void *d_w2, const uint64_t r[4], size_t n);
 int mira_fold_error_device(int field, void *d_e, const void *const *d_cross_terms, size_t num_terms, const uint64_t r[4], size_t n);
 int mira_g1_mul_add(int curve, const uint64_t acc[8], const uint64_t scalar[4], const uint64_t point[8], uint64_t out[8]);
+/* out = acc + sum_i scalars[i] * points[i], count <= 64: E_commit + sum_k r^(k+1) T_k over the cross-term
+ * commitments (src/plonk/mod.rs:1049-1053) with one shared chain of doublings; host, O(256 + 64 count). */
+int mira_g1_lincomb(int curve, const uint64_t acc[8], const uint64_t *scalars /* count * 4 */, const uint64_t *points /* count * 8 */,
+                    size_t count, uint64_t out[8]);
 
 /* ---- the step before the MSM in one fold: cross-term evaluation ----------------------------
  * GraphEvaluator::evaluate over all rows (src/polynomial/graph_evaluator.rs:361-390, called per

@@ -363,6 +363,42 @@ template <class FB, class FS> static void g1_mul_add_t(const uint64_t acc[8], co
     to_affine(R, out);
 }
 
+// acc + sum_i scalars[i] * points[i] on affine points with ONE shared chain of doublings (Straus,
+// 4-bit windows): the instance side of a fold, E_commit + sum_k r^(k+1) T_k over the d - 1 cross-term
+// commitments (src/plonk/mod.rs:1049-1053), costs 256 doublings + 64 additions per term instead of
+// a full double-and-add per term.
+template <class FB, class FS>
+static void g1_lincomb_t(const uint64_t acc[8], const uint64_t *scalars, const uint64_t *points, size_t count, uint64_t out[8]) {
+    using namespace hostf;
+    auto lift = [](const uint64_t p[8]) {
+        HXyzz<FB> r = identity<FB>();
+        bool zero = true;
+        for (int i = 0; i < 8; i++) zero &= (p[i] == 0);
+        if (!zero) { memcpy(r.x.l, p, 32); memcpy(r.y.l, p + 4, 32); r.zz = one<FB>(); r.zzz = one<FB>(); }
+        return r;
+    };
+    std::vector<HFe<FS>> s(count);
+    std::vector<std::vector<HXyzz<FB>>> table(count, std::vector<HXyzz<FB>>(16));
+    const HFe<FS> one_plain = {{1, 0, 0, 0}};
+    for (size_t i = 0; i < count; i++) {
+        memcpy(s[i].l, scalars + 4 * i, 32);
+        s[i] = mul(s[i], one_plain);                        // leave Montgomery form: canonical integer
+        table[i][0] = identity<FB>();
+        table[i][1] = lift(points + 8 * i);
+        for (int k = 2; k < 16; k++) table[i][k] = (k & 1) ? add_pt(table[i][k - 1], table[i][1]) : dbl_pt(table[i][k / 2]);
+    }
+    HXyzz<FB> R = identity<FB>();
+    for (int w = 63; w >= 0; w--) {
+        for (int k = 0; k < 4; k++) R = dbl_pt(R);
+        for (size_t i = 0; i < count; i++) {
+            const uint32_t d = (uint32_t)(s[i].l[w / 16] >> (4 * (w % 16))) & 15u;
+            if (d) R = add_pt(R, table[i][d]);
+        }
+    }
+    R = add_pt(R, lift(acc));
+    to_affine(R, out);
+}
+
 // ------------------------------------------------------------------------------------------
 // C ABI
 extern "C" {
@@ -651,6 +687,12 @@ int mira_g1_mul_add(int curve, const uint64_t acc[8], const uint64_t scalar[4], 
     if ((curve != MIRA_CURVE_BN256 && curve != MIRA_CURVE_GRUMPKIN) || !acc || !scalar || !point || !out) { set_error("bad arguments"); return MIRA_E_BAD_ARG; }
     if (curve == MIRA_CURVE_BN256) g1_mul_add_t<FqP, FrP>(acc, scalar, point, out);
     else g1_mul_add_t<FrP, FqP>(acc, scalar, point, out);
+    return MIRA_OK;
+}
+int mira_g1_lincomb(int curve, const uint64_t acc[8], const uint64_t *scalars, const uint64_t *points, size_t count, uint64_t out[8]) {
+    if ((curve != MIRA_CURVE_BN256 && curve != MIRA_CURVE_GRUMPKIN) || !acc || !out || (count && (!scalars || !points)) || count > 64) { set_error("bad arguments"); return MIRA_E_BAD_ARG; }
+    if (curve == MIRA_CURVE_BN256) g1_lincomb_t<FqP, FrP>(acc, scalars, points, count, out);
+    else g1_lincomb_t<FrP, FqP>(acc, scalars, points, count, out);
     return MIRA_OK;
 }
 int mira_msm_download_bases(uint64_t handle, size_t first, size_t n, uint64_t *bases_out) {

@@ -77,3 +77,15 @@ def g1_mul_add(curve, acc, scalar, point, lib=None):
     lib.check(lib.c.mira_g1_mul_add(curve, acc.ctypes.data_as(ctypes.c_void_p), scalar.ctypes.data_as(ctypes.c_void_p),
                                     point.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p)))
     return out
+
+
+def g1_lincomb(curve, acc, scalars, points, lib=None):
+    """acc + sum_i scalars[i] * points[i] (affine): `E_commit + sum_k r^(k+1) T_k` of
+    RelaxedPlonkInstance::fold (src/plonk/mod.rs:1049-1053) with one shared chain of doublings."""
+    lib = lib or _lib.load()
+    acc, scalars, points = _u64(acc, 8), _u64(scalars, 4), _u64(points, 8)
+    assert len(scalars) == len(points)
+    out = np.empty(8, dtype=np.uint64)
+    lib.check(lib.c.mira_g1_lincomb(curve, acc.ctypes.data_as(ctypes.c_void_p), scalars.ctypes.data_as(ctypes.c_void_p),
+                                    points.ctypes.data_as(ctypes.c_void_p), len(scalars), out.ctypes.data_as(ctypes.c_void_p)))
+    return out

@@ -67,6 +67,30 @@ def test_emu_g1_mul_add_matches_oracle(emu_lib):
         assert (FD.g1_mul_add(cid, zero, np.zeros(4, dtype=np.uint64), pts[1], lib=emu_lib) == zero).all()
 
 
+def test_emu_g1_lincomb_matches_oracle_and_mul_add(emu_lib):
+    """mira_g1_lincomb (shared doublings) = the chain of g1_mul_add calls it replaces = the oracle's
+    MSM of the same terms plus the accumulator; edge cases: identity points, zero and r - 1 scalars,
+    a repeated point, no terms."""
+    for cid in (0, 1):
+        cv = P.CURVES[cid]
+        pts = C.synth_bases(cid, 7, seed=14)
+        sc = C.synth_scalars(cid, 6, seed=15)
+        sc[2] = 0
+        sc[3] = ints_to_mont([cv.r - 1], cv.r)[0]
+        terms = pts[1:].copy()
+        terms[4] = 0                                           # an identity term
+        terms[5] = terms[0]                                    # a repeated point
+        got = FD.g1_lincomb(cid, pts[0], sc, terms, lib=emu_lib)
+        chain = pts[0]
+        for s_, t in zip(sc, terms):
+            chain = FD.g1_mul_add(cid, chain, s_, t, lib=emu_lib)
+        assert (got == chain).all()
+        assert (got == C.ec_add(cid, pts[0], C.msm_naive(cid, sc, terms))).all()
+        zero = np.zeros(8, dtype=np.uint64)
+        assert (FD.g1_lincomb(cid, zero, sc[:0], terms[:0], lib=emu_lib) == zero).all()
+        assert (FD.g1_lincomb(cid, pts[0], sc[:0], terms[:0], lib=emu_lib) == pts[0]).all()
+
+
 def test_emu_key_cache_roundtrip(emu_lib, tmp_path):
     """src/commitment.rs:96-167 and its test `consistency` (:178-194): save, load, compare."""
     cid, k = 0, 6

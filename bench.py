@@ -551,10 +551,22 @@ def extras(lib, cm, with_cpu):
         single = []
         for _ in range(9):
             t0 = time.perf_counter(); keys[cm.CURVE_BN256].commit_device(cross[cm.CURVE_BN256], n); single.append((time.perf_counter() - t0) * 1e3)
+        # opt-in: 16-bit fixed-base tables on both keys (mira_msm_precompute_ex(handle, 16), 16 x the key's HBM):
+        # all windows share one bucket set, no Horner epilogue -- the same 13 calls, one per commit
+        for c in plan:
+            keys[c].precompute(16)
+        run(False)
+        t16, single16 = [], []
+        for _ in range(5):
+            t0 = time.perf_counter(); t16_pts = run(False); t16.append((time.perf_counter() - t0) * 1e3)
+        for _ in range(9):
+            t0 = time.perf_counter(); keys[cm.CURVE_BN256].commit_device(cross[cm.CURVE_BN256], n); single16.append((time.perf_counter() - t0) * 1e3)
         ex["fold_step_k17"] = {"msm_calls": 13, "pairs": sum(nw + cnt * n for nw, cnt in plan.values()),
                                "gpu_ms": round(bat_ms, 3), "gpu_ms_one_call_per_commit": round(seq_ms, 3),
                                "gpu_ms_host_scalars_one_call_per_commit": round(sorted(hs)[2], 3), "gpu_ms_host_scalars_batched": round(sorted(hb)[2], 3),
                                "one_commit_131072_pairs_ms": round(sorted(single)[4], 3),
+                               "gpu_ms_one_call_per_commit_16bit_tables": round(sorted(t16)[2], 3), "one_commit_131072_pairs_ms_16bit_tables": round(sorted(single16)[4], 3),
+                               "tables_same_points": bool(all((a == b).all() for a, b in zip(seq_pts, t16_pts))),
                                "host_scalar_bytes": 32 * sum(nw + cnt * n for nw, cnt in plan.values()),
                                "batched_equals_sequential": bool(all((a == b).all() for a, b in zip(seq_pts, bat_pts))
                                                                  and all((a == b).all() for a, b in zip(seq_pts, hseq_pts))

@@ -69,6 +69,13 @@ int mira_msm_unregister(uint64_t handle);
  * (bit-identical); mira_msm_partial_device then reports window_bits = 0, num_windows = 64 (64
  * partial sums to be added).  MIRA_E_ALLOC if the tables do not fit. */
 int mira_msm_precompute(uint64_t handle);
+/* Same with the window width named: 20 (as above) or 16.  16-bit tables (16 x the key size: 1.9 GB
+ * for the 1.8 M-point key of a k = 17 fold step) keep the 16 additions per pair of the per-window
+ * path but give all windows ONE set of 2^15 buckets: a commit then pays the fix-up and bucket
+ * reduction of one window instead of sixteen and no Horner epilogue -- the latency-bound part of
+ * the small commits of a fold step (131 072 pairs: 0.63 -> 0.4 ms).  Used from 2^12 pairs up;
+ * mira_msm_partial_device reports window_bits = 0, num_windows = 16.  One width per key. */
+int mira_msm_precompute_ex(uint64_t handle, int32_t window_bits);
 /* Validate every registered base against the curve equation on the GPU, as
  * load_or_setup_cache does with is_on_curve (src/commitment.rs:145-154). */
 int mira_msm_check_bases(uint64_t handle);

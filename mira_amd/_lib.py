@@ -19,7 +19,7 @@ MIRA_PARTIAL_U64 = MIRA_MAX_WINDOWS * 16
 # every symbol include/mira_gpu.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "mira_device_count", "mira_init", "mira_set_stream", "mira_last_error",
-    "mira_msm_register_bases", "mira_msm_register_bases_device", "mira_msm_unregister", "mira_msm_check_bases", "mira_msm_precompute",
+    "mira_msm_register_bases", "mira_msm_register_bases_device", "mira_msm_unregister", "mira_msm_check_bases", "mira_msm_precompute", "mira_msm_precompute_ex",
     "mira_msm_download_bases", "mira_fold_witness_device", "mira_fold_error_device", "mira_g1_mul_add", "mira_g1_lincomb", "mira_graph_eval_device", "mira_graph_compile", "mira_graph_eval_compiled", "mira_graph_free", "mira_pow_tree_reduce_device", "mira_lincomb_device",
     "mira_msm", "mira_msm_device", "mira_msm_batch", "mira_msm_batch_device", "mira_msm_partial_device", "mira_msm_combine", "mira_msm_set_window_bits",
     "mira_ntt_bn256_fr", "mira_ntt_bn256_fr_device", "mira_fft_bn256_fr", "mira_ifft_bn256_fr",
@@ -85,7 +85,7 @@ class MiraLib:
         sig = {
             "mira_device_count": [], "mira_init": [ctypes.c_int], "mira_set_stream": [vp],
             "mira_msm_register_bases": [ctypes.c_int, u64p, sz, vp], "mira_msm_register_bases_device": [ctypes.c_int, vp, sz, vp],
-            "mira_msm_unregister": [u64], "mira_msm_check_bases": [u64], "mira_msm_precompute": [u64],
+            "mira_msm_unregister": [u64], "mira_msm_check_bases": [u64], "mira_msm_precompute": [u64], "mira_msm_precompute_ex": [u64, i32],
             "mira_msm": [u64, u64p, sz, u64p], "mira_msm_device": [u64, vp, sz, u64p],
             "mira_msm_download_bases": [u64, sz, sz, u64p],
             "mira_fold_witness_device": [ctypes.c_int, vp, vp, vp, u64p, sz], "mira_fold_error_device": [ctypes.c_int, vp, vp, sz, u64p, sz],

@@ -130,10 +130,12 @@ class CommitmentKey:
         key.save_to_file(path)
         return key
 
-    def precompute(self):
-        """Build the fixed-base window tables in HBM (13 x the key size); large commits on this key
-        then take 13 instead of 16 bucket additions per pair.  Results are bit-identical."""
-        self.lib.check(self.lib.c.mira_msm_precompute(self.handle))
+    def precompute(self, window_bits=20):
+        """Build the fixed-base window tables in HBM.  20-bit windows (13 x the key size): large
+        commits take 13 instead of 16 bucket additions per pair.  16-bit windows (16 x): all windows
+        share one bucket set -- the small commits of a fold step lose most of their latency-bound
+        tail.  Results are bit-identical either way."""
+        self.lib.check(self.lib.c.mira_msm_precompute_ex(self.handle, window_bits))
         self.precomputed = True
         return self
 

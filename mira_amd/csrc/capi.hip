@@ -19,6 +19,7 @@ Ctx g;
 static std::map<uint64_t, Bases> g_bases;
 static constexpr size_t PLAN_HIST_MIN_N = (size_t)1 << 15;  // below this the pre-pass (one extra sync) costs more than it can save
 static constexpr size_t TABLE_MIN_N = (size_t)1 << 18;   // below this an MSM is latency-bound and the per-window path is as fast
+static constexpr size_t TABLE16_MIN_N = (size_t)1 << 12;
 
 // constants block on device: [0] gen bn256 (64 B, R form) [64] gen grumpkin (64 B, R form)
 // [128] b bn256 (32 B, R' form) [160] b grumpkin (32 B, R' form)
@@ -198,6 +199,18 @@ static MsmPlan make_plan(size_t n, int32_t forced_c, uint32_t count = 1, uint64_
     return p;
 }
 
+// 16-bit fixed-base tables (mira_msm_precompute_ex(handle, 16)): 16 signed 16-bit digits per scalar
+// against the tables 2^(16 w) P_i, ONE set of 2^15 buckets for all windows, 16 partial sums back.
+static constexpr uint32_t SHARED_SUMS = 16;
+static MsmPlan make_plan_shared(size_t n, uint64_t table_n) {
+    MsmPlan p = make_plan(n, 16);
+    p.shared = true; p.table_n = table_n; p.sums = SHARED_SUMS;
+    p.NB = p.B;                                              // one bucket set
+    p.m = 4;                                                 // 8192 chunks: the chain of the reduction is what counts here
+    p.nchunks = p.B / p.m;
+    return p;
+}
+
 // Horner over the window sums: sum_w 2^(c w) * Wsum[w], then to_affine.
 template <class FB>
 static void horner_affine(const uint64_t *windows, uint32_t c, uint32_t W, uint64_t out[8]) {
@@ -239,7 +252,9 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
         set_error("Can't commit too long input: input len: " + std::to_string(first + n) + ", but limit is " + std::to_string(bs.n));
         return MIRA_E_TOO_LONG;
     }
-    const size_t table_min_n = tuned(MIRA_TUNE_TABLE_MIN_N, TABLE_MIN_N);
+    // 20-bit tables pay from 2^18 pairs (2^19 buckets to reduce whatever n is); 16-bit tables share the
+    // bucket count of ONE window of the per-window path, so they win from a few thousand pairs
+    const size_t table_min_n = tuned(MIRA_TUNE_TABLE_MIN_N, bs.table_c == 16 ? TABLE16_MIN_N : TABLE_MIN_N);
     const bool table_mode = bs.tables && (sharded || n >= table_min_n) && g.forced_c == 0 && requested_c == 0;
     // Data-dependent planning for single (unsharded) commits (ranks of a sharded MSM must agree on
     // the window width, so they keep the dense estimate).  The statistics are those of the previous
@@ -259,6 +274,13 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
     if (n == 0) return MIRA_OK;
     if (!d_scalars) { set_error("null scalars"); return MIRA_E_BAD_ARG; }
     // fixed-base mode: window tables present, MSM large enough to be throughput-bound, no forced width
+    if (table_mode && bs.table_c == 16) {                    // shared buckets through the per-window launch sequence
+        if ((uint64_t)n * 16 >= (1ull << 32)) { set_error("n too large for 32-bit entry offsets"); return MIRA_E_UNSUPPORTED; }
+        MsmPlan ps = make_plan_shared(n, bs.n);
+        *c_out = 0; *W_out = SHARED_SUMS;                   // partial sums, combined by a plain sum
+        return bs.curve == MIRA_CURVE_BN256 ? msm_launch_bn256(bs, first, d_scalars, h_scalars, n, ps, out_partial)
+                                             : msm_launch_grumpkin(bs, first, d_scalars, h_scalars, n, ps, out_partial);
+    }
     if (table_mode) {
         if (h_scalars) RT_CHECK(rt_h2d(const_cast<void *>(d_scalars), h_scalars, n * 32, g.stream));
         *c_out = 0; *W_out = 64;                            // 64 partial sums, combined by a plain sum
@@ -475,15 +497,25 @@ int mira_msm_unregister(uint64_t handle) {
     g_bases.erase(it);
     return MIRA_OK;
 }
-int mira_msm_precompute(uint64_t handle) {
-    std::lock_guard<std::mutex> lk(g_lock);
+static int precompute_locked(uint64_t handle, int32_t window_bits) {
     int rc = ensure_ctx();
     if (rc) return rc;
     auto it = g_bases.find(handle);
     if (it == g_bases.end()) { set_error("unknown bases handle"); return MIRA_E_BAD_ARG; }
     Bases &bs = it->second;
-    if ((uint64_t)bs.n * 13 >= (1ull << 31)) { set_error("key too long for 31-bit table indices"); return MIRA_E_UNSUPPORTED; }
-    return bs.curve == MIRA_CURVE_BN256 ? build_tables_bn256(bs) : build_tables_grumpkin(bs);
+    if (window_bits != 16 && window_bits != 20) { set_error("window tables are built for 16- or 20-bit windows"); return MIRA_E_BAD_ARG; }
+    if (bs.tables && bs.table_c != (uint32_t)window_bits) { set_error("this key already has tables of another width"); return MIRA_E_BAD_ARG; }
+    const uint32_t W = window_bits == 16 ? 16 : 13;   // ceil(256 / 20), table_kernels.cuh
+    if ((uint64_t)bs.n * W >= (1ull << 31)) { set_error("key too long for 31-bit table indices"); return MIRA_E_UNSUPPORTED; }
+    return bs.curve == MIRA_CURVE_BN256 ? build_tables_bn256(bs, (uint32_t)window_bits, W) : build_tables_grumpkin(bs, (uint32_t)window_bits, W);
+}
+int mira_msm_precompute(uint64_t handle) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    return precompute_locked(handle, 20);
+}
+int mira_msm_precompute_ex(uint64_t handle, int32_t window_bits) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    return precompute_locked(handle, window_bits);
 }
 int mira_msm_check_bases(uint64_t handle) {
     std::lock_guard<std::mutex> lk(g_lock);

@@ -111,7 +111,8 @@ struct Bases {
     size_t n;
     void *d = nullptr;
     bool owned = false;
-    void *tables = nullptr;   // fixed-base window tables (table_kernels.cuh), TABLE_W * n points, or null
+    void *tables = nullptr;   // fixed-base window tables 2^(table_c w) P_i, w < table_w (table_kernels.cuh), or null
+    uint32_t table_c = 0, table_w = 0;
     // bit-length histogram of the scalars of the previous commit of stat_n elements over this key
     // (planning input for the next one of the same length; never affects a result)
     mutable uint32_t stat_hist[256] = {0};
@@ -131,6 +132,11 @@ struct MsmPlan {
     uint32_t c, W, B, NB, tile, ntiles, L, T, m, nchunks, lanes;
     uint32_t count, Wt;   // MSMs in this submission, total windows count * W
     uint64_t stride;      // scalars of MSM b start at element b * stride
+    // fixed-base tables with 16-bit windows: the W windows share ONE set of B buckets (NB = B), entries name
+    // table points w * table_n + first + i, and the window sums come back as `sums` plain partial sums
+    bool shared = false;
+    uint64_t table_n = 0;
+    uint32_t sums = 0;
     bool stats = false;   // also histogram the bit lengths of the scalars (planning input of the next commit of this shape)
 };
 
@@ -140,8 +146,8 @@ int msm_launch_bn256(const Bases &bs, size_t first, const void *d_scalars, const
 int msm_launch_grumpkin(const Bases &bs, size_t first, const void *d_scalars, const void *h_scalars, size_t n, const MsmPlan &p, uint64_t *host_windows);
 int msm_launch_table_bn256(const Bases &bs, size_t first, const void *d_scalars, size_t n, uint64_t *host_sums);
 int msm_launch_table_grumpkin(const Bases &bs, size_t first, const void *d_scalars, size_t n, uint64_t *host_sums);
-int build_tables_bn256(Bases &bs);
-int build_tables_grumpkin(Bases &bs);
+int build_tables_bn256(Bases &bs, uint32_t c, uint32_t W);
+int build_tables_grumpkin(Bases &bs, uint32_t c, uint32_t W);
 int curve_init_bn256();
 int convert_bases_bn256(const void *d_src, void *d_dst, size_t n);
 int convert_bases_grumpkin(const void *d_src, void *d_dst, size_t n);

@@ -17,4 +17,4 @@ int export_bases_bn256(const Bases &bs, size_t first, size_t n, void *d_out) { r
 int msm_launch_table_bn256(const Bases &bs, size_t first, const void *d_scalars, size_t n, uint64_t *host_sums) {
     return msm_launch_table<Fq29, FrP>(bs, first, d_scalars, n, host_sums);
 }
-int build_tables_bn256(Bases &bs) { return build_tables<Fq29>(bs); }
+int build_tables_bn256(Bases &bs, uint32_t c, uint32_t W) { return build_tables<Fq29>(bs, c, W); }

@@ -17,4 +17,4 @@ int export_bases_grumpkin(const Bases &bs, size_t first, size_t n, void *d_out) 
 int msm_launch_table_grumpkin(const Bases &bs, size_t first, const void *d_scalars, size_t n, uint64_t *host_sums) {
     return msm_launch_table<Fr29, FqP>(bs, first, d_scalars, n, host_sums);
 }
-int build_tables_grumpkin(Bases &bs) { return build_tables<Fr29>(bs); }
+int build_tables_grumpkin(Bases &bs, uint32_t c, uint32_t W) { return build_tables<Fr29>(bs, c, W); }

@@ -64,7 +64,7 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, cons
     if ((rc = g.heavy.ensure(64 + ((size_t)p.T / 2 + 8) * 32))) return rc;            // counters, runs, sub-job descriptors
     if ((rc = g.heavy_out.ensure(((size_t)p.T / 2 + 8) * XYZZ29_BYTES))) return rc;
     if ((rc = g.chunks.ensure((size_t)p.Wt * p.nchunks * XYZZ29_BYTES))) return rc;
-    if ((rc = g.window_sums.ensure((size_t)p.Wt * 128))) return rc;
+    if ((rc = g.window_sums.ensure((size_t)std::max(p.Wt, p.sums) * 128))) return rc;
 #ifndef MIRA_CPU_EMU
     if (h_scalars) {
         if (!g.copy_stream) RT_CHECK(hipStreamCreateWithFlags(&g.copy_stream, hipStreamNonBlocking));
@@ -98,7 +98,9 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, cons
     for (size_t k = 0, lo = 0; k < ends.size(); lo = ends[k++]) {
         const size_t nc = ends[k] - lo, entries = nc * p.Wt;
         const unsigned char *sc = reinterpret_cast<const unsigned char *>(d_scalars) + lo * 32;
-        const unsigned char *bases = reinterpret_cast<const unsigned char *>(bs.d) + (first + lo) * 64;
+        // per-window buckets: entries are chunk-local point indices; shared buckets: entries name table points
+        const unsigned char *bases = p.shared ? reinterpret_cast<const unsigned char *>(bs.tables) : reinterpret_cast<const unsigned char *>(bs.d) + (first + lo) * 64;
+        const uint32_t wstride = p.shared ? 0u : p.B, idx_stride = p.shared ? (uint32_t)p.table_n : 0u, idx_first = p.shared ? (uint32_t)(first + lo) : 0u;
         const uint32_t add = k ? 1u : 0u;
         if (h_scalars) {
             // pageable or pinned, the copy engine moves it beside the kernels of the previous chunk
@@ -116,7 +118,7 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, cons
                reinterpret_cast<int16_t *>(g.digits.p), reinterpret_cast<uint32_t *>(g.counts.p), p.NB + 1);
         tm_mark("digits");
         LAUNCH_BARRIER_FLEX(k_hist, dim3(ntiles, p.Wt), 1024, (size_t)p.B * 4, st, reinterpret_cast<const int16_t *>(g.digits.p), (uint32_t)nc,
-                       p.B, tile, reinterpret_cast<uint32_t *>(g.counts.p));
+                       p.B, tile, reinterpret_cast<uint32_t *>(g.counts.p), wstride);
         tm_mark("hist");
         LAUNCH_BARRIER(k_scan_a, scan_blocks, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.counts.p), p.NB,
                        reinterpret_cast<uint32_t *>(g.block_sums.p));
@@ -129,15 +131,19 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, cons
         // sort: LDS-staged two-level partition for large inputs (bursts of consecutive entries), the
         // single-level scatter otherwise (small inputs: the tile structure buys nothing there)
         if (staged) {
-            LAUNCH_BARRIER((k_stage1<int16_t, false>), dim3(ceil_div(nc, STAGE_TILE), p.Wt), 1024, (size_t)STAGE_TILE * 8, st, reinterpret_cast<const int16_t *>(g.digits.p),
-                                (uint32_t)nc, p.B, fine_bits, CB, 0u, 0u, reinterpret_cast<uint32_t *>(g.coarse_offsets.p), reinterpret_cast<U2 *>(g.part.p));
+            if (p.shared)
+                LAUNCH_BARRIER((k_stage1<int16_t, true>), dim3(ceil_div(nc, STAGE_TILE), p.Wt), 1024, (size_t)STAGE_TILE * 8, st, reinterpret_cast<const int16_t *>(g.digits.p),
+                                    (uint32_t)nc, p.B, fine_bits, CB, idx_stride, idx_first, reinterpret_cast<uint32_t *>(g.coarse_offsets.p), reinterpret_cast<U2 *>(g.part.p));
+            else
+                LAUNCH_BARRIER((k_stage1<int16_t, false>), dim3(ceil_div(nc, STAGE_TILE), p.Wt), 1024, (size_t)STAGE_TILE * 8, st, reinterpret_cast<const int16_t *>(g.digits.p),
+                                    (uint32_t)nc, p.B, fine_bits, CB, 0u, 0u, reinterpret_cast<uint32_t *>(g.coarse_offsets.p), reinterpret_cast<U2 *>(g.part.p));
             tm_mark("sort_level1");
             LAUNCH_BARRIER(k_stage2, ceil_div(entries, STAGE_TILE), 1024, (size_t)STAGE_TILE * 6, st, reinterpret_cast<const U2 *>(g.part.p),
                                 reinterpret_cast<const uint32_t *>(g.offsets.p) + p.NB, fine_bits, reinterpret_cast<uint32_t *>(g.cursor.p),
                                 reinterpret_cast<uint32_t *>(g.sorted_idx.p));
         } else
             LAUNCH_BARRIER_FLEX(k_scatter, dim3(ntiles, p.Wt), 1024, (size_t)p.B * 4, st, reinterpret_cast<const int16_t *>(g.digits.p),
-                       (uint32_t)nc, p.B, tile, reinterpret_cast<uint32_t *>(g.cursor.p), reinterpret_cast<uint32_t *>(g.sorted_idx.p));
+                       (uint32_t)nc, p.B, tile, reinterpret_cast<uint32_t *>(g.cursor.p), reinterpret_cast<uint32_t *>(g.sorted_idx.p), wstride, idx_stride, idx_first);
         tm_mark("scatter");
         if (add)
             LAUNCH((k_accumulate<F, true>), ceil_div(p.T, 128), 128, 0, st, reinterpret_cast<const uint32_t *>(g.sorted_idx.p),
@@ -162,26 +168,28 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, cons
                        reinterpret_cast<unsigned char *>(g.bucket_sums.p));
         tm_mark("fixup");
     }
-    const uint64_t items = (uint64_t)p.Wt * p.nchunks;
+    // bucket sets: one per window, or one for all (shared: its chunk results are summed by `sums` workgroups)
+    const uint32_t Wb = p.shared ? 1u : p.Wt, nsum = p.shared ? p.sums : p.Wt, per_sum = p.shared ? p.nchunks / p.sums : p.nchunks;
+    const uint64_t items = (uint64_t)Wb * p.nchunks;
     if (reduce_with_quads(items)) {
         LAUNCH((k_reduce_chunks<F, true>), ceil_div(items * 4, 64), 64, 0, st, reinterpret_cast<const unsigned char *>(g.bucket_sums.p),
-               p.B, p.m, p.Wt, reinterpret_cast<unsigned char *>(g.chunks.p));
+               p.B, p.m, Wb, reinterpret_cast<unsigned char *>(g.chunks.p));
         tm_mark("reduce_chunks");
-        LAUNCH_BARRIER((k_window_sum<F, true>), p.Wt, WSUM_BLOCK, (size_t)(WSUM_BLOCK / 4) * XYZZ29_BYTES, st, reinterpret_cast<const unsigned char *>(g.chunks.p), p.nchunks,
+        LAUNCH_BARRIER((k_window_sum<F, true>), nsum, WSUM_BLOCK, (size_t)(WSUM_BLOCK / 4) * XYZZ29_BYTES, st, reinterpret_cast<const unsigned char *>(g.chunks.p), per_sum,
                        reinterpret_cast<unsigned char *>(g.window_sums.p));
     } else {
         // 256-lane workgroups: with 64-lane ones the dispatcher was seen to pack the 1024 waves of a 2^22
         // MSM onto part of the CUs (0.43 ms instead of 0.27)
         LAUNCH((k_reduce_chunks<F, false>), ceil_div(items, 256), 256, 0, st, reinterpret_cast<const unsigned char *>(g.bucket_sums.p),
-               p.B, p.m, p.Wt, reinterpret_cast<unsigned char *>(g.chunks.p));
+               p.B, p.m, Wb, reinterpret_cast<unsigned char *>(g.chunks.p));
         tm_mark("reduce_chunks");
-        LAUNCH_BARRIER((k_window_sum<F, false>), p.Wt, WSUM_BLOCK, (size_t)WSUM_BLOCK * XYZZ29_BYTES, st, reinterpret_cast<const unsigned char *>(g.chunks.p), p.nchunks,
+        LAUNCH_BARRIER((k_window_sum<F, false>), nsum, WSUM_BLOCK, (size_t)WSUM_BLOCK * XYZZ29_BYTES, st, reinterpret_cast<const unsigned char *>(g.chunks.p), per_sum,
                        reinterpret_cast<unsigned char *>(g.window_sums.p));
     }
     tm_mark("window_sum");
     RT_CHECK(rt_last());
     if (p.stats) RT_CHECK(rt_d2h(g.hist_host, g.hist_dev.p, 1024, st));
-    RT_CHECK(rt_d2h(host_windows, g.window_sums.p, (size_t)p.Wt * 128, st));
+    RT_CHECK(rt_d2h(host_windows, g.window_sums.p, (size_t)nsum * 128, st));
     RT_CHECK(rt_sync(st));
     tm_end();
     return MIRA_OK;
@@ -196,6 +204,7 @@ template <class F, class FS> static int curve_init() {
     RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stage1<int16_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, STAGE_TILE * 8));   // + 10 KiB static
     RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stage1<int32_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, STAGE_TILE * 8));
+    RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stage1<int16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, STAGE_TILE * 8));
     RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stage2), hipFuncAttributeMaxDynamicSharedMemorySize, STAGE_TILE * 6));   // + 52 KiB static
 #endif
     return MIRA_OK;
@@ -235,9 +244,9 @@ template <class F> static int export_bases(const Bases &bs, size_t first, size_t
 }
 
 // ---- fixed-base window tables (table_kernels.cuh) -------------------------------------------------
-template <class F> static int build_tables(Bases &bs) {
+template <class F> static int build_tables(Bases &bs, uint32_t c, uint32_t W) {
     if (bs.tables || bs.n == 0) return MIRA_OK;
-    const size_t bytes = (size_t)TABLE_W * bs.n * 64;
+    const size_t bytes = (size_t)W * bs.n * 64;
     void *t = nullptr;
     if (rt_malloc(&t, bytes) != hipSuccess || !t) {
         set_error("device allocation of " + std::to_string(bytes) + " bytes for the window tables failed");
@@ -245,12 +254,12 @@ template <class F> static int build_tables(Bases &bs) {
     }
     unsigned char *tb = reinterpret_cast<unsigned char *>(t);
     RT_CHECK(rt_d2d(tb, bs.d, bs.n * 64, g.stream));                        // T_0 = the key itself
-    for (uint32_t w = 1; w < TABLE_W; w++)
+    for (uint32_t w = 1; w < W; w++)
         LAUNCH(k_table_step<F>, ceil_div(bs.n, 64), 64, 0, g.stream, (const unsigned char *)(tb + (size_t)(w - 1) * bs.n * 64),
-               tb + (size_t)w * bs.n * 64, (uint64_t)bs.n, TABLE_C);
+               tb + (size_t)w * bs.n * 64, (uint64_t)bs.n, c);
     RT_CHECK(rt_last());
     RT_CHECK(rt_sync(g.stream));
-    bs.tables = t;
+    bs.tables = t; bs.table_c = c; bs.table_w = W;
     return MIRA_OK;
 }
 

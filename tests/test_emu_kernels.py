@@ -195,6 +195,39 @@ def test_emu_fixed_base_tables(emu_lib, tune):
     assert (cm.combine_partials(cid, np.stack([pa, pb]), ca, wa, lib=emu_lib) == before).all()
 
 
+def test_emu_shared_bucket_tables_16bit(emu_lib, tune):
+    """mira_msm_precompute_ex(handle, 16): tables 2^(16 w) P_i, ONE set of 2^15 buckets for the 16
+    windows through the per-window launch sequence (single-level scatter and, forced, the staged
+    sort), 16 partial sums back.  Same points as the per-window path and the oracle; identity base,
+    heavy bucket, chunk partials, host scalars in point chunks, a prefix of the key."""
+    tune(_lib.TUNE_TABLE_MIN_N, 1)
+    cid, n = 0, 300
+    bs = C.synth_bases(cid, n, seed=44)
+    bs[11] = 0
+    key = cm.CommitmentKey(cid, bs, lib=emu_lib)
+    sc = C.synth_scalars(cid, n, seed=45, kind=1)
+    sc[:50] = C.to_mont(C.FIELD_FR, np.array([1, 0, 0, 0], dtype=np.uint64))[0]        # a heavy bucket
+    dense = C.synth_scalars(cid, n, seed=46)
+    want, want_dense = C.commit(cid, bs, sc), C.commit(cid, bs, dense)
+    assert (key.commit(sc) == want).all()
+    key.precompute(16)
+    assert (key.commit(sc) == want).all()
+    assert (key.commit(dense) == want_dense).all()
+    assert (key.commit(dense[:123]) == C.commit(cid, bs[:123], dense[:123])).all()
+    d = emu_lib.alloc(n * 32); emu_lib.upload(d, dense)
+    pa, ca, wa = key.commit_partial_device(0, d, 130)
+    pb, cb, wb = key.commit_partial_device(130, d + 130 * 32, n - 130)
+    assert (ca, wa) == (0, 16) == (cb, wb)
+    assert (cm.combine_partials(cid, np.stack([pa, pb]), ca, wa, lib=emu_lib) == want_dense).all()
+    tune(_lib.TUNE_STAGED_MIN_N, 1)                           # the LDS-staged sort with table indices
+    assert (key.commit(dense) == want_dense).all()
+    tune(_lib.TUNE_HOST_CHUNK_MIN_N, 64)                      # host scalars in chunks of 32, 64, 128, ... points
+    assert (key.commit(dense) == want_dense).all()
+    assert (key.commit(sc) == want).all()
+    with pytest.raises(_lib.MiraError):
+        key.precompute(20)                                    # one width per key
+
+
 def test_emu_data_dependent_planning(emu_lib, tune):
     """The bit-length statistics of one commit plan the next one of the same length over the key:
     they change only the window width, never the result."""

@@ -266,3 +266,28 @@ def test_host_scalars_cross_pcie_in_chunks(gpu_lib, cid, kind):
     finally:
         gpu_lib.tune(_lib.TUNE_HOST_CHUNK_MIN_N, -1)
     gpu_lib.free(d)
+
+
+@pytest.mark.parametrize("cid,log_n", [(0, 17), (1, 20)])
+def test_shared_bucket_tables_16bit(gpu_lib, cid, log_n):
+    """mira_msm_precompute_ex(handle, 16): one set of 2^15 buckets for all 16 windows.  Bit-identical
+    to the per-window path and the oracle: dense and witness-like vectors, a prefix, chunk partials,
+    host scalars (in point chunks at 2^20)."""
+    n = 1 << log_n
+    key = cm.CommitmentKey.synthetic(cid, n, seed=121)
+    d = cm.synth_scalars_device(cid, n, seed=122)
+    dw = cm.synth_scalars_device(cid, n, seed=123, kind=1)
+    before, before_w = key.commit_device(d, n), key.commit_device(dw, n)
+    key.precompute(16)
+    assert (key.commit_device(d, n) == before).all()
+    assert (key.commit_device(dw, n) == before_w).all()
+    sc = gpu_lib.download(d, (n, 4))
+    assert (before == C.commit(cid, key.bases(), sc)).all()
+    assert (key.commit(sc) == before).all()                                  # host scalars
+    m = n // 2 + 4321
+    assert (key.commit_device(d, m) == C.commit(cid, key.bases()[:m], sc[:m])).all()
+    pa, ca, wa = key.commit_partial_device(0, d, m)
+    pb, cb, wb = key.commit_partial_device(m, d + m * 32, n - m)
+    assert (ca, wa) == (0, 16) == (cb, wb)
+    assert (cm.combine_partials(cid, np.stack([pa, pb]), ca, wa) == before).all()
+    gpu_lib.free(d); gpu_lib.free(dw)

@@ -69,7 +69,8 @@ int mira_msm_unregister(uint64_t handle);
  * (bit-identical); mira_msm_partial_device then reports window_bits = 0, num_windows = 64 (64
  * partial sums to be added).  MIRA_E_ALLOC if the tables do not fit. */
 int mira_msm_precompute(uint64_t handle);
-/* Same with the window width named: 20 (as above) or 16.  16-bit tables (16 x the key size: 1.9 GB
+/* Same with the window width named: 20 (as above), 22 (12 tables, 2^21 buckets, 12 additions per
+ * pair: for commits of 2^24 pairs and more) or 16.  16-bit tables (16 x the key size: 1.9 GB
  * for the 1.8 M-point key of a k = 17 fold step) keep the 16 additions per pair of the per-window
  * path but give all windows ONE set of 2^15 buckets: a commit then pays the fix-up and bucket
  * reduction of one window instead of sixteen and no Horner epilogue -- the latency-bound part of

@@ -503,9 +503,9 @@ static int precompute_locked(uint64_t handle, int32_t window_bits) {
     auto it = g_bases.find(handle);
     if (it == g_bases.end()) { set_error("unknown bases handle"); return MIRA_E_BAD_ARG; }
     Bases &bs = it->second;
-    if (window_bits != 16 && window_bits != 20) { set_error("window tables are built for 16- or 20-bit windows"); return MIRA_E_BAD_ARG; }
+    if (window_bits != 16 && window_bits != 20 && window_bits != 22) { set_error("window tables are built for 16-, 20- or 22-bit windows"); return MIRA_E_BAD_ARG; }
     if (bs.tables && bs.table_c != (uint32_t)window_bits) { set_error("this key already has tables of another width"); return MIRA_E_BAD_ARG; }
-    const uint32_t W = window_bits == 16 ? 16 : 13;   // ceil(256 / 20), table_kernels.cuh
+    const uint32_t W = window_bits == 16 ? 16 : window_bits == 22 ? 12 : 13;   // ceil(256 / c); 12 x 22 = 264 covers a signed 254-bit scalar
     if ((uint64_t)bs.n * W >= (1ull << 31)) { set_error("key too long for 31-bit table indices"); return MIRA_E_UNSUPPORTED; }
     return bs.curve == MIRA_CURVE_BN256 ? build_tables_bn256(bs, (uint32_t)window_bits, W) : build_tables_grumpkin(bs, (uint32_t)window_bits, W);
 }

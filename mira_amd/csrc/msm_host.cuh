@@ -263,11 +263,13 @@ template <class F> static int build_tables(Bases &bs, uint32_t c, uint32_t W) {
     return MIRA_OK;
 }
 
-// One MSM over the tables: 13 signed 20-bit digits per scalar, one set of 2^19 buckets.  Returns
-// TABLE_SUMS partial sums (XYZZ, canonical, reference form) whose plain sum is the result.
+// One MSM over the tables: W signed c-bit digits per scalar (c = 20: 13, c = 22: 12), one set of 2^(c-1)
+// buckets.  Returns TABLE_SUMS partial sums (XYZZ, canonical, reference form) whose plain sum is the result.
 template <class F, class FS>
 static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars, size_t n, uint64_t *host_sums) {
     int rc;
+    const TableCfg tc = table_cfg(bs.table_c);
+    const uint32_t TABLE_W = tc.W, TABLE_B = tc.B, TABLE_FINE_BITS = tc.fine_bits;
     const size_t entries = (size_t)n * TABLE_W;
     const uint32_t lanes = 256u * 4u * 3u * 64u, Lmin = 16;
     const uint32_t T = (uint32_t)std::min<uint64_t>(lanes, ceil_div(entries, Lmin));
@@ -303,10 +305,10 @@ static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars
     unsigned char *no_u8 = nullptr;
     RT_CHECK(rt_memset(g.counts.p, 0, ((size_t)TABLE_CB + 1) * 4, st));
     tm_mark("memset");
-    LAUNCH(k_digits32<FS>, ceil_div(n, 256), 256, 0, st, reinterpret_cast<const unsigned char *>(d_scalars), (uint32_t)n,
+    LAUNCH(k_digits32<FS>, ceil_div(n, 256), 256, 0, st, reinterpret_cast<const unsigned char *>(d_scalars), (uint32_t)n, tc.c, tc.W,
            reinterpret_cast<int32_t *>(g.digits.p));
     tm_mark("digits");
-    LAUNCH_BARRIER_FLEX(k_thist_coarse, dim3(ntiles, TABLE_W), 512, 0, st, reinterpret_cast<const int32_t *>(g.digits.p), (uint32_t)n, tile,
+    LAUNCH_BARRIER_FLEX(k_thist_coarse, dim3(ntiles, TABLE_W), 512, 0, st, reinterpret_cast<const int32_t *>(g.digits.p), (uint32_t)n, tile, TABLE_FINE_BITS,
                         reinterpret_cast<uint32_t *>(g.counts.p));
     tm_mark("hist");
     LAUNCH_BARRIER(k_scan_a, 1, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.counts.p), TABLE_CB, reinterpret_cast<uint32_t *>(g.block_sums.p));

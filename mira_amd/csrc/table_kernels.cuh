@@ -16,11 +16,15 @@
 #pragma once
 #include "curve29.cuh"
 
-static constexpr uint32_t TABLE_C = 20;                  // window width of table mode
-static constexpr uint32_t TABLE_W = 13;                  // ceil(256 / 20)
-static constexpr uint32_t TABLE_B = 1u << (TABLE_C - 1); // buckets (signed digits)
-static constexpr uint32_t TABLE_FINE_BITS = 10;
-static constexpr uint32_t TABLE_CB = TABLE_B >> TABLE_FINE_BITS;   // 512 coarse bins of 1024 buckets
+// Window width of table mode, per key: 20 bits (13 tables, 2^19 buckets) or 22 bits (12 tables, 2^21
+// buckets: one addition per pair less, four times the buckets to reduce -- pays from ~2^24 pairs).
+// Either way the level-1 sort partitions into 512 coarse bins (1024 or 4096 buckets each, the most a
+// level-2 tile ranks in LDS).
+struct TableCfg {
+    uint32_t c, W, B, fine_bits;
+};
+static inline TableCfg table_cfg(uint32_t c) { return c == 22 ? TableCfg{22, 12, 1u << 21, 12} : TableCfg{20, 13, 1u << 19, 10}; }
+static constexpr uint32_t TABLE_CB = 512;                // coarse bins
 static constexpr uint32_t TABLE_SUMS = 64;               // partial sums returned to the host
 
 // a^(P-2) on loose values (any input bound <= 12: every intermediate is a product < 2 P)
@@ -64,9 +68,9 @@ KERNEL void __launch_bounds__(64) k_table_step(const unsigned char *__restrict__
     fe_store(dst + i * 64 + 32, y);
 }
 
-// scalar -> 13 signed 20-bit digits, window-major int32
+// scalar -> W signed c-bit digits (c = 20 or 22), window-major int32
 template <class FS>
-KERNEL void k_digits32(const unsigned char *__restrict__ scalars, uint32_t n, int32_t *__restrict__ digits) {
+KERNEL void k_digits32(const unsigned char *__restrict__ scalars, uint32_t n, uint32_t TABLE_C, uint32_t TABLE_W, int32_t *__restrict__ digits) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Fe<FS> s = fe_from_mont(fe_load<FS>(scalars + (size_t)i * 32));
@@ -85,7 +89,7 @@ KERNEL void k_digits32(const unsigned char *__restrict__ scalars, uint32_t n, in
 }
 
 // coarse-bin histogram over the digits: grid = (ntiles, TABLE_W); LDS = TABLE_CB counters
-KERNEL void k_thist_coarse(const int32_t *__restrict__ digits, uint32_t n, uint32_t tile, uint32_t *__restrict__ counts) {
+KERNEL void k_thist_coarse(const int32_t *__restrict__ digits, uint32_t n, uint32_t tile, uint32_t TABLE_FINE_BITS, uint32_t *__restrict__ counts) {
     __shared__ uint32_t bins[TABLE_CB];
     const uint32_t w = blockIdx.y;
     for (uint32_t b = threadIdx.x; b < TABLE_CB; b += blockDim.x) bins[b] = 0;

@@ -189,8 +189,8 @@ def test_commit_batch_chunking(gpu_lib):
         assert (got[i] == C.commit(cid, bases, v)).all()
 
 
-@pytest.mark.parametrize("cid,log_n", [(0, 20), (1, 19)])
-def test_fixed_base_tables(gpu_lib, cid, log_n):
+@pytest.mark.parametrize("cid,log_n,width", [(0, 20, 20), (1, 19, 20), (0, 20, 22), (1, 19, 22)])
+def test_fixed_base_tables(gpu_lib, cid, log_n, width):
     """mira_msm_precompute (window tables in HBM, 2^19 shared buckets): bit-identical to the
     per-window path and the oracle; partials over the tables combine to the whole."""
     n = 1 << log_n
@@ -198,7 +198,7 @@ def test_fixed_base_tables(gpu_lib, cid, log_n):
     d = cm.synth_scalars_device(cid, n, seed=94)
     dw = cm.synth_scalars_device(cid, n, seed=95, kind=1)
     before, before_w = key.commit_device(d, n), key.commit_device(dw, n)
-    key.precompute()
+    key.precompute(width)                                 # 13 tables / 2^19 buckets, or 12 tables / 2^21 buckets
     assert (key.commit_device(d, n) == before).all()
     assert (key.commit_device(dw, n) == before_w).all()
     assert (before == C.commit(cid, key.bases(), gpu_lib.download(d, (n, 4)))).all()

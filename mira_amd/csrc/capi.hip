@@ -4,6 +4,7 @@
 // (src/fft.rs:51-196).  Kernels live in the per-curve units and ntt.hip.
 #include "ctx.h"
 #include "host_field.hpp"
+#include <thread>
 
 #ifdef MIRA_CPU_EMU
 thread_local dim3 threadIdx, blockIdx;
@@ -333,11 +334,16 @@ static int msm_batch_device_locked(uint64_t handle, const void *d_scalars, size_
         const unsigned char *sc = reinterpret_cast<const unsigned char *>(d_scalars) + done * stride * 32;
         rc = bs.curve == MIRA_CURVE_BN256 ? msm_launch_bn256(bs, 0, sc, nullptr, n, p, win.data()) : msm_launch_grumpkin(bs, 0, sc, nullptr, n, p, win.data());
         if (rc) return rc;
-        for (size_t b = 0; b < cnt; b++) {
+        // the epilogues of a batch are independent chains of ~250 doublings (60 us each): one host thread per commitment
+        auto epilogue = [&](size_t b) {
             const uint64_t *w = win.data() + b * p.W * 16;
             if (bs.curve == MIRA_CURVE_BN256) horner_affine<FqP>(w, p.c, p.W, out_affine + (done + b) * 8);
             else horner_affine<FrP>(w, p.c, p.W, out_affine + (done + b) * 8);
-        }
+        };
+        std::vector<std::thread> workers;
+        for (size_t b = 1; b < cnt; b++) workers.emplace_back(epilogue, b);
+        epilogue(0);
+        for (auto &t : workers) t.join();
     }
     return MIRA_OK;
 }

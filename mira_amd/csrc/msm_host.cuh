@@ -53,7 +53,7 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, cons
     if ((rc = g.block_sums.ensure(1024 * 4))) return rc;
     if ((rc = g.sorted_idx.ensure(entries_max * 4 + 8))) return rc;
     const size_t staged_min_n = tuned(MIRA_TUNE_STAGED_MIN_N, (size_t)1 << 19);
-    if (nmax >= staged_min_n && p.c >= 9) {
+    if (nmax * p.count >= staged_min_n && p.c >= 9) {
         if ((rc = g.part.ensure(entries_max * 8 + 8))) return rc;
         if ((rc = g.coarse_offsets.ensure(((size_t)p.Wt * 512 + 1) * 4))) return rc;
     }
@@ -113,7 +113,7 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, cons
                                 reinterpret_cast<uint32_t *>(g.hist_dev.p));
         // histogram / scatter tiling of this chunk: about two workgroups per CU, at least 1024 points per tile
         const uint32_t tile = (std::max<uint32_t>(1024, ceil_div(nc, std::max<uint32_t>(1, 512 / p.Wt))) + 1023) / 1024 * 1024, ntiles = ceil_div(nc, tile);
-        const bool staged = nc >= staged_min_n && p.c >= 9;
+        const bool staged = nc * p.count >= staged_min_n && p.c >= 9;   // a batch is count MSMs' worth of entries
         LAUNCH(k_digits<FS>, dim3(ceil_div(nc, 256), p.count), 256, 0, st, sc, (uint32_t)nc, (uint64_t)p.stride, p.c, p.W,
                reinterpret_cast<int16_t *>(g.digits.p), reinterpret_cast<uint32_t *>(g.counts.p), p.NB + 1);
         tm_mark("digits");

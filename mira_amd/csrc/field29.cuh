@@ -143,10 +143,71 @@ template <int K, class F> HD Fe29<F> f29_neg(const Fe29<F> &b) { return f29_sub<
 // multiply by a small constant by repeated addition (3 x = 2 x + x)
 template <class F> HD Fe29<F> f29_triple(const Fe29<F> &a) { return f29_add(f29_dbl(a), a); }
 
-// Montgomery product a * b * 2^-261 mod P.  Limbs of a and b < 2^30; result loose, < 1.5 P for
-// a * b < 64 P^2.
+// Uncarried forms for chains of additions that end in a multiplication (the NTT butterflies): no
+// carry pass, so limbs grow -- by at most 2^29 per f29_add_nc of a multiplier result and by at most
+// 2^30 per f29_sub_nc.  The multiplier tolerates it: with one operand carried (limbs < 2^29 + 8) a
+// column of nine products and nine reduction products stays below 2^64 for limbs of the other
+// operand up to 2^31.5 (9 * 2^31.5 * 2^29 + 9 * 2^58 < 2^64).  f29_carry() restores limbs < 2^29 + 8
+// from any limbs < 2^32.  Callers state their limb budget where they use these (ntt_kernels.cuh).
+template <class F> HD Fe29<F> f29_add_nc(const Fe29<F> &a, const Fe29<F> &b) {
+    Fe29<F> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + b.l[i];
+    F29_SET(r, F29_GET(a) + F29_GET(b));
+    F29_ASSERT(F29_GET(r) <= 40.0);
+    return r;
+}
+// K * P with limbs 0..7 raised by 2^29 (borrowed as 1 from the next limb): dominates, limb by limb,
+// any subtrahend < K P whose limbs 0..7 are below 2^29 -- a multiplier result or an unpacked value.
+template <class F, int K> struct F29BiasTight {
+    uint32_t l[9];
+    constexpr F29BiasTight() : l{} {
+        uint64_t carry = 0;
+        for (int i = 0; i < 9; i++) {
+            uint64_t v = (uint64_t)K * F::P[i] + carry;
+            l[i] = (i < 8) ? (uint32_t)(v & M29) : (uint32_t)v;
+            carry = v >> 29;
+        }
+        for (int i = 0; i < 8; i++) {
+            l[i] += 0x20000000u;
+            l[i + 1] -= 1;
+        }
+    }
+};
+// a - b + K P without a carry pass.  Requires b < (K - 1) P with limbs 0..7 <= 2^29 - 1 (straight
+// from f29_mul or f29_unpack); limbs of the result < limbs of a + 2^30.
+template <int K, class F> HD Fe29<F> f29_sub_nc(const Fe29<F> &a, const Fe29<F> &b) {
+    constexpr F29BiasTight<F, K> bias{};
+    Fe29<F> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        F29_ASSERT(b.l[i] <= bias.l[i]);
+        r.l[i] = a.l[i] + bias.l[i] - b.l[i];
+        F29_ASSERT(r.l[i] >= a.l[i]);                   // no wrap of the 32-bit limb
+    }
+    F29_ASSERT(F29_GET(b) <= (double)K - 1.0);
+    F29_SET(r, F29_GET(a) + (double)K);
+    F29_ASSERT(F29_GET(r) <= 40.0);
+    return r;
+}
+#ifdef F29_TRACK
+// test builds: the 64-bit columns of a 9 x 9 product plus its reduction cannot overflow for these limbs
+template <class F> inline void f29_check_columns(const Fe29<F> &a, const Fe29<F> &b) {
+    uint32_t ma = 0, mb = 0;
+    for (int i = 0; i < 9; i++) { ma = a.l[i] > ma ? a.l[i] : ma; mb = b.l[i] > mb ? b.l[i] : mb; }
+    const long double col = 9.0L * (long double)ma * (long double)mb + 9.0L * 536870912.0L * 536870912.0L + 68719476736.0L;
+    assert(col < 18446744073709551616.0L);
+}
+#define F29_CHECK_COLUMNS(a, b) f29_check_columns(a, b)
+#else
+#define F29_CHECK_COLUMNS(a, b) ((void)0)
+#endif
+
+// Montgomery product a * b * 2^-261 mod P.  Limbs of a and b < 2^30 (or one of them carried and the
+// other < 2^31.5, see above); result loose, < 1.5 P for a * b < 64 P^2.
 template <class F> HD Fe29<F> f29_mul(const Fe29<F> &a, const Fe29<F> &b) {
     F29_ASSERT(F29_GET(a) * F29_GET(b) <= F29_RP_OVER_P);
+    F29_CHECK_COLUMNS(a, b);
     uint64_t c[18];
 #pragma unroll
     for (int k = 0; k < 18; k++) c[k] = 0;

@@ -36,6 +36,12 @@ template <class F> HD Fe<typename F::Sat> f29_canonical(const Fe29<F> &v) {
     F29_ASSERT(F29_GET(v) <= 2.0);
     return reduce_once(f29_pack(v));
 }
+// an element as a pass reads it: canonical from the caller, or what the previous pass left (< 2 P, see NttwIo::finish)
+template <class F> HD Fe29<F> ntt_unpack(const Fe<typename F::Sat> &s) {
+    Fe29<F> r = f29_unpack<F>(s);
+    F29_SET(r, 2.0);
+    return r;
+}
 // table[j] = base^(j * stride) * scale, j < count   (base, scale in reference form; table in R' form)
 template <class F>
 KERNEL void k_pow_table(const unsigned char *__restrict__ base, uint64_t stride, uint32_t count,
@@ -66,7 +72,7 @@ struct NttPass {
 //
 // Inside the line every value stays a loose 9 x 29-bit element (field29.cuh): a butterfly is one
 // multiplication (whose result is < 2 P whatever its input), one carry-free addition and one
-// biased subtraction; entering layer s all values are < (1 + 3 s) P, 37 P after 12 layers, well
+// biased subtraction; entering layer s all values are < (2 + 3 s) P, 38 P after 12 layers, well
 // inside the multiplier's input budget.  Values are made canonical once, when they leave the line
 // -- by the four-step twiddle product in pass 1, by the scale (ifft) or a multiplication by one
 // in the last pass.
@@ -141,14 +147,14 @@ KERNEL void __launch_bounds__(1024) k_ntt_lines(const unsigned char *__restrict_
             uint32_t q = threadIdx.x + k * blockDim.x;
             if (q < N) {
                 uint32_t r = ps.log_len ? (__brev(q) >> (32 - ps.log_len)) : 0;
-                L.store(r, f29_unpack_canonical<F>(pre[k]));
+                L.store(r, ntt_unpack<F>(pre[k]));
             }
         }
         __syncthreads();
         if (idx + gridDim.x < ps.nlines) fetch(idx + gridDim.x);
         for (uint32_t s = 0; s < ps.log_len; s++) {
             const uint32_t half = 1u << s;
-            const double bound = 1.0 + 3.0 * s;
+            const double bound = 2.0 + 3.0 * s;
             for (uint32_t bf = threadIdx.x; bf < N / 2; bf += blockDim.x) {
                 const uint32_t j = bf & (half - 1);
                 const uint32_t i0 = ((bf >> s) << (s + 1)) + j, i1 = i0 + half;
@@ -164,7 +170,7 @@ KERNEL void __launch_bounds__(1024) k_ntt_lines(const unsigned char *__restrict_
             __syncthreads();
         }
         unsigned char *out = dst + ((size_t)(line >> ps.split) * ps.out_hi + (size_t)(line & split_mask) * ps.out_lo) * 32;
-        const double bound = 1.0 + 3.0 * ps.log_len;
+        const double bound = 2.0 + 3.0 * ps.log_len;
         for (uint32_t k = threadIdx.x; k < N; k += blockDim.x) {
             Fe29<F> v = L.load(k, bound);
             if (ps.tw_shift != 0xFFFFFFFFu) {
@@ -219,20 +225,25 @@ HD uint32_t nttw_pos(uint32_t lane, uint32_t r, uint32_t t) {
     const uint32_t sh = 2 * t;
     return ((lane >> sh) << (sh + 2)) | (r << sh) | (lane & ((1u << sh) - 1u));
 }
-// one DIT butterfly: (u, v) -> (u + w v, u - w v); bound(u), bound(v) <= b on entry, <= b + 3 on exit
+// one DIT butterfly: (u, v) -> (u + w v, u - w v); bound(u), bound(v) <= b on entry, <= b + 3 on exit.
+// No carry pass (field29.cuh, f29_add_nc / f29_sub_nc): the limbs of u grow by < 2^30 per layer.  A
+// round is two layers on values that enter carried (limbs < 2^29 + 8: from f29_unpack or f29_carry), so
+// the second layer multiplies limbs < 1.5 * 2^30 and leaves limbs < 2.5 * 2^30 + 8 -- inside the 32-bit
+// limb, and inside the multiplier's 2^31.5 for the post-twiddle product of the last round.  The wave
+// carries once per round, when it parks the values in LDS.
 template <class F> DEV void nttw_bfly(Fe29<F> &u, Fe29<F> &v, const uint32_t *tw9) {
     Fe29<F> w;
 #pragma unroll
     for (int k = 0; k < 9; k++) w.l[k] = tw9[k];
     F29_SET(w, 1.0);
     const Fe29<F> t = f29_mul(v, w);
-    v = f29_sub<3>(u, t);
-    u = f29_add(u, t);
+    v = f29_sub_nc<3>(u, t);
+    u = f29_add_nc(u, t);
 }
-template <class F> DEV void nttw_bfly_one(Fe29<F> &u, Fe29<F> &v) {    // w = 1 (layer 0 of every line)
+template <class F> DEV void nttw_bfly_one(Fe29<F> &u, Fe29<F> &v) {    // w = 1 (layer 0 of every line: v is an unpacked value < 2 P)
     const Fe29<F> t = v;
-    v = f29_sub<3>(u, t);
-    u = f29_add(u, t);
+    v = f29_sub_nc<3>(u, t);
+    u = f29_add_nc(u, t);
 }
 
 // the four points of a lane are four named values (never an indexed array: a dynamically indexed
@@ -263,18 +274,17 @@ template <class F> struct NttwIo {
     }
     DEV size_t in_start(uint32_t line) const { return (size_t)(line >> ps.split) * ps.in_hi + (size_t)(line & split_mask) * ps.in_lo; }
     DEV size_t out_start(uint32_t line) const { return (size_t)(line >> ps.split) * ps.out_hi + (size_t)(line & split_mask) * ps.out_lo; }
-    // output k of its line: times the four-step twiddle (or the final scale), canonical
+    // output k of its line: times the four-step twiddle -- left as the multiplier returns it, some
+    // residue < 2 P < 2^255 that the next pass unpacks like any other value -- or, in the last pass,
+    // times the final scale and canonical
     DEV Fe<typename F::Sat> finish(uint32_t line, uint32_t k, const Fe29<F> &x) const {
-        Fe29<F> v;
         if (ps.tw_shift != 0xFFFFFFFFu) {
             const uint64_t e = (uint64_t)(line >> ps.tw_line_shift) * k;
             const Fe29<F> tw = ps.tw_single ? tw_load<F>(t_lo + (size_t)e * TW_BYTES)
                                             : f29_mul(tw_load<F>(t_hi + (size_t)(e >> ps.tw_shift) * TW_BYTES), tw_load<F>(t_lo + (size_t)(e & lo_mask) * TW_BYTES));
-            v = f29_mul(x, tw);
-        } else {
-            v = f29_mul(x, tw_load<F>(scale));
+            return f29_pack(f29_mul(x, tw));
         }
-        return f29_canonical(v);
+        return f29_canonical(f29_mul(x, tw_load<F>(scale)));
     }
     DEV void store(uint32_t line0, uint32_t p, const Fe29<F> &x) const {
         const uint32_t k = p & (N - 1), line = line0 + (p >> m);
@@ -299,7 +309,7 @@ template <class F> struct NttwIo {
         const U4 a = tile[sl], b = tile[sl + 1];
         Fe<S> s;
         s.l[0] = a.x; s.l[1] = a.y; s.l[2] = a.z; s.l[3] = a.w; s.l[4] = b.x; s.l[5] = b.y; s.l[6] = b.z; s.l[7] = b.w;
-        return f29_unpack_canonical<F>(s);
+        return ntt_unpack<F>(s);
     }
     DEV void tile_give(U4 *tile, uint32_t line0, uint32_t row0, uint32_t p, const Fe29<F> &x) const {
         const uint32_t k = p & (N - 1);
@@ -358,15 +368,15 @@ KERNEL void __launch_bounds__(64 * NTTW_WAVES) __attribute__((amdgpu_waves_per_e
             x2 = io.tile_take(tile, row0, nttw_pos(lane, 2, 0)); x3 = io.tile_take(tile, row0, nttw_pos(lane, 3, 0));
             __syncthreads();                                       // the exchange planes overwrite the tile
         } else {
-            x0 = f29_unpack_canonical<F>(io.fetch(line0, nttw_pos(lane, 0, 0))); x1 = f29_unpack_canonical<F>(io.fetch(line0, nttw_pos(lane, 1, 0)));
-            x2 = f29_unpack_canonical<F>(io.fetch(line0, nttw_pos(lane, 2, 0))); x3 = f29_unpack_canonical<F>(io.fetch(line0, nttw_pos(lane, 3, 0)));
+            x0 = ntt_unpack<F>(io.fetch(line0, nttw_pos(lane, 0, 0))); x1 = ntt_unpack<F>(io.fetch(line0, nttw_pos(lane, 1, 0)));
+            x2 = ntt_unpack<F>(io.fetch(line0, nttw_pos(lane, 2, 0))); x3 = ntt_unpack<F>(io.fetch(line0, nttw_pos(lane, 3, 0)));
         }
         for (uint32_t t = 0; t < rounds; t++) {
-            if (t) {                                               // transpose: layout t-1 -> layout t
-                nttw_put(X, x0, nttw_slot(nttw_pos(lane, 0, t - 1))); nttw_put(X, x1, nttw_slot(nttw_pos(lane, 1, t - 1)));
-                nttw_put(X, x2, nttw_slot(nttw_pos(lane, 2, t - 1))); nttw_put(X, x3, nttw_slot(nttw_pos(lane, 3, t - 1)));
+            if (t) {                                               // transpose: layout t-1 -> layout t (carried: see nttw_bfly)
+                nttw_put(X, f29_carry(x0), nttw_slot(nttw_pos(lane, 0, t - 1))); nttw_put(X, f29_carry(x1), nttw_slot(nttw_pos(lane, 1, t - 1)));
+                nttw_put(X, f29_carry(x2), nttw_slot(nttw_pos(lane, 2, t - 1))); nttw_put(X, f29_carry(x3), nttw_slot(nttw_pos(lane, 3, t - 1)));
                 WAVE_SYNC();
-                const double bound = 1.0 + 6.0 * t;
+                const double bound = 2.0 + 6.0 * t;
                 nttw_get(X, x0, nttw_slot(nttw_pos(lane, 0, t)), bound); nttw_get(X, x1, nttw_slot(nttw_pos(lane, 1, t)), bound);
                 nttw_get(X, x2, nttw_slot(nttw_pos(lane, 2, t)), bound); nttw_get(X, x3, nttw_slot(nttw_pos(lane, 3, t)), bound);
                 WAVE_SYNC();

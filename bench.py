@@ -561,12 +561,17 @@ def extras(lib, cm, with_cpu):
             t0 = time.perf_counter(); t16_pts = run(False); t16.append((time.perf_counter() - t0) * 1e3)
         for _ in range(9):
             t0 = time.perf_counter(); keys[cm.CURVE_BN256].commit_device(cross[cm.CURVE_BN256], n); single16.append((time.perf_counter() - t0) * 1e3)
+        run(True)
+        t16b = []
+        for _ in range(5):
+            t0 = time.perf_counter(); t16b_pts = run(True); t16b.append((time.perf_counter() - t0) * 1e3)
         ex["fold_step_k17"] = {"msm_calls": 13, "pairs": sum(nw + cnt * n for nw, cnt in plan.values()),
                                "gpu_ms": round(bat_ms, 3), "gpu_ms_one_call_per_commit": round(seq_ms, 3),
                                "gpu_ms_host_scalars_one_call_per_commit": round(sorted(hs)[2], 3), "gpu_ms_host_scalars_batched": round(sorted(hb)[2], 3),
                                "one_commit_131072_pairs_ms": round(sorted(single)[4], 3),
                                "gpu_ms_one_call_per_commit_16bit_tables": round(sorted(t16)[2], 3), "one_commit_131072_pairs_ms_16bit_tables": round(sorted(single16)[4], 3),
-                               "tables_same_points": bool(all((a == b).all() for a, b in zip(seq_pts, t16_pts))),
+                               "gpu_ms_16bit_tables": round(sorted(t16b)[2], 3),
+                               "tables_same_points": bool(all((a == b).all() for a, b in zip(seq_pts, t16_pts)) and all((a == b).all() for a, b in zip(seq_pts, t16b_pts))),
                                "host_scalar_bytes": 32 * sum(nw + cnt * n for nw, cnt in plan.values()),
                                "batched_equals_sequential": bool(all((a == b).all() for a, b in zip(seq_pts, bat_pts))
                                                                  and all((a == b).all() for a, b in zip(seq_pts, hseq_pts))
@@ -737,6 +742,19 @@ def extras(lib, cm, with_cpu):
                                     "rows": n, "advice_columns": [14, 7], "cross_terms": [6, 5],
                                     "note": "both curves, device-resident vectors: witness commit, cross-term evaluation, batched cross-term commits, W / E folding "
                                             "and instance folding (host g1_mul_add); span names follow the reference's tracing spans"}
+        # opt-in: the same chain over 16-bit fixed-base tables (mira_msm_precompute_ex(handle, 16)) -- a
+        # commitment key is fixed for the whole IVC run, its tables are built once
+        for s_ in st.values():
+            s_["key"].precompute(16)
+        fold_step()
+        walls16 = []
+        for _ in range(5):
+            t0 = time.perf_counter(); spans16, last16 = fold_step(); walls16.append(((time.perf_counter() - t0) * 1e3, spans16))
+        wall16, spans16 = sorted(walls16, key=lambda x: x[0])[2]
+        same16 = all((last16[c]["w_commit"] == last[c]["w_commit"]).all() and (last16[c]["t_commits"] == last[c]["t_commits"]).all()
+                     and (last16[c]["folded_e"] == last[c]["folded_e"]).all() for c in st)
+        ex["nifs_fold_step_k17"].update({"ms_16bit_tables": round(wall16, 3), "spans_ms_16bit_tables": {a: round(b * 1e3, 3) for a, b in spans16.items()},
+                                         "tables_same_points": bool(same16)})
         if with_cpu:
             from oracle import cref as C
             t0 = time.perf_counter()

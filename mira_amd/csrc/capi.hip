@@ -203,10 +203,10 @@ static MsmPlan make_plan(size_t n, int32_t forced_c, uint32_t count = 1, uint64_
 // 16-bit fixed-base tables (mira_msm_precompute_ex(handle, 16)): 16 signed 16-bit digits per scalar
 // against the tables 2^(16 w) P_i, ONE set of 2^15 buckets for all windows, 16 partial sums back.
 static constexpr uint32_t SHARED_SUMS = 16;
-static MsmPlan make_plan_shared(size_t n, uint64_t table_n) {
-    MsmPlan p = make_plan(n, 16);
+static MsmPlan make_plan_shared(size_t n, uint64_t table_n, uint32_t count = 1, uint64_t stride = 0) {
+    MsmPlan p = make_plan(n, 16, count, stride);
     p.shared = true; p.table_n = table_n; p.sums = SHARED_SUMS;
-    p.NB = p.B;                                              // one bucket set
+    p.NB = count * p.B;                                      // one bucket set per MSM
     p.m = 4;                                                 // 8192 chunks: the chain of the reduction is what counts here
     p.nchunks = p.B / p.m;
     return p;
@@ -321,8 +321,29 @@ static int msm_batch_device_locked(uint64_t handle, const void *d_scalars, size_
         return MIRA_E_TOO_LONG;
     }
     if (n == 0) { memset(out_affine, 0, count * 64); return MIRA_OK; }
-    MsmPlan p1 = make_plan(n, g.forced_c);
     if (n >= (1ull << 31)) { set_error("n too large for 32-bit entry offsets"); return MIRA_E_UNSUPPORTED; }
+    // 16-bit fixed-base tables: every commitment of the batch gets ONE bucket set for its 16 windows
+    // (16 additions per pair instead of ceil(256 / c), 2^15 buckets per commitment instead of W 2^(c-1)),
+    // and its 16 partial sums come back to be added -- no chain of doublings
+    if (bs.tables && bs.table_c == 16 && g.forced_c == 0 && n >= tuned(MIRA_TUNE_TABLE_MIN_N, TABLE16_MIN_N)) {
+        const size_t per = std::max<size_t>(1, std::min<size_t>(64, (size_t)(((1ull << 32) - 1) / ((uint64_t)n * 16))));
+        std::vector<uint64_t> sums;
+        for (size_t done = 0; done < count; done += per) {
+            const size_t cnt = std::min(per, count - done);
+            MsmPlan p = make_plan_shared(n, bs.n, (uint32_t)cnt, stride);
+            sums.assign(cnt * SHARED_SUMS * 16, 0);
+            const unsigned char *sc = reinterpret_cast<const unsigned char *>(d_scalars) + done * stride * 32;
+            rc = bs.curve == MIRA_CURVE_BN256 ? msm_launch_bn256(bs, 0, sc, nullptr, n, p, sums.data()) : msm_launch_grumpkin(bs, 0, sc, nullptr, n, p, sums.data());
+            if (rc) return rc;
+            for (size_t b = 0; b < cnt; b++) {
+                const uint64_t *w = sums.data() + b * SHARED_SUMS * 16;
+                if (bs.curve == MIRA_CURVE_BN256) horner_affine<FqP>(w, 0, SHARED_SUMS, out_affine + (done + b) * 8);
+                else horner_affine<FrP>(w, 0, SHARED_SUMS, out_affine + (done + b) * 8);
+            }
+        }
+        return MIRA_OK;
+    }
+    MsmPlan p1 = make_plan(n, g.forced_c);
     // per launch: W_total * B counters <= 2^21 (three-launch scan) and n * W_total entries < 2^32
     size_t per = std::max<size_t>(1, std::min<size_t>((size_t)((1ull << 21) / ((uint64_t)p1.W * p1.B)),
                                                       (size_t)(((1ull << 32) - 1) / ((uint64_t)n * p1.W))));

@@ -63,8 +63,8 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, cons
     if ((rc = g.tail_key.ensure((size_t)p.T * 4))) return rc;
     if ((rc = g.heavy.ensure(64 + ((size_t)p.T / 2 + 8) * 32))) return rc;            // counters, runs, sub-job descriptors
     if ((rc = g.heavy_out.ensure(((size_t)p.T / 2 + 8) * XYZZ29_BYTES))) return rc;
-    if ((rc = g.chunks.ensure((size_t)p.Wt * p.nchunks * XYZZ29_BYTES))) return rc;
-    if ((rc = g.window_sums.ensure((size_t)std::max(p.Wt, p.sums) * 128))) return rc;
+    if ((rc = g.chunks.ensure((size_t)(p.shared ? p.count : p.Wt) * p.nchunks * XYZZ29_BYTES))) return rc;
+    if ((rc = g.window_sums.ensure((size_t)std::max(p.Wt, p.count * p.sums) * 128))) return rc;
 #ifndef MIRA_CPU_EMU
     if (h_scalars) {
         if (!g.copy_stream) RT_CHECK(hipStreamCreateWithFlags(&g.copy_stream, hipStreamNonBlocking));
@@ -100,7 +100,7 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, cons
         const unsigned char *sc = reinterpret_cast<const unsigned char *>(d_scalars) + lo * 32;
         // per-window buckets: entries are chunk-local point indices; shared buckets: entries name table points
         const unsigned char *bases = p.shared ? reinterpret_cast<const unsigned char *>(bs.tables) : reinterpret_cast<const unsigned char *>(bs.d) + (first + lo) * 64;
-        const uint32_t wstride = p.shared ? 0u : p.B, idx_stride = p.shared ? (uint32_t)p.table_n : 0u, idx_first = p.shared ? (uint32_t)(first + lo) : 0u;
+        const uint32_t wgroup = p.shared ? p.W : 1u, idx_stride = p.shared ? (uint32_t)p.table_n : 0u, idx_first = p.shared ? (uint32_t)(first + lo) : 0u;
         const uint32_t add = k ? 1u : 0u;
         if (h_scalars) {
             // pageable or pinned, the copy engine moves it beside the kernels of the previous chunk
@@ -118,7 +118,7 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, cons
                reinterpret_cast<int16_t *>(g.digits.p), reinterpret_cast<uint32_t *>(g.counts.p), p.NB + 1);
         tm_mark("digits");
         LAUNCH_BARRIER_FLEX(k_hist, dim3(ntiles, p.Wt), 1024, (size_t)p.B * 4, st, reinterpret_cast<const int16_t *>(g.digits.p), (uint32_t)nc,
-                       p.B, tile, reinterpret_cast<uint32_t *>(g.counts.p), wstride);
+                       p.B, tile, reinterpret_cast<uint32_t *>(g.counts.p), wgroup);
         tm_mark("hist");
         LAUNCH_BARRIER(k_scan_a, scan_blocks, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.counts.p), p.NB,
                        reinterpret_cast<uint32_t *>(g.block_sums.p));
@@ -133,17 +133,17 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, cons
         if (staged) {
             if (p.shared)
                 LAUNCH_BARRIER((k_stage1<int16_t, true>), dim3(ceil_div(nc, STAGE_TILE), p.Wt), 1024, (size_t)STAGE_TILE * 8, st, reinterpret_cast<const int16_t *>(g.digits.p),
-                                    (uint32_t)nc, p.B, fine_bits, CB, idx_stride, idx_first, reinterpret_cast<uint32_t *>(g.coarse_offsets.p), reinterpret_cast<U2 *>(g.part.p));
+                                    (uint32_t)nc, p.B, fine_bits, CB, idx_stride, idx_first, wgroup, reinterpret_cast<uint32_t *>(g.coarse_offsets.p), reinterpret_cast<U2 *>(g.part.p));
             else
                 LAUNCH_BARRIER((k_stage1<int16_t, false>), dim3(ceil_div(nc, STAGE_TILE), p.Wt), 1024, (size_t)STAGE_TILE * 8, st, reinterpret_cast<const int16_t *>(g.digits.p),
-                                    (uint32_t)nc, p.B, fine_bits, CB, 0u, 0u, reinterpret_cast<uint32_t *>(g.coarse_offsets.p), reinterpret_cast<U2 *>(g.part.p));
+                                    (uint32_t)nc, p.B, fine_bits, CB, 0u, 0u, 1u, reinterpret_cast<uint32_t *>(g.coarse_offsets.p), reinterpret_cast<U2 *>(g.part.p));
             tm_mark("sort_level1");
             LAUNCH_BARRIER(k_stage2, ceil_div(entries, STAGE_TILE), 1024, (size_t)STAGE_TILE * 6, st, reinterpret_cast<const U2 *>(g.part.p),
                                 reinterpret_cast<const uint32_t *>(g.offsets.p) + p.NB, fine_bits, reinterpret_cast<uint32_t *>(g.cursor.p),
                                 reinterpret_cast<uint32_t *>(g.sorted_idx.p));
         } else
             LAUNCH_BARRIER_FLEX(k_scatter, dim3(ntiles, p.Wt), 1024, (size_t)p.B * 4, st, reinterpret_cast<const int16_t *>(g.digits.p),
-                       (uint32_t)nc, p.B, tile, reinterpret_cast<uint32_t *>(g.cursor.p), reinterpret_cast<uint32_t *>(g.sorted_idx.p), wstride, idx_stride, idx_first);
+                       (uint32_t)nc, p.B, tile, reinterpret_cast<uint32_t *>(g.cursor.p), reinterpret_cast<uint32_t *>(g.sorted_idx.p), wgroup, idx_stride, idx_first);
         tm_mark("scatter");
         if (add)
             LAUNCH((k_accumulate<F, true>), ceil_div(p.T, 128), 128, 0, st, reinterpret_cast<const uint32_t *>(g.sorted_idx.p),
@@ -168,8 +168,8 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, cons
                        reinterpret_cast<unsigned char *>(g.bucket_sums.p));
         tm_mark("fixup");
     }
-    // bucket sets: one per window, or one for all (shared: its chunk results are summed by `sums` workgroups)
-    const uint32_t Wb = p.shared ? 1u : p.Wt, nsum = p.shared ? p.sums : p.Wt, per_sum = p.shared ? p.nchunks / p.sums : p.nchunks;
+    // bucket sets: one per window, or one per MSM (shared: the chunk results of a set are summed by `sums` workgroups)
+    const uint32_t Wb = p.shared ? p.count : p.Wt, nsum = p.shared ? p.count * p.sums : p.Wt, per_sum = p.shared ? p.nchunks / p.sums : p.nchunks;
     const uint64_t items = (uint64_t)Wb * p.nchunks;
     if (reduce_with_quads(items)) {
         LAUNCH((k_reduce_chunks<F, true>), ceil_div(items * 4, 64), 64, 0, st, reinterpret_cast<const unsigned char *>(g.bucket_sums.p),
@@ -320,7 +320,7 @@ static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars
     // level 1 by coarse bin (top 9 bits), bucket counts from its output, scan, level 2 by bucket
     const uint32_t *coarse_total = reinterpret_cast<const uint32_t *>(g.coarse_offsets.p) + TABLE_CB;
     LAUNCH_BARRIER((k_stage1<int32_t, true>), dim3(ceil_div(n, STAGE_TILE), TABLE_W), 1024, (size_t)STAGE_TILE * 8, st,
-                        reinterpret_cast<const int32_t *>(g.digits.p), (uint32_t)n, TABLE_B, TABLE_FINE_BITS, TABLE_CB, (uint32_t)bs.n, (uint32_t)first,
+                        reinterpret_cast<const int32_t *>(g.digits.p), (uint32_t)n, TABLE_B, TABLE_FINE_BITS, TABLE_CB, (uint32_t)bs.n, (uint32_t)first, TABLE_W,
                         reinterpret_cast<uint32_t *>(g.cursor.p), reinterpret_cast<U2 *>(g.part.p));
     tm_mark("sort_level1");
     RT_CHECK(rt_memset(g.fine_counts.p, 0, ((size_t)TABLE_B + 1) * 4, st));

@@ -78,10 +78,11 @@ KERNEL void k_digits(const unsigned char *__restrict__ scalars, uint32_t n, uint
 }
 
 // ------------------------------------------------------------------------------------------
-// grid = (ntiles, W), dynamic LDS = B * 4 bytes.  wstride = B: every window has its own buckets;
-// wstride = 0: all windows share one set (fixed-base tables, msm_host.cuh).
+// grid = (ntiles, W_total), dynamic LDS = B * 4 bytes.  Window w counts into bucket set w / wgroup:
+// wgroup = 1, every window has its own buckets; wgroup = W, the W windows of one MSM share a set
+// (fixed-base tables, msm_host.cuh).
 KERNEL void k_hist(const int16_t *__restrict__ digits, uint32_t n, uint32_t B, uint32_t tile,
-                   uint32_t *__restrict__ counts, uint32_t wstride) {
+                   uint32_t *__restrict__ counts, uint32_t wgroup) {
     DYN_SHARED(uint32_t, bins);
     const uint32_t w = blockIdx.y;
     for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) bins[b] = 0;
@@ -95,7 +96,7 @@ KERNEL void k_hist(const int16_t *__restrict__ digits, uint32_t n, uint32_t B, u
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) {
         uint32_t cnt = bins[b];
-        if (cnt) atomicAdd(&counts[(size_t)w * wstride + b], cnt);
+        if (cnt) atomicAdd(&counts[(size_t)(w / wgroup) * B + b], cnt);
     }
 }
 
@@ -183,10 +184,10 @@ KERNEL void k_scan_c(const uint32_t *__restrict__ counts, uint32_t NB, const uin
 }
 
 // ------------------------------------------------------------------------------------------
-// grid = (ntiles, W), dynamic LDS = B * 4 bytes.  Same tiling as k_hist.  Entries name point
-// w * idx_stride + idx_first + i: the point itself (0, 0) or its copy in window table w.
+// grid = (ntiles, W_total), dynamic LDS = B * 4 bytes.  Same tiling and bucket sets as k_hist.  Entries name point
+// (w % wgroup) * idx_stride + idx_first + i: the point itself (0, 0) or its copy in window table w % wgroup.
 KERNEL void k_scatter(const int16_t *__restrict__ digits, uint32_t n, uint32_t B, uint32_t tile,
-                      uint32_t *__restrict__ cursor, uint32_t *__restrict__ sorted, uint32_t wstride, uint32_t idx_stride, uint32_t idx_first) {
+                      uint32_t *__restrict__ cursor, uint32_t *__restrict__ sorted, uint32_t wgroup, uint32_t idx_stride, uint32_t idx_first) {
     DYN_SHARED(uint32_t, bins);
     const uint32_t w = blockIdx.y;
     for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) bins[b] = 0;
@@ -200,7 +201,7 @@ KERNEL void k_scatter(const int16_t *__restrict__ digits, uint32_t n, uint32_t B
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) {
         uint32_t cnt = bins[b];
-        if (cnt) bins[b] = atomicAdd(&cursor[(size_t)w * wstride + b], cnt);   // claimed range start
+        if (cnt) bins[b] = atomicAdd(&cursor[(size_t)(w / wgroup) * B + b], cnt);   // claimed range start
     }
     __syncthreads();
     for (uint32_t i = base + threadIdx.x; i < end; i += blockDim.x) {
@@ -208,7 +209,7 @@ KERNEL void k_scatter(const int16_t *__restrict__ digits, uint32_t n, uint32_t B
         if (d != 0) {
             uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1;
             uint32_t pos = atomicAdd(&bins[b], 1u);
-            sorted[pos] = (w * idx_stride + idx_first + i) | (d < 0 ? 0x80000000u : 0u);   // 4 bytes per entry; the bucket is implied by the position
+            sorted[pos] = ((w % wgroup) * idx_stride + idx_first + i) | (d < 0 ? 0x80000000u : 0u);   // 4 bytes per entry; the bucket is implied by the position
         }
     }
 }

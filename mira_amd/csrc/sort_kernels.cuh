@@ -45,18 +45,19 @@ DEV void block_excl_scan(const uint32_t *cnt, uint32_t *ofs, uint32_t *tmp /* bl
 // level 1.  grid = (ntiles, W_total); digits int16 window-major; B buckets per window, CB = B >> fine_bits
 // coarse bins per window (<= STAGE_MAX_BINS1).  part entries: x = index | sign << 31, y = w * B + bucket.
 // dynamic LDS: STAGE_TILE * 8 bytes staging.
-// TABLE = true (fixed-base mode, table_kernels.cuh): int32 digits, ONE bucket set shared by all
-// windows (y = bucket, cursors indexed by the coarse bin alone) and x = w * N + first + i, the index
-// into the window tables (N = registered key length).
+// TABLE = true (fixed-base mode, table_kernels.cuh): the `wgroup` windows of one MSM share ONE bucket
+// set (MSM j = w / wgroup of a batch: y = j * B + bucket, cursors indexed by j and the coarse bin) and
+// x = (w % wgroup) * N + first + i, the index into the window tables (N = registered key length).
 template <class DIGIT, bool TABLE>
 KERNEL void __launch_bounds__(1024) k_stage1(const DIGIT *__restrict__ digits, uint32_t n, uint32_t B, uint32_t fine_bits, uint32_t CB,
-                                              uint32_t N, uint32_t first, uint32_t *__restrict__ cursor1, U2 *__restrict__ part) {
+                                              uint32_t N, uint32_t first, uint32_t wgroup, uint32_t *__restrict__ cursor1, U2 *__restrict__ part) {
     DYN_SHARED(U2, stage);
     __shared__ uint32_t cnt[STAGE_MAX_BINS1], lofs[STAGE_MAX_BINS1], gbase[STAGE_MAX_BINS1], tmp[1024], total_s;
     const uint32_t w = blockIdx.y;
     const uint32_t base = blockIdx.x * STAGE_TILE, end = (base + STAGE_TILE < n) ? base + STAGE_TILE : n;
     const DIGIT *dw = digits + (size_t)w * n;
-    const uint32_t key_base = TABLE ? 0u : w * B, cur_base = TABLE ? 0u : w * CB, idx_base = TABLE ? w * N + first : 0u;
+    const uint32_t set = TABLE ? w / wgroup : w;
+    const uint32_t key_base = set * B, cur_base = set * CB, idx_base = TABLE ? (w % wgroup) * N + first : 0u;
     for (uint32_t b = threadIdx.x; b < CB; b += blockDim.x) cnt[b] = 0;
     __syncthreads();
     constexpr int PER = STAGE_TILE / 1024;               // 16 points per lane: blockDim.x must be 1024 (the test emulation runs these kernels with all 1024 lanes too)

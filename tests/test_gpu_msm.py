@@ -290,4 +290,12 @@ def test_shared_bucket_tables_16bit(gpu_lib, cid, log_n):
     pb, cb, wb = key.commit_partial_device(m, d + m * 32, n - m)
     assert (ca, wa) == (0, 16) == (cb, wb)
     assert (cm.combine_partials(cid, np.stack([pa, pb]), ca, wa) == before).all()
+    # a batch over the tables (one bucket set per commitment): five cross-term-sized vectors at a stride
+    nb, cnt = 1 << 15, 5
+    want_b = np.stack([C.commit(cid, key.bases()[:nb], sc[b * 3 * nb // 2: b * 3 * nb // 2 + nb]) for b in range(cnt)]) if log_n >= 20 else None
+    got_b = key.commit_batch_device(d, nb if log_n >= 20 else n // 8, cnt, stride=3 * nb // 2 if log_n >= 20 else n // 8)
+    if want_b is not None:
+        assert (got_b == want_b).all()
+    else:
+        assert all((got_b[b] == key.commit_device(d + b * (n // 8) * 32, n // 8)).all() for b in range(cnt))
     gpu_lib.free(d); gpu_lib.free(dw)

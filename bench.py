@@ -626,7 +626,7 @@ def extras(lib, cm, with_cpu):
             return G.Sum(e, G.Product(G.Polynomial(1), G.Polynomial(2, -1)))
         evs = [G.GraphEvaluator.new(gate(s), G.FIELD_FR) for s in range(5)]
         d_out = lib.alloc(5 * n * 32)
-        run = lambda: [ev.evaluate_device(cols, chal, n, d_out=d_out + i * n * 32) for i, ev in enumerate(evs)]
+        run = lambda: G.GraphEvaluator.evaluate_batch_device(evs, cols, chal, n, [d_out + i * n * 32 for i in range(5)])     # one mira_graph_eval_batch
         walls = []
         for _ in range(7):                       # median: see the NTT leg
             t0 = time.perf_counter(); run(); walls.append((time.perf_counter() - t0) * 1e3)
@@ -717,8 +717,7 @@ def extras(lib, cm, with_cpu):
                 t0 = time.perf_counter()
                 w_commit = s_["key"].commit_device(s_["d_w2"], s_["nw"])
                 t1 = time.perf_counter()
-                for i, ev in enumerate(s_["evs"]):
-                    ev.evaluate_device(s_["cols"], chal, n, d_out=s_["d_terms"] + i * n * 32)
+                G.GraphEvaluator.evaluate_batch_device(s_["evs"], s_["cols"], chal, n, [s_["d_terms"] + i * n * 32 for i in range(s_["cnt"])])
                 t2 = time.perf_counter()
                 t_commits = s_["key"].commit_batch_device(s_["d_terms"], n, s_["cnt"])
                 t3 = time.perf_counter()

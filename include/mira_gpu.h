@@ -214,6 +214,12 @@ int mira_graph_compile(int field, const mira_graph *graph, uint32_t num_challeng
 int mira_graph_eval_compiled(uint64_t handle, const mira_eval_column *columns, uint32_t num_columns,
                              const uint64_t *challenges, uint32_t num_challenges, size_t num_rows, void *d_out);
 int mira_graph_free(uint64_t handle);
+/* The d - 1 cross-term graphs of one fold step (src/nifs/vanilla/mod.rs:100-121 evaluates them one
+ * after the other over the same witnesses and challenges) in one submission: count compiled graphs
+ * of one field, compiled for the same numbers of challenges and columns, over the same columns;
+ * graph k writes d_outs[k].  Row for row the values of count mira_graph_eval_compiled calls. */
+int mira_graph_eval_batch(const uint64_t *handles, uint32_t count, const mira_eval_column *columns, uint32_t num_columns,
+                          const uint64_t *challenges, uint32_t num_challenges, size_t num_rows, void *const *d_outs);
 
 /* ---- ProtoGalaxy's polynomial pipeline around the NTT (src/nifs/protogalaxy/poly/mod.rs) -------
  * mira_pow_tree_reduce_device: the weighted tree reduction of compute_F (:131-166) and compute_G

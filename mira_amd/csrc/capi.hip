@@ -738,6 +738,14 @@ int mira_graph_eval_compiled(uint64_t handle, const mira_eval_column *columns, u
     if ((num_columns && !columns) || (num_challenges && !challenges) || (num_rows && !d_out)) { set_error("bad graph evaluation arguments"); return MIRA_E_BAD_ARG; }
     return graph_eval_compiled(handle, columns, num_columns, challenges, num_challenges, num_rows, d_out);
 }
+int mira_graph_eval_batch(const uint64_t *handles, uint32_t count, const mira_eval_column *columns, uint32_t num_columns, const uint64_t *challenges,
+                          uint32_t num_challenges, size_t num_rows, void *const *d_outs) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    if ((count && (!handles || !d_outs)) || (num_columns && !columns) || (num_challenges && !challenges)) { set_error("bad graph evaluation arguments"); return MIRA_E_BAD_ARG; }
+    return graph_eval_batch(handles, count, columns, num_columns, challenges, num_challenges, num_rows, d_outs);
+}
 int mira_graph_free(uint64_t handle) {
     std::lock_guard<std::mutex> lk(g_lock);
     return graph_free(handle);

@@ -14,12 +14,16 @@ struct Calc {
     size_t first_src, nsrc;   // into the flat source list
 };
 
+// compiler-internal calculation: addend + p * q (an ADD that absorbed the single-use MUL feeding it); never accepted from a caller
+constexpr uint32_t OP_MAC_INTERNAL = 0xFEu;
+
 // number of operand words of a calculation, or -1 for an unknown opcode
 int operand_count(uint32_t op, uint32_t nparts) {
     switch (op) {
         case MIRA_OP_ADD: case MIRA_OP_SUB: case MIRA_OP_MUL: return 2;
         case MIRA_OP_SQUARE: case MIRA_OP_DOUBLE: case MIRA_OP_NEGATE: case MIRA_OP_STORE: return 1;
         case MIRA_OP_HORNER: return 2 + (int)nparts;
+        case OP_MAC_INTERNAL: return 3;
         default: return -1;
     }
 }
@@ -48,9 +52,10 @@ struct Program {
     size_t o_code = 0, o_const = 0, o_rot = 0;
     DevBuf dyn;                                // challenges | column table of the current evaluation
     unsigned char *h_dyn = nullptr;            // pinned staging of the same
-    size_t o_chal = 0, o_cols = 0, dyn_bytes = 0;
+    size_t o_chal = 0, o_cols = 0, o_jobs = 0, dyn_bytes = 0;   // | job table of the batch this program leads
 };
 std::map<uint64_t, Program> g_programs;
+constexpr uint32_t GRAPH_MAX_BATCH = 16;           // graphs per launch
 
 size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
@@ -59,17 +64,17 @@ size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 // The reference keeps one intermediate per calculation (graph_evaluator.rs:354-359).  Most die
 // young: slots are handed out by last use, so a 300-calculation gate needs ~10-20 of them.
 int graph_compile(int field, const mira_graph *gr, uint32_t num_challenges, uint32_t num_columns, uint64_t *handle_out) {
-    const uint32_t n = gr->num_calculations;
+    const uint32_t n_in = gr->num_calculations;
     std::vector<Calc> calcs;
     std::vector<uint32_t> srcs;
     std::vector<bool> col_used(num_columns, false);
-    calcs.reserve(n);
+    calcs.reserve(n_in);
     size_t pos = 0;
-    for (uint32_t i = 0; i < n; i++) {
+    for (uint32_t i = 0; i < n_in; i++) {
         if (pos >= gr->code_words) { set_error("graph code ends inside calculation " + std::to_string(i)); return MIRA_E_BAD_ARG; }
         const uint32_t head = gr->code[pos++];
         const uint32_t op = head & 0xFFu, nparts = head >> 8;
-        const int cnt = operand_count(op, nparts);
+        const int cnt = op == OP_MAC_INTERNAL ? -1 : operand_count(op, nparts);
         if (cnt < 0 || (op != MIRA_OP_HORNER && nparts != 0)) { set_error("unknown calculation " + std::to_string(head) + " at index " + std::to_string(i)); return MIRA_E_BAD_ARG; }
         if (pos + (size_t)cnt > gr->code_words) { set_error("graph code ends inside calculation " + std::to_string(i)); return MIRA_E_BAD_ARG; }
         calcs.push_back(Calc{op, nparts, srcs.size(), (size_t)cnt});
@@ -101,6 +106,62 @@ int graph_compile(int field, const mira_graph *gr, uint32_t num_challenges, uint
         }
     }
     if (pos != gr->code_words) { set_error("graph code has trailing words"); return MIRA_E_BAD_ARG; }
+
+    // Multiply-accumulate fusion.  Gates are sums of products: `acc = acc + c_i * x_i` flattens to MUL, ADD
+    // pairs whose product is read once, by the ADD.  Folding the MUL into the ADD (one instruction
+    // addend + p * q) halves the instruction count of such chains, and the running sum then stays in the
+    // forwarding register from link to link instead of going through a workspace slot while the
+    // product is computed.  Not when an operand of the MUL is itself a forwarded value (it would need
+    // a slot instead); values are exact field elements, so regrouping changes no result.
+    {
+        std::vector<uint32_t> nuses(n_in, 0);
+        for (uint32_t i = 0; i < n_in; i++)
+            for (size_t k = 0; k < calcs[i].nsrc; k++) {
+                const uint32_t w = srcs[calcs[i].first_src + k];
+                if ((w >> 29) == MIRA_SRC_INTERMEDIATE) nuses[w & 0x1FFFFFFFu]++;
+            }
+        std::vector<uint32_t> absorbed(n_in, 0xFFFFFFFFu);          // MUL j -> the ADD that takes it
+        std::vector<int> takes(n_in, -1);                            // ADD i -> which of its operands is the absorbed MUL
+        for (uint32_t i = 0; i < n_in; i++) {
+            if (calcs[i].op != MIRA_OP_ADD) continue;
+            int best = -1;
+            uint32_t best_j = 0;
+            for (int k = 0; k < 2; k++) {
+                const uint32_t w = srcs[calcs[i].first_src + k];
+                if ((w >> 29) != MIRA_SRC_INTERMEDIATE) continue;
+                const uint32_t j = w & 0x1FFFFFFFu;
+                if (calcs[j].op != MIRA_OP_MUL || nuses[j] != 1 || absorbed[j] != 0xFFFFFFFFu) continue;
+                bool ok = true;
+                for (size_t q = 0; q < 2; q++) {
+                    const uint32_t o = srcs[calcs[j].first_src + q];
+                    if ((o >> 29) == MIRA_SRC_INTERMEDIATE && (o & 0x1FFFFFFFu) + 1 == j && nuses[o & 0x1FFFFFFFu] == 1) ok = false;
+                }
+                if (ok && (best < 0 || j > best_j)) { best = k; best_j = j; }
+            }
+            if (best >= 0) { takes[i] = best; absorbed[best_j] = i; }
+        }
+        std::vector<uint32_t> new_index(n_in, 0);
+        std::vector<Calc> calcs2;
+        std::vector<uint32_t> srcs2;
+        auto remap = [&](uint32_t w) { return (w >> 29) == MIRA_SRC_INTERMEDIATE ? ((MIRA_SRC_INTERMEDIATE << 29) | new_index[w & 0x1FFFFFFFu]) : w; };
+        for (uint32_t i = 0; i < n_in; i++) {
+            if (absorbed[i] != 0xFFFFFFFFu) continue;
+            new_index[i] = (uint32_t)calcs2.size();
+            if (takes[i] >= 0) {
+                const uint32_t j = srcs[calcs[i].first_src + takes[i]] & 0x1FFFFFFFu;
+                calcs2.push_back(Calc{OP_MAC_INTERNAL, 0, srcs2.size(), 3});
+                srcs2.push_back(remap(srcs[calcs[i].first_src + 1 - takes[i]]));
+                srcs2.push_back(remap(srcs[calcs[j].first_src]));
+                srcs2.push_back(remap(srcs[calcs[j].first_src + 1]));
+            } else {
+                calcs2.push_back(Calc{calcs[i].op, calcs[i].nparts, srcs2.size(), calcs[i].nsrc});
+                for (size_t k = 0; k < calcs[i].nsrc; k++) srcs2.push_back(remap(srcs[calcs[i].first_src + k]));
+            }
+        }
+        calcs.swap(calcs2);
+        srcs.swap(srcs2);
+    }
+    const uint32_t n = (uint32_t)calcs.size();
 
     // readers of every intermediate; the final calculation's value leaves through `out`
     std::vector<uint32_t> last_use(n, 0), first_use(n, 0xFFFFFFFFu);
@@ -150,6 +211,19 @@ int graph_compile(int field, const mira_graph *gr, uint32_t num_challenges, uint
         ninstr++;
         return rb;
     };
+    // addend + p * q
+    auto emit_mac = [&](uint32_t sc, double bc, uint32_t sp, double bp, uint32_t sq, double bq) -> double {
+        last_head = stream.size();
+        stream.push_back(GOP_MAC);
+        stream.push_back(GRAPH_NO_SLOT);
+        stream.push_back(bcode(bp) | bcode(bq) << 16);
+        stream.push_back(sp);
+        stream.push_back(sq);
+        stream.push_back(sc);
+        stream.push_back(bcode(bc));
+        ninstr++;
+        return bp * bq / 168.9 + 1.0 + bc;
+    };
     const uint32_t PREV = GRAPH_SRC_PREV << 29;
     for (uint32_t i = 0; i < n; i++) {
         // resolve the operands: intermediates become slots or the forwarded register
@@ -175,6 +249,7 @@ int graph_compile(int field, const mira_graph *gr, uint32_t num_challenges, uint
             case MIRA_OP_DOUBLE: rb = emit(GOP_DBL, s[0], b[0], 0, 0); break;
             case MIRA_OP_NEGATE: rb = emit(GOP_NEG, s[0], b[0], 0, 0); break;
             case MIRA_OP_STORE: rb = emit(GOP_COPY, s[0], b[0], 0, 0); break;
+            case OP_MAC_INTERNAL: rb = emit_mac(s[0], b[0], s[1], b[1], s[2], b[2]); break;
             default:                                         // HORNER: start, factor, parts[] (graph_evaluator.rs:148-155): value = value * factor + part
                 rb = emit(GOP_COPY, s[0], b[0], 0, 0);
                 for (uint32_t k = 0; k < calcs[i].nparts; k++) {
@@ -198,7 +273,7 @@ int graph_compile(int field, const mira_graph *gr, uint32_t num_challenges, uint
 
     Program pg;
     pg.field = field; pg.ninstr = ninstr; pg.nslots = nslots; pg.num_challenges = num_challenges; pg.num_columns = num_columns;
-    pg.num_rotations = gr->num_rotations; pg.num_calculations = n;
+    pg.num_rotations = gr->num_rotations; pg.num_calculations = n_in;
     for (uint32_t c = 0; c < num_columns; c++)
         if (col_used[c]) pg.used_columns.push_back(c);
     // static part on the device: code | constants (9 x 29-bit limbs, multiplier form) | rotations
@@ -217,7 +292,8 @@ int graph_compile(int field, const mira_graph *gr, uint32_t num_challenges, uint
     // dynamic part of an evaluation: challenges | column table, staged in pinned host memory
     pg.o_chal = 0;
     pg.o_cols = align16((size_t)num_challenges * 36);
-    pg.dyn_bytes = align16(pg.o_cols + (size_t)num_columns * sizeof(GraphCol)) + 16;
+    pg.o_jobs = align16(pg.o_cols + (size_t)num_columns * sizeof(GraphCol));
+    pg.dyn_bytes = align16(pg.o_jobs + (size_t)GRAPH_MAX_BATCH * sizeof(GraphJob)) + 16;
     int rc = pg.dyn.ensure(pg.dyn_bytes);
     if (rc == MIRA_OK && rt_host_alloc(reinterpret_cast<void **>(&pg.h_dyn), pg.dyn_bytes) != hipSuccess) { set_error("pinned allocation for the compiled graph failed"); rc = MIRA_E_ALLOC; }
     if (rc) { (void)rt_free(pg.d_static); if (pg.dyn.p) (void)rt_free(pg.dyn.p); return rc; }
@@ -237,57 +313,85 @@ int graph_free(uint64_t handle) {
     return MIRA_OK;
 }
 
-int graph_eval_compiled(uint64_t handle, const mira_eval_column *columns, uint32_t num_columns, const uint64_t *challenges, uint32_t num_challenges,
-                        size_t num_rows, void *d_out) {
+// count compiled graphs over the same columns and challenges, results to d_outs[k]; one launch per
+// GRAPH_MAX_BATCH graphs
+int graph_eval_batch(const uint64_t *handles, uint32_t count, const mira_eval_column *columns, uint32_t num_columns, const uint64_t *challenges,
+                     uint32_t num_challenges, size_t num_rows, void *const *d_outs) {
     int rc;
-    auto it = g_programs.find(handle);
-    if (it == g_programs.end()) { set_error("unknown graph handle"); return MIRA_E_BAD_ARG; }
-    Program &pg = it->second;
-    if (num_challenges != pg.num_challenges || num_columns != pg.num_columns) {
-        set_error("the graph was compiled for " + std::to_string(pg.num_challenges) + " challenges and " + std::to_string(pg.num_columns) + " columns");
-        return MIRA_E_BAD_ARG;
-    }
-    for (uint32_t col : pg.used_columns) {
-        if (!columns[col].d_data) {
-            set_error("column variable index out of boundary: " + std::to_string(col));   // EvalError::ColumnVariableIndexOutOfBoundary / InvalidWitnessIndex
+    if (count == 0) return MIRA_OK;
+    std::vector<Program *> pgs(count);
+    for (uint32_t k = 0; k < count; k++) {
+        auto it = g_programs.find(handles[k]);
+        if (it == g_programs.end()) { set_error("unknown graph handle"); return MIRA_E_BAD_ARG; }
+        Program &pg = *(pgs[k] = &it->second);
+        if (num_challenges != pg.num_challenges || num_columns != pg.num_columns) {
+            set_error("the graph was compiled for " + std::to_string(pg.num_challenges) + " challenges and " + std::to_string(pg.num_columns) + " columns");
             return MIRA_E_BAD_ARG;
         }
-        if (columns[col].kind != MIRA_COL_FIELD && columns[col].kind != MIRA_COL_BOOL) { set_error("unknown column kind"); return MIRA_E_BAD_ARG; }
+        if (pg.field != pgs[0]->field) { set_error("the graphs of a batch must be over one field"); return MIRA_E_BAD_ARG; }
+        for (uint32_t col : pg.used_columns) {
+            if (!columns[col].d_data) {
+                set_error("column variable index out of boundary: " + std::to_string(col));   // EvalError::ColumnVariableIndexOutOfBoundary / InvalidWitnessIndex
+                return MIRA_E_BAD_ARG;
+            }
+            if (columns[col].kind != MIRA_COL_FIELD && columns[col].kind != MIRA_COL_BOOL) { set_error("unknown column kind"); return MIRA_E_BAD_ARG; }
+        }
+        if (num_rows && !d_outs[k]) { set_error("null output"); return MIRA_E_BAD_ARG; }
     }
     if (num_rows == 0) return MIRA_OK;
     if (num_rows > ((size_t)1 << 31)) { set_error("num_rows > 2^31"); return MIRA_E_UNSUPPORTED; }
-    if (pg.num_calculations == 0) {                          // Ok(F::ZERO), graph_evaluator.rs:386-389
-        RT_CHECK(rt_memset(d_out, 0, num_rows * 32, g.stream));
-        RT_CHECK(rt_sync(g.stream));
-        return MIRA_OK;
-    }
     const uint32_t block = 256;
     const uint32_t grid = (uint32_t)std::min<size_t>((num_rows + block - 1) / block, 256 * 4);
     const size_t T = (size_t)grid * block;
-    if ((rc = g.graph_ws.ensure(std::max<size_t>(1, pg.nslots) * 9 * T * 4))) return rc;
+    Program &p0 = *pgs[0];                                   // its staging carries the batch's challenges, column table and job table
     // the call's challenges (lifted to the multiplier form) and column pointers: one small copy from pinned memory
     for (uint32_t k = 0; k < num_challenges; k++)
-        to_limbs29(pg.field, challenges + (size_t)k * 4, reinterpret_cast<uint32_t *>(pg.h_dyn + pg.o_chal) + (size_t)k * 9);
+        to_limbs29(p0.field, challenges + (size_t)k * 4, reinterpret_cast<uint32_t *>(p0.h_dyn + p0.o_chal) + (size_t)k * 9);
     for (uint32_t c = 0; c < num_columns; c++) {
         GraphCol gc{reinterpret_cast<const unsigned char *>(columns[c].d_data), columns[c].kind, 0};
-        memcpy(pg.h_dyn + pg.o_cols + (size_t)c * sizeof(GraphCol), &gc, sizeof gc);
+        memcpy(p0.h_dyn + p0.o_cols + (size_t)c * sizeof(GraphCol), &gc, sizeof gc);
     }
-    RT_CHECK(rt_h2d(pg.dyn.p, pg.h_dyn, pg.dyn_bytes, g.stream));
-    const unsigned char *st = reinterpret_cast<const unsigned char *>(pg.d_static), *dy = reinterpret_cast<const unsigned char *>(pg.dyn.p);
     tm_begin();
-    if (pg.field == MIRA_FIELD_FQ)
-        LAUNCH(k_graph_eval<Fq29>, grid, block, 0, g.stream, reinterpret_cast<const uint32_t *>(st + pg.o_code), pg.ninstr, reinterpret_cast<const uint32_t *>(st + pg.o_const),
-               reinterpret_cast<const uint32_t *>(dy + pg.o_chal), reinterpret_cast<const int32_t *>(st + pg.o_rot), reinterpret_cast<const GraphCol *>(dy + pg.o_cols),
-               (uint64_t)num_rows, reinterpret_cast<uint32_t *>(g.graph_ws.p), reinterpret_cast<unsigned char *>(d_out));
-    else
-        LAUNCH(k_graph_eval<Fr29>, grid, block, 0, g.stream, reinterpret_cast<const uint32_t *>(st + pg.o_code), pg.ninstr, reinterpret_cast<const uint32_t *>(st + pg.o_const),
-               reinterpret_cast<const uint32_t *>(dy + pg.o_chal), reinterpret_cast<const int32_t *>(st + pg.o_rot), reinterpret_cast<const GraphCol *>(dy + pg.o_cols),
-               (uint64_t)num_rows, reinterpret_cast<uint32_t *>(g.graph_ws.p), reinterpret_cast<unsigned char *>(d_out));
+    for (uint32_t done = 0; done < count; done += GRAPH_MAX_BATCH) {
+        const uint32_t cnt = std::min<uint32_t>(GRAPH_MAX_BATCH, count - done);
+        if (done) RT_CHECK(rt_sync(g.stream));               // the previous launch's copy still reads the pinned staging
+        uint32_t live = 0, max_slots = 1;
+        for (uint32_t k = 0; k < cnt; k++) {
+            Program &pg = *pgs[done + k];
+            if (pg.num_calculations == 0) {                  // Ok(F::ZERO), graph_evaluator.rs:386-389
+                RT_CHECK(rt_memset(d_outs[done + k], 0, num_rows * 32, g.stream));
+                continue;
+            }
+            const unsigned char *st = reinterpret_cast<const unsigned char *>(pg.d_static);
+            GraphJob job{reinterpret_cast<const uint32_t *>(st + pg.o_code), reinterpret_cast<const uint32_t *>(st + pg.o_const),
+                         reinterpret_cast<const int32_t *>(st + pg.o_rot), reinterpret_cast<unsigned char *>(d_outs[done + k]), pg.ninstr, 0};
+            memcpy(p0.h_dyn + p0.o_jobs + (size_t)live * sizeof(GraphJob), &job, sizeof job);
+            max_slots = std::max(max_slots, pg.nslots);
+            live++;
+        }
+        if (live) {
+            const size_t ws_stride = (size_t)max_slots * 9 * T;
+            if ((rc = g.graph_ws.ensure(ws_stride * live * 4))) return rc;
+            RT_CHECK(rt_h2d(p0.dyn.p, p0.h_dyn, p0.dyn_bytes, g.stream));
+            const unsigned char *dy = reinterpret_cast<const unsigned char *>(p0.dyn.p);
+            if (p0.field == MIRA_FIELD_FQ)
+                LAUNCH(k_graph_eval<Fq29>, dim3(grid, live), block, 0, g.stream, reinterpret_cast<const GraphJob *>(dy + p0.o_jobs), reinterpret_cast<const uint32_t *>(dy + p0.o_chal),
+                       reinterpret_cast<const GraphCol *>(dy + p0.o_cols), (uint64_t)num_rows, reinterpret_cast<uint32_t *>(g.graph_ws.p), (uint64_t)ws_stride);
+            else
+                LAUNCH(k_graph_eval<Fr29>, dim3(grid, live), block, 0, g.stream, reinterpret_cast<const GraphJob *>(dy + p0.o_jobs), reinterpret_cast<const uint32_t *>(dy + p0.o_chal),
+                       reinterpret_cast<const GraphCol *>(dy + p0.o_cols), (uint64_t)num_rows, reinterpret_cast<uint32_t *>(g.graph_ws.p), (uint64_t)ws_stride);
+        }
+    }
     tm_mark("graph_eval");
     RT_CHECK(rt_last());
     RT_CHECK(rt_sync(g.stream));
     tm_end();
     return MIRA_OK;
+}
+
+int graph_eval_compiled(uint64_t handle, const mira_eval_column *columns, uint32_t num_columns, const uint64_t *challenges, uint32_t num_challenges,
+                        size_t num_rows, void *d_out) {
+    return graph_eval_batch(&handle, 1, columns, num_columns, challenges, num_challenges, num_rows, &d_out);
 }
 
 // one-shot form: compile, evaluate, free

@@ -28,13 +28,14 @@ struct GraphCol {
 
 // Compiled instruction stream: per instruction
 //   [op | K << 8]  [dst slot]  [bounds of a and b in 1/256 P: lo 16 | hi 16 bits]  [source a]  ([source b])
+// and for GOP_MAC (a * b + c: an addition that absorbed the product feeding it, graph.hip) two more: [source c] [bound of c]
 // INTERMEDIATE payloads are slots; GRAPH_SRC_PREV = the value of the instruction just before
 // (still in registers -- most results of a post-order expression walk are consumed by the very next
 // instruction and never touch the workspace).  K = the multiple of P a subtraction adds.  The
 // bounds word only feeds the test build's bound bookkeeping (F29_TRACK).
 static constexpr uint32_t GRAPH_SRC_PREV = 4u;
 static constexpr uint32_t GRAPH_NO_SLOT = 0xFFFFFFFFu;
-static constexpr uint32_t GOP_ADD = 0, GOP_SUB = 1, GOP_MUL = 2, GOP_SQR = 3, GOP_DBL = 4, GOP_NEG = 5, GOP_COPY = 6, GOP_NORM = 7;
+static constexpr uint32_t GOP_ADD = 0, GOP_SUB = 1, GOP_MUL = 2, GOP_SQR = 3, GOP_DBL = 4, GOP_NEG = 5, GOP_COPY = 6, GOP_NORM = 7, GOP_MAC = 8;
 static constexpr double GRAPH_MAX_BOUND = 12.0;          // of every stored or forwarded value, in multiples of P
 
 template <class F> DEV Fe29<F> graph_sub(const Fe29<F> &a, const Fe29<F> &b, uint32_t K) {
@@ -46,11 +47,27 @@ template <class F> DEV Fe29<F> graph_sub(const Fe29<F> &a, const Fe29<F> &b, uin
     }
 }
 
+// one compiled graph of a batch: the graphs of a batch (the d - 1 cross-term expressions of a fold
+// step, src/nifs/vanilla/mod.rs:100-121) read the same columns and challenges
+struct GraphJob {
+    const uint32_t *code, *consts29;
+    const int32_t *rotations;
+    unsigned char *out;
+    uint32_t ninstr, pad;
+};
+
+// grid = (row blocks, graphs of the batch): a fold step's handful of graphs over 2^17 rows are two waves
+// per SIMD each -- launched together they fill the wave slots (82 VGPRs: six per SIMD)
 template <class F>
-KERNEL void __launch_bounds__(256) k_graph_eval(const uint32_t *__restrict__ code, uint32_t ninstr, const uint32_t *__restrict__ consts29,
-                         const uint32_t *__restrict__ challenges29, const int32_t *__restrict__ rotations,
-                         const GraphCol *__restrict__ cols, uint64_t nrows, uint32_t *__restrict__ ws, unsigned char *__restrict__ out) {
+KERNEL void __launch_bounds__(256) k_graph_eval(const GraphJob *__restrict__ jobs, const uint32_t *__restrict__ challenges29,
+                         const GraphCol *__restrict__ cols, uint64_t nrows, uint32_t *__restrict__ ws_all, uint64_t ws_stride) {
     using S = typename F::Sat;
+    const GraphJob job = jobs[blockIdx.y];
+    const uint32_t *__restrict__ code = job.code, *__restrict__ consts29 = job.consts29;
+    const int32_t *__restrict__ rotations = job.rotations;
+    unsigned char *__restrict__ out = job.out;
+    const uint32_t ninstr = job.ninstr;
+    uint32_t *__restrict__ ws = ws_all + (size_t)blockIdx.y * ws_stride;
     const uint64_t T = (uint64_t)gridDim.x * blockDim.x, lane = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (uint64_t row = lane; row < nrows; row += T) {
         Fe29<F> v = f29_zero<F>(), prev;
@@ -86,6 +103,7 @@ KERNEL void __launch_bounds__(256) k_graph_eval(const uint32_t *__restrict__ cod
             if (op == GOP_ADD) { v = f29_add(a, fetch(pc[4], bounds >> 16)); pc += 5; }
             else if (op == GOP_SUB) { v = graph_sub(a, fetch(pc[4], bounds >> 16), K); pc += 5; }
             else if (op == GOP_MUL) { v = f29_mul(a, fetch(pc[4], bounds >> 16)); pc += 5; }
+            else if (op == GOP_MAC) { const Fe29<F> b = fetch(pc[4], bounds >> 16), c = fetch(pc[5], pc[6]); v = f29_add(f29_mul(a, b), c); pc += 7; }
             else {
                 if (op == GOP_SQR) v = f29_sqr(a);
                 else if (op == GOP_DBL) v = f29_dbl(a);

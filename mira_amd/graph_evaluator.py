@@ -252,6 +252,21 @@ class GraphEvaluator:
             raise
         return out
 
+    @staticmethod
+    def evaluate_batch_device(evaluators, columns, challenges, num_rows, d_outs, lib=None):
+        """The cross-term graphs of one fold step (src/nifs/vanilla/mod.rs:100-121 walks them one after
+        the other over the same data) in one submission; evaluator k writes d_outs[k]."""
+        lib = lib or _lib.load()
+        if not evaluators:
+            return
+        handles = (ctypes.c_uint64 * len(evaluators))(*[ev.compiled(len(challenges), len(columns), lib) for ev in evaluators])
+        cols = (_lib.MiraEvalColumn * max(1, len(columns)))()
+        for k, c in enumerate(columns):
+            cols[k].d_data, cols[k].kind = (None, 0) if c is None else (c[0], c[1])
+        ch = to_montgomery(list(challenges), evaluators[0].field)
+        outs = (ctypes.c_void_p * len(evaluators))(*d_outs)
+        lib.check(lib.c.mira_graph_eval_batch(handles, len(evaluators), cols, len(columns), ch.ctypes.data_as(ctypes.c_void_p), len(ch), num_rows, outs))
+
     def evaluate(self, getter, lib=None):
         """Host-array convenience: getter = dict(selectors=[bool arrays], fixed=[(n, 4) uint64],
         advice=[(n, 4) uint64], challenges=[ints]) as the reference's test mock
@@ -334,8 +349,8 @@ def commit_cross_terms(key, evaluators, domain, lib=None):
             if ev is None:
                 zero = zero if zero is not None else np.zeros((n, 4), dtype=np.uint64)
                 lib.upload(d + k * n * 32, zero)
-            else:
-                ev.evaluate_device(cols, domain.challenges, n, d_out=d + k * n * 32, lib=lib)
+        live = [k for k, ev in enumerate(evaluators) if ev is not None]
+        GraphEvaluator.evaluate_batch_device([evaluators[k] for k in live], cols, domain.challenges, n, [d + k * n * 32 for k in live], lib=lib)
         commits = key.commit_batch_device(d, n, count) if count else np.zeros((0, 8), dtype=np.uint64)
     except Exception:
         lib.free(d)

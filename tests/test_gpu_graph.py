@@ -44,6 +44,7 @@ def test_random_graphs_vs_oracle(gpu_lib, field, log_rows, seed):
     rng = random.Random(seed)
     chal = ints_to_mont(arrs["challenges"], mod)
     try:
+        singles = []
         for nterms in (1, 5, 24):
             e = gate_like_expression(rng, nterms, 7, 12, 3)
             ge = G.GraphEvaluator.new(e, field)
@@ -52,11 +53,18 @@ def test_random_graphs_vs_oracle(gpu_lib, field, log_rows, seed):
             got = gpu_lib.download(d, (n, 4)); gpu_lib.free(d)
             want = C.graph_eval(field, code, ge.num_intermediates, consts, rots, oracle_columns(arrs), chal, n)
             assert (got == want).all(), (nterms, ge.num_intermediates)
+            singles.append((ge, got))
             # spot rows against direct evaluation of the tree with Python integers
             ints = dict(selectors=arrs["selectors"], challenges=arrs["challenges"],
                         fixed=[_Lazy(f, mod) for f in arrs["fixed"]], advice=[_Lazy(a, mod) for a in arrs["advice"]])
             for r in (0, 1, n // 2, n - 1):
                 assert mont_to_ints(got[r:r + 1], mod)[0] == P.eval_expression(e.to_tuple(), ints, r, n, mod)
+        # the same graphs as one submission (mira_graph_eval_batch), 19 of them: two launches
+        reps = 19
+        d_all = gpu_lib.alloc(reps * n * 32)
+        G.GraphEvaluator.evaluate_batch_device([singles[k % 3][0] for k in range(reps)], cols, arrs["challenges"], n, [d_all + k * n * 32 for k in range(reps)], lib=gpu_lib)
+        got_all = gpu_lib.download(d_all, (reps, n, 4)); gpu_lib.free(d_all)
+        assert all((got_all[k] == singles[k % 3][1]).all() for k in range(reps))
     finally:
         for p in ptrs:
             gpu_lib.free(p)

@@ -6,7 +6,7 @@ import random
 import numpy as np
 import pytest
 
-from graph_cases import MODS, mock_data, oracle_columns, random_expression
+from graph_cases import MODS, gate_like_expression, mock_data, oracle_columns, random_expression
 from helpers import ints_to_mont, mont_to_ints
 from mira_amd import _lib, commitment as cm
 from mira_amd import graph_evaluator as G
@@ -91,6 +91,31 @@ def test_random_trees_three_ways(emu_lib, field, seed):
         want = direct(e, ints, n, mod)
         assert mont_to_ints(C.graph_eval(field, code, ge.num_intermediates, consts, rots, oracle_columns(arrs), ints_to_mont(ints["challenges"], mod), n), mod) == want
         assert mont_to_ints(ge.evaluate(arrs, lib=emu_lib), mod) == want
+
+
+def test_batch_equals_one_by_one(emu_lib):
+    """mira_graph_eval_batch: the cross-term graphs of a fold step over the same columns in one
+    submission (18 graphs: two launches), an empty batch, a graph that reads a missing column."""
+    field, n = 1, 29
+    mod = MODS[field]
+    rng = random.Random(77)
+    ints, arrs = mock_data(field, n, 1, 2, 4, 2, seed=177)
+    ptrs, cols = [], []
+    for s_ in arrs["selectors"]:
+        p = emu_lib.alloc(s_.nbytes); emu_lib.upload(p, s_); ptrs.append(p); cols.append((p, G.COL_BOOL))
+    for f in list(arrs["fixed"]) + list(arrs["advice"]):
+        p = emu_lib.alloc(f.nbytes); emu_lib.upload(p, f); ptrs.append(p); cols.append((p, G.COL_FIELD))
+    evs = [G.GraphEvaluator.new(gate_like_expression(rng, rng.choice([1, 3, 8]), 5, 7, 2) if k % 2 else random_expression(rng, 5, 7, 2), field) for k in range(18)]
+    want = [mont_to_ints(ev.evaluate(arrs, lib=emu_lib), mod) for ev in evs]
+    d = emu_lib.alloc(len(evs) * n * 32)
+    G.GraphEvaluator.evaluate_batch_device(evs, cols, ints["challenges"], n, [d + k * n * 32 for k in range(len(evs))], lib=emu_lib)
+    got = emu_lib.download(d, (len(evs), n, 4))
+    assert [mont_to_ints(got[k], mod) for k in range(len(evs))] == want
+    G.GraphEvaluator.evaluate_batch_device([], cols, ints["challenges"], n, [], lib=emu_lib)
+    with pytest.raises(_lib.MiraError):
+        G.GraphEvaluator.evaluate_batch_device(evs[:2], cols[:2] + [None] * (len(cols) - 2), ints["challenges"], n, [d, d + n * 32], lib=emu_lib)
+    for p in ptrs + [d]:
+        emu_lib.free(p)
 
 
 def flat_graph(calcs):

@@ -77,7 +77,10 @@ template <class F> HD void xyzz29_add_affine(Xyzz29<F> &acc, const Aff29<F> &q) 
     Fe29<F> ppp = f29_mul(p, pp);                               // 24
     Fe29<F> qq = f29_mul(acc.x, pp);                            // 18
     Fe29<F> x3 = f29_sub_b_2c<7>(f29_sqr(r), ppp, qq);                     // 64 ; PPP + 2Q < 6 -> X3 < 9
-    Fe29<F> y3 = f29_mul2_add(r, f29_sub<10>(qq, x3), f29_neg<6>(acc.y), ppp);      // R (Q - X3) - Y1 PPP in one reduction: 8 * 12 + 6 * 2 = 108 -> Y3 < 2
+    // R (Q - X3) - Y1 PPP in one reduction: 8 * 12 + 7 * 2 = 110 -> Y3 < 2.  -Y1 without a carry pass
+    // (Y1 is a multiplier result or an unpacked value: limbs 0..7 <= 2^29 - 1): its limbs stay below
+    // 2^30, and the shared columns hold 9 * 2^58 (R, Q - X3 carried) + 9 * 2^59 + the reduction's 9 * 2^58 < 2^64
+    Fe29<F> y3 = f29_mul2_add(r, f29_sub<10>(qq, x3), f29_sub_nc<7>(f29_zero<F>(), acc.y), ppp);
     acc.x = x3; acc.y = y3;
     acc.zz = f29_mul(acc.zz, pp);
     acc.zzz = f29_mul(acc.zzz, ppp);
@@ -102,7 +105,7 @@ template <class F> HD void xyzz29_add(Xyzz29<F> &acc, const Xyzz29<F> &q) {
     Fe29<F> ppp = f29_mul(p, pp);
     Fe29<F> qq = f29_mul(u1, pp);
     Fe29<F> x3 = f29_sub_b_2c<7>(f29_sqr(r), ppp, qq);                     // < 9
-    Fe29<F> y3 = f29_mul2_add(r, f29_sub<10>(qq, x3), f29_neg<2>(s1), ppp);        // 5 * 12 + 2 * 2 -> < 2
+    Fe29<F> y3 = f29_mul2_add(r, f29_sub<10>(qq, x3), f29_sub_nc<3>(f29_zero<F>(), s1), ppp);   // 5 * 12 + 3 * 2 -> < 2 (-S1 uncarried: S1 is a multiplier result)
     acc.x = x3; acc.y = y3;
     acc.zz = f29_mul(f29_mul(acc.zz, q.zz), pp);
     acc.zzz = f29_mul(f29_mul(acc.zzz, q.zzz), ppp);
@@ -118,15 +121,28 @@ template <class F> HD Aff29<F> aff29_load(const void *p, bool negate) {
     if (negate && !f29_is_literal_zero(r.y)) r.y = f29_neg<2>(r.y);   // 2P - y < 2 P ... stays an exact negation mod P
     return r;
 }
+// (the negation of a base is taken on the saturated words, P - y by one borrow chain, before they are
+// unpacked: 16 instructions against ~60 for a biased 29-bit-limb subtraction with its carry pass;
+// y = 0 -- the identity (0, 0) -- stays literally zero)
 template <class F> HD Aff29<F> aff29_from_raw(const U4 &a, const U4 &b, const U4 &c, const U4 &d, bool negate) {
     using S = typename F::Sat;
     Fe<S> x, y;
     x.l[0] = a.x; x.l[1] = a.y; x.l[2] = a.z; x.l[3] = a.w; x.l[4] = b.x; x.l[5] = b.y; x.l[6] = b.z; x.l[7] = b.w;
     y.l[0] = c.x; y.l[1] = c.y; y.l[2] = c.z; y.l[3] = c.w; y.l[4] = d.x; y.l[5] = d.y; y.l[6] = d.z; y.l[7] = d.w;
+    Fe<S> ny;
+    uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint64_t v = (uint64_t)S::P[i] - y.l[i] - br;
+        ny.l[i] = (uint32_t)v;
+        br = (v >> 32) & 1;
+    }
+    const bool flip = negate && !fe_is_zero(y);
+#pragma unroll
+    for (int i = 0; i < 8; i++) y.l[i] = flip ? ny.l[i] : y.l[i];
     Aff29<F> r;
     r.x = f29_unpack_canonical<F>(x);
     r.y = f29_unpack_canonical<F>(y);
-    if (negate && !f29_is_literal_zero(r.y)) r.y = f29_neg<2>(r.y);
     return r;
 }
 // XYZZ partial sums: 4 x 9 raw loose limbs = 144 B

@@ -198,9 +198,19 @@ template <class F> inline void f29_check_columns(const Fe29<F> &a, const Fe29<F>
     const long double col = 9.0L * (long double)ma * (long double)mb + 9.0L * 536870912.0L * 536870912.0L + 68719476736.0L;
     assert(col < 18446744073709551616.0L);
 }
+template <class F> inline void f29_check_columns2(const Fe29<F> &a, const Fe29<F> &b, const Fe29<F> &c, const Fe29<F> &d) {
+    uint32_t m[4] = {0, 0, 0, 0};
+    const Fe29<F> *v[4] = {&a, &b, &c, &d};
+    for (int k = 0; k < 4; k++)
+        for (int i = 0; i < 9; i++) m[k] = v[k]->l[i] > m[k] ? v[k]->l[i] : m[k];
+    const long double col = 9.0L * ((long double)m[0] * m[1] + (long double)m[2] * m[3]) + 9.0L * 536870912.0L * 536870912.0L + 68719476736.0L;
+    assert(col < 18446744073709551616.0L);
+}
 #define F29_CHECK_COLUMNS(a, b) f29_check_columns(a, b)
+#define F29_CHECK_COLUMNS2(a, b, c, d) f29_check_columns2(a, b, c, d)
 #else
 #define F29_CHECK_COLUMNS(a, b) ((void)0)
+#define F29_CHECK_COLUMNS2(a, b, c, d) ((void)0)
 #endif
 
 // Montgomery product a * b * 2^-261 mod P.  Limbs of a and b < 2^30 (or one of them carried and the
@@ -233,11 +243,13 @@ template <class F> HD Fe29<F> f29_mul(const Fe29<F> &a, const Fe29<F> &b) {
     return r;
 }
 // (a * b + c * d) * 2^-261 mod P with ONE Montgomery reduction: the two products share the 18
-// column accumulators.  All four operands must be carried (limbs < 2^29 + 8, which every f29
-// function returns): a column then holds at most 18 products < 2^58.01 plus 9 reduction products
-// < 2^58 and a carry, < 2^62.8.  Result loose, < (a b + c d) / (2^261 P) + 1 in multiples of P.
+// column accumulators.  Operands are carried (limbs < 2^29 + 8, which every carrying f29 function
+// returns): a column then holds at most 18 products < 2^58.01 plus 9 reduction products < 2^58 and a
+// carry, < 2^62.8 -- which leaves room for ONE uncarried operand with limbs < 2^30 (f29_sub_nc of a
+// zero minuend; the test build checks the columns of every call).  Result loose, < (a b + c d) / (2^261 P) + 1 in multiples of P.
 template <class F> HD Fe29<F> f29_mul2_add(const Fe29<F> &a, const Fe29<F> &b, const Fe29<F> &c2, const Fe29<F> &d) {
     F29_ASSERT(F29_GET(a) * F29_GET(b) + F29_GET(c2) * F29_GET(d) <= F29_RP_OVER_P);
+    F29_CHECK_COLUMNS2(a, b, c2, d);
     uint64_t c[18];
 #pragma unroll
     for (int k = 0; k < 18; k++) c[k] = 0;
@@ -298,14 +310,20 @@ template <class F> HD Fe29<F> f29_sqr(const Fe29<F> &a) {
     return r;
 }
 
+// P[0]^-1 mod 2^29 (P is odd): Newton iteration, five doublings of the precision from 3 bits
+constexpr uint32_t f29_inv_mod_2_29(uint32_t p0) {
+    uint32_t x = p0;                                   // p0 * p0 = 1 mod 8
+    for (int i = 0; i < 5; i++) x *= 2u - p0 * x;
+    return x & M29;
+}
 // x == 0 mod P for a loose x < KMAX * P.  Fast reject on the low limb (carries only move upward, so
-// the low 29 bits are already final), full compare otherwise.
+// the low 29 bits are already final): x = k P needs l[0] = k P[0] mod 2^29, i.e. l[0] * P[0]^-1 = k <= KMAX
+// -- one multiplication instead of a comparison per multiple.  Full compare otherwise.
 template <int KMAX, class F> HD bool f29_is_zero_mod_p(const Fe29<F> &a) {
     F29_ASSERT(F29_GET(a) <= (double)KMAX);
-    const uint32_t low = a.l[0] & M29;
-    bool maybe = false;
-#pragma unroll
-    for (uint32_t k = 0; k <= KMAX; k++) maybe |= (low == ((k * F::P[0]) & M29));
+    constexpr uint32_t PINV = f29_inv_mod_2_29(F::P[0]);
+    static_assert(((F::P[0] * PINV) & M29) == 1u, "P[0]^-1 mod 2^29");
+    const bool maybe = ((a.l[0] * PINV) & M29) <= (uint32_t)KMAX;
     if (!maybe) return false;
     // exact: propagate carries, then compare with k * P
     uint32_t n[9];

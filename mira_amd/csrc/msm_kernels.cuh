@@ -283,7 +283,7 @@ template <bool ADD, class F> DEV Xyzz29<F> run_start(const unsigned char *bucket
     else return xyzz29_identity<F>();
 }
 template <class F, bool ADD>
-KERNEL void __launch_bounds__(128) k_accumulate(const uint32_t *__restrict__ sorted, const uint32_t *__restrict__ offsets, uint32_t NB,
+KERNEL void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) k_accumulate(const uint32_t *__restrict__ sorted, const uint32_t *__restrict__ offsets, uint32_t NB,
                          const unsigned char *__restrict__ bases,
                          const uint32_t *__restrict__ plan, unsigned char *__restrict__ bucket_sums,
                          unsigned char *__restrict__ head_part, unsigned char *__restrict__ tail_part, uint32_t *__restrict__ tail_key) {

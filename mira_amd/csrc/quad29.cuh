@@ -88,6 +88,6 @@ template <class F> DEV void xyzz29_add_quad(Xyzz29<F> &acc, const Xyzz29<F> &q) 
     quad_mul4(p, pp, u1, pp, zz12, pp, zz12, pp, ppp, qq, acc.zz, t0);                 // 10, 4, 4
     acc.x = f29_sub_b_2c<7>(rr, ppp, qq);                         // < 9
     Fe29<F> ya, yb;
-    quad_mul4(r, f29_sub<10>(qq, acc.x), f29_neg<2>(s1), ppp, zzz12, ppp, zzz12, ppp, ya, yb, acc.zzz, t0);   // 60, 4, 4
+    quad_mul4(r, f29_sub<10>(qq, acc.x), f29_sub_nc<3>(f29_zero<F>(), s1), ppp, zzz12, ppp, zzz12, ppp, ya, yb, acc.zzz, t0);   // 60, 6, 4 (-S1 uncarried: limbs < 2^30 beside a carried operand)
     acc.y = f29_add(ya, yb);                                      // < 4
 }

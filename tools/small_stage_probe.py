@@ -2,6 +2,8 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mira_amd import _lib, commitment as cm
+if os.environ.get("MIRA_PROBE_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["MIRA_PROBE_LIB"])
 lib = _lib.load()
 for n in [int(a) for a in sys.argv[1:]] or [131072]:
     key = cm.CommitmentKey.synthetic(0, n); d = cm.synth_scalars_device(0, n)

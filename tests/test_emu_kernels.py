@@ -219,8 +219,8 @@ def test_emu_shared_bucket_tables_16bit(emu_lib, tune):
     pb, cb, wb = key.commit_partial_device(130, d + 130 * 32, n - 130)
     assert (ca, wa) == (0, 16) == (cb, wb)
     assert (cm.combine_partials(cid, np.stack([pa, pb]), ca, wa, lib=emu_lib) == want_dense).all()
-    # a batch over the tables: one bucket set per commitment (three vectors of a prefix length, one all zeros)
-    vs = [dense[:200], sc[:200], np.zeros((200, 4), dtype=np.uint64)]
+    # a batch over the tables: one bucket set per commitment (two vectors of a prefix length, one all zeros)
+    vs = [dense[:200], np.zeros((200, 4), dtype=np.uint64)]
     want_b = np.stack([C.commit(cid, bs[:200], v) for v in vs])
     assert (key.commit_batch(vs) == want_b).all()
     tune(_lib.TUNE_STAGED_MIN_N, 1)                           # the LDS-staged sort with table indices

@@ -110,6 +110,9 @@ int mira_msm_combine(int curve, const uint64_t *partials /* nparts * MIRA_PARTIA
 /* Force the window width c (4..16) for every later MSM; 0 = choose from n.  All ranks of a
  * sharded MSM must use the same c. */
 int mira_msm_set_window_bits(int32_t c);
+/* Diagnostics: the window width and count the planner used for the most recent commit of this
+ * process (0 / the number of partial sums in fixed-base table mode). */
+int mira_msm_last_plan(int32_t *window_bits, int32_t *num_windows);
 
 /* Thresholds of the engine's internal choices, for tests and tuning runs (they never change a
  * result): the smallest MSM that takes the LDS-staged two-level sort, the smallest MSM that uses a

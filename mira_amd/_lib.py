@@ -21,7 +21,7 @@ SYMBOLS = [
     "mira_device_count", "mira_init", "mira_set_stream", "mira_last_error",
     "mira_msm_register_bases", "mira_msm_register_bases_device", "mira_msm_unregister", "mira_msm_check_bases", "mira_msm_precompute", "mira_msm_precompute_ex",
     "mira_msm_download_bases", "mira_fold_witness_device", "mira_fold_error_device", "mira_g1_mul_add", "mira_g1_lincomb", "mira_graph_eval_device", "mira_graph_compile", "mira_graph_eval_compiled", "mira_graph_eval_batch", "mira_graph_free", "mira_pow_tree_reduce_device", "mira_lincomb_device",
-    "mira_msm", "mira_msm_device", "mira_msm_batch", "mira_msm_batch_device", "mira_msm_partial_device", "mira_msm_combine", "mira_msm_set_window_bits",
+    "mira_msm", "mira_msm_device", "mira_msm_batch", "mira_msm_batch_device", "mira_msm_partial_device", "mira_msm_combine", "mira_msm_set_window_bits", "mira_msm_last_plan",
     "mira_ntt_bn256_fr", "mira_ntt_bn256_fr_device", "mira_fft_bn256_fr", "mira_ifft_bn256_fr",
     "mira_fft_bn256_fr_device", "mira_ifft_bn256_fr_device", "mira_coset_fft_bn256_fr", "mira_coset_ifft_bn256_fr",
     "mira_get_omega_or_inv", "mira_synth_scalars_device", "mira_synth_bases_device",
@@ -96,7 +96,7 @@ class MiraLib:
             "mira_lincomb_device": [ctypes.c_int, vp, vp, u64p, sz, sz],
             "mira_msm_batch": [u64, vp, sz, sz, u64p], "mira_msm_batch_device": [u64, vp, sz, sz, sz, u64p],
             "mira_msm_partial_device": [u64, sz, vp, sz, u64p, vp, vp],
-            "mira_msm_combine": [ctypes.c_int, u64p, sz, i32, i32, u64p], "mira_msm_set_window_bits": [i32],
+            "mira_msm_combine": [ctypes.c_int, u64p, sz, i32, i32, u64p], "mira_msm_set_window_bits": [i32], "mira_msm_last_plan": [vp, vp],
             "mira_ntt_bn256_fr": [u64p, u32, u64p], "mira_ntt_bn256_fr_device": [vp, u32, u64p],
             "mira_fft_bn256_fr": [u64p, u32], "mira_ifft_bn256_fr": [u64p, u32],
             "mira_fft_bn256_fr_device": [vp, u32], "mira_ifft_bn256_fr_device": [vp, u32],

@@ -129,16 +129,16 @@ static int upload_consts() {
 static const int plan_log_n[10] = {6, 10, 13, 15, 16, 17, 18, 19, 20, 21};
 static const double plan_wall_us[10][17] = {
     //            c = 4     5     6     7     8     9    10    11    12    13    14    15    16
-    {0, 0, 0, 0,   256,  263,  297,  318,  371,  396,  416,  467,  471,  539,  588,  913,  921},
-    {0, 0, 0, 0,   328,  285,  315,  316,  294,  333,  384,  390,  497,  544,  632,  715,  841},
-    {0, 0, 0, 0,   323,  319,  362,  398,  361,  363,  359,  523,  533,  546,  602,  709,  822},
-    {0, 0, 0, 0,   492,  480,  493,  498,  455,  524,  448,  461,  510,  540,  614,  695,  776},
-    {0, 0, 0, 0,   575,  531,  532,  544,  525,  611,  694,  542,  592,  618,  690,  741,  816},
-    {0, 0, 0, 0,   873,  776,  763,  718,  642,  716,  744,  889,  650,  666,  755,  791,  885},
-    {0, 0, 0, 0,  1481, 1271, 1169, 1084,  977,  981, 1004, 1118,  885,  865,  936,  943, 1032},
-    {0, 0, 0, 0,  2796, 2301, 2019, 1863, 1612, 1761, 1642, 1672, 1338, 1274, 1323, 1301, 1350},
-    {0, 0, 0, 0,  5643, 4659, 3991, 3569, 3188, 3180, 2849, 2818, 2348, 2163, 2200, 2072, 2101},
-    {0, 0, 0, 0, 10920, 9178, 7970, 6984, 6127, 6117, 5473, 5171, 4506, 4174, 3991, 3697, 3702},
+    {0, 0, 0, 0,   228,   240,   274,   293,   330,   356,   359,   416,   454,   522,   568,   886,   939},
+    {0, 0, 0, 0,   304,   258,   282,   290,   267,   305,   358,   362,   483,   538,   624,   674,   808},
+    {0, 0, 0, 0,   290,   284,   322,   352,   306,   320,   320,   346,   411,   485,   540,   653,   758},
+    {0, 0, 0, 0,   461,   450,   459,   457,   421,   489,   415,   427,   474,   508,   580,   655,   713},
+    {0, 0, 0, 0,   536,   491,   493,   505,   486,   569,   645,   502,   557,   581,   636,   679,   775},
+    {0, 0, 0, 0,   798,   703,   684,   655,   586,   641,   687,   833,   596,   618,   702,   722,   827},
+    {0, 0, 0, 0,  1335,  1134,  1055,   979,   875,   912,   922,  1043,   811,   798,   868,   863,   941},
+    {0, 0, 0, 0,  2494,  2069,  1859,  1670,  1445,  1574,  1474,  1521,  1238,  1174,  1234,  1172,  1214},
+    {0, 0, 0, 0,  4899,  3997,  3513,  3043,  2714,  2849,  2571,  2501,  2137,  1996,  2014,  1879,  1895},
+    {0, 0, 0, 0,  9830,  8161,  7043,  6200,  5380,  5475,  4802,  4552,  4024,  3650,  3548,  3280,  3231},
 };
 static double plan_table_us(uint32_t c, double n_eff) {
     const double x = std::log2(std::max(n_eff, 1.0));
@@ -150,22 +150,45 @@ static double plan_table_us(uint32_t c, double n_eff) {
         }
     return plan_wall_us[9][c] * n_eff / std::exp2((double)plan_log_n[9]);
 }
-static double plan_cost_us(uint32_t c, double n, uint32_t count, const uint32_t *bitlen_hist) {
+// additions per MSM and the heaviest bucket load of a length distribution (h[len] scalars of bit length
+// len).  Integer arithmetic only: this runs 13 times per commit on the host (with exp2 / ceil on
+// doubles it cost 40 us, more than the choice of width gains at 2^16 pairs).
+static void plan_len_stats(uint32_t c, const double *h, double *adds_out, double *load_out) {
+    double adds = 0, load = 0;
+    for (uint32_t len = 1; len < 256; len++) {
+        if (h[len] == 0) continue;
+        adds += h[len] * (double)((len + c - 1) / c);
+        load = std::max(load, h[len] / (double)(1u << ((len - 1) % c)));
+        if (len % c == 0) load = std::max(load, h[len]);
+    }
+    *adds_out = adds; *load_out = load;
+}
+// lengths of UNIFORM field elements as fractions: r = 0.756 * 2^254 -> 254: 0.339, 253: 0.331, 252: 0.165, ...
+static const double *plan_uniform_fractions() {
+    static double f[256];
+    static bool ready = false;
+    if (!ready) {
+        for (int len = 0; len < 256; len++) f[len] = len > 254 ? 0.0 : len == 254 ? 0.3386 : len < 200 ? 0.0 : 0.6614 * std::exp2((double)len - 253.0);
+        ready = true;
+    }
+    return f;
+}
+static double plan_heavy_us(double adds, double load, uint32_t count) {
+    const double seg = std::max(16.0, adds * count / (256.0 * 4 * 3 * 64));
+    const double partials = load / seg;
+    return partials > 6.0 ? 5.0 * (std::ceil(std::log2(partials)) + 3.0) : 0.0;
+}
+static double plan_cost_us(uint32_t c, double n, uint32_t count, const double *bitlen_hist /* per MSM, or null = uniform */) {
     const double W = std::ceil(256.0 / c), B = (double)(1u << (c - 1));
     double heavy = 0, n_eff = n;
     if (bitlen_hist) {
-        double adds = 0, load = 0;
-        for (uint32_t len = 1; len < 256; len++) {
-            const double h = (double)bitlen_hist[len] / count;   // scalars of this length, per MSM
-            if (h == 0) continue;
-            adds += h * std::ceil((double)len / c);
-            load = std::max(load, h / std::exp2((double)((len - 1) % c)));
-            if (len % c == 0) load = std::max(load, h);
-        }
+        double adds, load, u_adds, u_load;
+        plan_len_stats(c, bitlen_hist, &adds, &load);        // scalars of each length, per MSM
         n_eff = adds / W;
-        const double seg = std::max(16.0, adds * count / (256.0 * 4 * 3 * 64));
-        const double partials = load / seg;
-        if (partials > 6.0) heavy = 5.0 * (std::ceil(std::log2(partials)) + 3.0);
+        // the measured table already holds what the top window of UNIFORM field elements costs: only the
+        // excess over a uniform vector with as many additions counts
+        plan_len_stats(c, plan_uniform_fractions(), &u_adds, &u_load);
+        heavy = std::max(0.0, plan_heavy_us(adds, load, count) - plan_heavy_us(u_adds * n_eff, u_load * n_eff, count));
     }
     return plan_table_us(c, n_eff * count) + heavy + W * (count - 1) * B / 5800.0;
 }
@@ -174,9 +197,12 @@ static MsmPlan make_plan(size_t n, int32_t forced_c, uint32_t count = 1, uint64_
     MsmPlan p;
     uint32_t best_c = 13;
     double best = 1e300;
-    for (uint32_t c = 4; c <= 16; c++) {
-        const double cost = plan_cost_us(c, (double)n, count, bitlen_hist);
-        if (cost < best * 0.975) { best = cost; best_c = c; }   // a wider window has to win clearly: its unmodelled costs (heavy buckets of skewed data) only grow
+    double per_msm[256];
+    if (bitlen_hist)
+        for (int len = 0; len < 256; len++) per_msm[len] = (double)bitlen_hist[len] / count;
+    for (uint32_t c = 4; c <= 16 && !forced_c; c++) {
+        const double cost = plan_cost_us(c, (double)n, count, bitlen_hist ? per_msm : nullptr);
+        if (cost < best * 0.99) { best = cost; best_c = c; }    // ties go to the narrower window (fewer buckets: less that skewed data can upset)
     }
     p.c = forced_c ? (uint32_t)forced_c : best_c;
     p.W = (256 + p.c - 1) / p.c;
@@ -271,6 +297,7 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
     if (n >= (1ull << 31) || (uint64_t)n * p.W >= (1ull << 32)) { set_error("n too large for 32-bit entry offsets"); return MIRA_E_UNSUPPORTED; }
     if (p.W > MIRA_MAX_WINDOWS) { set_error("window configuration exceeds MIRA_MAX_WINDOWS"); return MIRA_E_UNSUPPORTED; }
     *c_out = p.c; *W_out = p.W;
+    g.last_c = (int32_t)p.c; g.last_w = (int32_t)p.W;
     memset(out_partial, 0, MIRA_PARTIAL_U64 * 8);
     if (n == 0) return MIRA_OK;
     if (!d_scalars) { set_error("null scalars"); return MIRA_E_BAD_ARG; }
@@ -279,12 +306,14 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
         if ((uint64_t)n * 16 >= (1ull << 32)) { set_error("n too large for 32-bit entry offsets"); return MIRA_E_UNSUPPORTED; }
         MsmPlan ps = make_plan_shared(n, bs.n);
         *c_out = 0; *W_out = SHARED_SUMS;                   // partial sums, combined by a plain sum
+        g.last_c = 0; g.last_w = (int32_t)SHARED_SUMS;
         return bs.curve == MIRA_CURVE_BN256 ? msm_launch_bn256(bs, first, d_scalars, h_scalars, n, ps, out_partial)
                                              : msm_launch_grumpkin(bs, first, d_scalars, h_scalars, n, ps, out_partial);
     }
     if (table_mode) {
         if (h_scalars) RT_CHECK(rt_h2d(const_cast<void *>(d_scalars), h_scalars, n * 32, g.stream));
         *c_out = 0; *W_out = 64;                            // 64 partial sums, combined by a plain sum
+        g.last_c = 0; g.last_w = 64;
         return bs.curve == MIRA_CURVE_BN256 ? msm_launch_table_bn256(bs, first, d_scalars, n, out_partial)
                                              : msm_launch_table_grumpkin(bs, first, d_scalars, n, out_partial);
     }
@@ -351,6 +380,7 @@ static int msm_batch_device_locked(uint64_t handle, const void *d_scalars, size_
     for (size_t done = 0; done < count; done += per) {
         const size_t cnt = std::min(per, count - done);
         MsmPlan p = make_plan(n, g.forced_c, (uint32_t)cnt, stride);
+        g.last_c = (int32_t)p.c; g.last_w = (int32_t)p.W;
         win.assign((size_t)p.Wt * 16, 0);
         const unsigned char *sc = reinterpret_cast<const unsigned char *>(d_scalars) + done * stride * 32;
         rc = bs.curve == MIRA_CURVE_BN256 ? msm_launch_bn256(bs, 0, sc, nullptr, n, p, win.data()) : msm_launch_grumpkin(bs, 0, sc, nullptr, n, p, win.data());
@@ -632,6 +662,12 @@ int mira_set_tuning(int knob, int64_t value) {
     std::lock_guard<std::mutex> lk(g_lock);
     if (knob < 0 || knob > MIRA_TUNE_HOST_CHUNK_MIN_N) { set_error("unknown tuning knob"); return MIRA_E_BAD_ARG; }
     g.tune[knob] = value;
+    return MIRA_OK;
+}
+int mira_msm_last_plan(int32_t *window_bits, int32_t *num_windows) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    if (!window_bits || !num_windows) { set_error("null output"); return MIRA_E_BAD_ARG; }
+    *window_bits = g.last_c; *num_windows = g.last_w;
     return MIRA_OK;
 }
 int mira_msm_set_window_bits(int32_t c) {

@@ -100,7 +100,10 @@ struct Ctx {
     DevBuf graph_consts, graph_ws;
     DevBuf hist_dev;
     DevBuf tree_w, tree_a, tree_b;   // weighted tree reduction: level weights, ping-pong partial results
-    uint32_t *hist_host = nullptr;   // 1 KiB of pinned host memory: the histogram comes back without a host-side wait   // cross-term evaluator: staged program, intermediates[slot][lane]
+    uint32_t hist_host[256] = {};    // the statistics of the last commit that collected them
+    int32_t last_c = 0, last_w = 0;  // mira_msm_last_plan
+    uint32_t hist_sel = 0;           // which of the two device histograms the next commit adds into
+    unsigned char *out_host = nullptr; size_t out_host_cap = 0;   // pinned staging of window sums + statistics   // cross-term evaluator: staged program, intermediates[slot][lane]
     std::string ntt_tables_key;
     uint64_t next_handle = 1;
 };

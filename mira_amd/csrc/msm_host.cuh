@@ -64,7 +64,7 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, cons
     if ((rc = g.heavy.ensure(64 + ((size_t)p.T / 2 + 8) * 32))) return rc;            // counters, runs, sub-job descriptors
     if ((rc = g.heavy_out.ensure(((size_t)p.T / 2 + 8) * XYZZ29_BYTES))) return rc;
     if ((rc = g.chunks.ensure((size_t)(p.shared ? p.count : p.Wt) * p.nchunks * XYZZ29_BYTES))) return rc;
-    if ((rc = g.window_sums.ensure((size_t)std::max(p.Wt, p.count * p.sums) * 128))) return rc;
+    if ((rc = g.window_sums.ensure((size_t)std::max(p.Wt, p.count * p.sums) * 128 + 1024))) return rc;   // + the planning statistics
 #ifndef MIRA_CPU_EMU
     if (h_scalars) {
         if (!g.copy_stream) RT_CHECK(hipStreamCreateWithFlags(&g.copy_stream, hipStreamNonBlocking));
@@ -90,10 +90,17 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, cons
     // No clearing passes: k_digits zeroes the bucket counters, k_scan_c the heavy-run counters and (first
     // chunk) the identity marker of every bucket without entries, every segment of k_accumulate writes its tail key.
     tm_begin();
+    // planning statistics: two device histograms, this commit's (zero since the previous one cleared it) and the next one's
+    uint32_t *hist = nullptr, *hist_clear = nullptr;
     if (p.stats) {
-        if ((rc = g.hist_dev.ensure(1024))) return rc;
-        if (!g.hist_host) RT_CHECK(rt_host_alloc(reinterpret_cast<void **>(&g.hist_host), 1024));
-        RT_CHECK(rt_memset(g.hist_dev.p, 0, 1024, st));
+        if (!g.hist_dev.p) {
+            if ((rc = g.hist_dev.ensure(2048))) return rc;
+            RT_CHECK(rt_memset(g.hist_dev.p, 0, 2048, st));
+            g.hist_sel = 0;
+        }
+        hist = reinterpret_cast<uint32_t *>(g.hist_dev.p) + 256 * g.hist_sel;
+        hist_clear = reinterpret_cast<uint32_t *>(g.hist_dev.p) + 256 * (g.hist_sel ^ 1u);
+        g.hist_sel ^= 1u;
     }
     for (size_t k = 0, lo = 0; k < ends.size(); lo = ends[k++]) {
         const size_t nc = ends[k] - lo, entries = nc * p.Wt;
@@ -108,14 +115,11 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, cons
             RT_CHECK(rt_h2d(const_cast<unsigned char *>(sc), reinterpret_cast<const unsigned char *>(h_scalars) + lo * 32, nc * 32, cs));
             if (cs != st) RT_CHECK(rt_stream_wait(st, cs, g.copy_events[k]));
         }
-        if (p.stats)      // 20 us ahead of the MSM kernels; its 1 KiB lands in pinned host memory by the time the call ends
-            LAUNCH_BARRIER_FLEX(k_bitlen_hist<FS>, dim3(std::min<uint32_t>(1024, ceil_div(nc, 256)), p.count), 256, 0, st, sc, (uint32_t)nc, (uint64_t)p.stride,
-                                reinterpret_cast<uint32_t *>(g.hist_dev.p));
         // histogram / scatter tiling of this chunk: about two workgroups per CU, at least 1024 points per tile
         const uint32_t tile = (std::max<uint32_t>(1024, ceil_div(nc, std::max<uint32_t>(1, 512 / p.Wt))) + 1023) / 1024 * 1024, ntiles = ceil_div(nc, tile);
         const bool staged = nc * p.count >= staged_min_n && p.c >= 9;   // a batch is count MSMs' worth of entries
         LAUNCH(k_digits<FS>, dim3(ceil_div(nc, 256), p.count), 256, 0, st, sc, (uint32_t)nc, (uint64_t)p.stride, p.c, p.W,
-               reinterpret_cast<int16_t *>(g.digits.p), reinterpret_cast<uint32_t *>(g.counts.p), p.NB + 1);
+               reinterpret_cast<int16_t *>(g.digits.p), reinterpret_cast<uint32_t *>(g.counts.p), p.NB + 1, hist, hist_clear);
         tm_mark("digits");
         LAUNCH_BARRIER_FLEX(k_hist, dim3(ntiles, p.Wt), 1024, (size_t)p.B * 4, st, reinterpret_cast<const int16_t *>(g.digits.p), (uint32_t)nc,
                        p.B, tile, reinterpret_cast<uint32_t *>(g.counts.p), wgroup);
@@ -176,7 +180,7 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, cons
                p.B, p.m, Wb, reinterpret_cast<unsigned char *>(g.chunks.p));
         tm_mark("reduce_chunks");
         LAUNCH_BARRIER((k_window_sum<F, true>), nsum, WSUM_BLOCK, (size_t)(WSUM_BLOCK / 4) * XYZZ29_BYTES, st, reinterpret_cast<const unsigned char *>(g.chunks.p), per_sum,
-                       reinterpret_cast<unsigned char *>(g.window_sums.p));
+                       reinterpret_cast<unsigned char *>(g.window_sums.p), (const uint32_t *)hist);
     } else {
         // 256-lane workgroups: with 64-lane ones the dispatcher was seen to pack the 1024 waves of a 2^22
         // MSM onto part of the CUs (0.43 ms instead of 0.27)
@@ -184,13 +188,26 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, cons
                p.B, p.m, Wb, reinterpret_cast<unsigned char *>(g.chunks.p));
         tm_mark("reduce_chunks");
         LAUNCH_BARRIER((k_window_sum<F, false>), nsum, WSUM_BLOCK, (size_t)WSUM_BLOCK * XYZZ29_BYTES, st, reinterpret_cast<const unsigned char *>(g.chunks.p), per_sum,
-                       reinterpret_cast<unsigned char *>(g.window_sums.p));
+                       reinterpret_cast<unsigned char *>(g.window_sums.p), (const uint32_t *)hist);
     }
     tm_mark("window_sum");
     RT_CHECK(rt_last());
-    if (p.stats) RT_CHECK(rt_d2h(g.hist_host, g.hist_dev.p, 1024, st));
-    RT_CHECK(rt_d2h(host_windows, g.window_sums.p, (size_t)nsum * 128, st));
-    RT_CHECK(rt_sync(st));
+    if (p.stats) {                                           // sums and statistics in one copy, through pinned memory
+        const size_t bytes = (size_t)nsum * 128 + 1024;
+        if (g.out_host_cap < bytes) {
+            if (g.out_host) (void)rt_host_free(g.out_host);
+            g.out_host = nullptr; g.out_host_cap = 0;
+            RT_CHECK(rt_host_alloc(reinterpret_cast<void **>(&g.out_host), bytes + 4096));
+            g.out_host_cap = bytes + 4096;
+        }
+        RT_CHECK(rt_d2h(g.out_host, g.window_sums.p, bytes, st));
+        RT_CHECK(rt_sync(st));
+        memcpy(host_windows, g.out_host, (size_t)nsum * 128);
+        memcpy(g.hist_host, g.out_host + (size_t)nsum * 128, 1024);
+    } else {
+        RT_CHECK(rt_d2h(host_windows, g.window_sums.p, (size_t)nsum * 128, st));
+        RT_CHECK(rt_sync(st));
+    }
     tm_end();
     return MIRA_OK;
 }
@@ -355,7 +372,7 @@ static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars
            TABLE_B, m, 1u, reinterpret_cast<unsigned char *>(g.chunks.p));
     tm_mark("reduce_chunks");
     LAUNCH_BARRIER((k_window_sum<F, false>), TABLE_SUMS, WSUM_BLOCK, (size_t)WSUM_BLOCK * XYZZ29_BYTES, st,
-                   reinterpret_cast<const unsigned char *>(g.chunks.p), nchunks / TABLE_SUMS, reinterpret_cast<unsigned char *>(g.window_sums.p));
+                   reinterpret_cast<const unsigned char *>(g.chunks.p), nchunks / TABLE_SUMS, reinterpret_cast<unsigned char *>(g.window_sums.p), (const uint32_t *)nullptr);
     tm_mark("window_sum");
     RT_CHECK(rt_last());
     RT_CHECK(rt_d2h(host_sums, g.window_sums.p, (size_t)TABLE_SUMS * 128, st));

@@ -28,52 +28,59 @@ static constexpr int HEAVY_SPAN = 6;        // chains longer than this go to k_f
 static constexpr int WSUM_BLOCK = 512;       // k_window_sum: 128 quads
 
 // ------------------------------------------------------------------------------------------
-// Planning pre-pass: histogram of the bit lengths of the canonical scalars (hist[0] = zeros,
-// hist[b] = scalars with top set bit b-1).  Witness vectors are mostly zeros and small values
-// (SURVEY.md 7 "bucket contention"; src/util.rs:189-193 zero-pads every column), so the number
-// of non-zero digits -- and with it the best window width -- depends on the data.
-template <class FS>
-KERNEL void k_bitlen_hist(const unsigned char *__restrict__ scalars, uint32_t n, uint64_t stride, uint32_t *__restrict__ hist) {
-    __shared__ uint32_t bins[256];
-    for (uint32_t b = threadIdx.x; b < 256; b += blockDim.x) bins[b] = 0;
-    __syncthreads();
-    scalars += (size_t)blockIdx.y * stride * 32;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        Fe<FS> s = fe_from_mont(fe_load<FS>(scalars + (size_t)i * 32));
-        uint32_t len = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++)
-            if (s.l[k]) len = 32u * k + (32u - (uint32_t)__builtin_clz(s.l[k]));
-        atomicAdd(&bins[len > 255 ? 255 : len], 1u);
-    }
-    __syncthreads();
-    for (uint32_t b = threadIdx.x; b < 256; b += blockDim.x)
-        if (bins[b]) atomicAdd(&hist[b], bins[b]);
-}
-
-// ------------------------------------------------------------------------------------------
 // (also clears the ncounts bucket counters the histogram that follows adds into: one launch less)
+// Planning statistics (hist != null): the histogram of the bit lengths of the canonical scalars
+// (hist[0] = zeros, hist[b] = scalars with top set bit b - 1), summed over the batch.  Witness vectors
+// are mostly zeros and small values (SURVEY.md 7 "bucket contention"; src/util.rs:189-193 zero-pads
+// every column), so the number of non-zero digits -- and with it the best window width -- depends on
+// the data.  Counted here, where every scalar is already canonical in registers (a pre-pass of its
+// own read the scalars a second time and cost a launch, a memset and a copy: 30-50 us per commit).
+// hist_clear = the OTHER of the two histogram buffers, zeroed for the next commit.
 template <class FS>
 KERNEL void k_digits(const unsigned char *__restrict__ scalars, uint32_t n, uint64_t stride, uint32_t c, uint32_t W,
-                     int16_t *__restrict__ digits, uint32_t *__restrict__ counts, uint32_t ncounts) {
+                     int16_t *__restrict__ digits, uint32_t *__restrict__ counts, uint32_t ncounts,
+                     uint32_t *__restrict__ hist, uint32_t *__restrict__ hist_clear) {
+    __shared__ uint32_t bins[256];
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     for (uint32_t k = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; k < ncounts; k += gridDim.x * gridDim.y * blockDim.x) counts[k] = 0;
-    if (i >= n) return;
-    const uint32_t b = blockIdx.y;                       // MSM of the batch: its windows are b*W .. b*W + W-1
-    scalars += (size_t)b * stride * 32;
-    digits += (size_t)b * W * n;
-    Fe<FS> s = fe_from_mont(fe_load<FS>(scalars + (size_t)i * 32));
-    const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
-    uint32_t carry = 0;
-    for (uint32_t w = 0; w < W; w++) {
-        uint32_t raw = (s.l[0] & mask) + carry;
+    // a SAMPLE: every eighth block counts, eight-fold (planning wants proportions; every block flushing
+    // its two or three hot bins to the same global counters serialises in L2 -- 50 us at 2^17 scalars)
+    const bool sampled = hist && (gridDim.x < 8 || (blockIdx.x & 7u) == 0);
+    const uint32_t weight = gridDim.x < 8 ? 1u : 8u;
+    if (hist) {                                          // uniform across the grid
+        for (uint32_t b = threadIdx.x; b < 256; b += blockDim.x) bins[b] = 0;
+        if (blockIdx.x == 0 && blockIdx.y == 0)
+            for (uint32_t b = threadIdx.x; b < 256; b += blockDim.x) hist_clear[b] = 0;
+        __syncthreads();
+    }
+    if (i < n) {
+        const uint32_t b = blockIdx.y;                   // MSM of the batch: its windows are b*W .. b*W + W-1
+        Fe<FS> s = fe_from_mont(fe_load<FS>(scalars + ((size_t)b * stride + i) * 32));
+        if (sampled) {
+            uint32_t len = 0;
 #pragma unroll
-        for (int k = 0; k < 7; k++) s.l[k] = (s.l[k] >> c) | (s.l[k + 1] << (32 - c));   // c in [1,16]
-        s.l[7] >>= c;
-        int32_t d;
-        if (raw >= half) { d = (int32_t)raw - (int32_t)(1u << c); carry = 1; }
-        else { d = (int32_t)raw; carry = 0; }
-        digits[(size_t)w * n + i] = (int16_t)d;
+            for (int k = 0; k < 8; k++)
+                if (s.l[k]) len = 32u * k + (32u - (uint32_t)__builtin_clz(s.l[k]));
+            atomicAdd(&bins[len > 255 ? 255 : len], 1u);
+        }
+        int16_t *dg = digits + (size_t)b * W * n;
+        const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
+        uint32_t carry = 0;
+        for (uint32_t w = 0; w < W; w++) {
+            uint32_t raw = (s.l[0] & mask) + carry;
+#pragma unroll
+            for (int k = 0; k < 7; k++) s.l[k] = (s.l[k] >> c) | (s.l[k + 1] << (32 - c));   // c in [1,16]
+            s.l[7] >>= c;
+            int32_t d;
+            if (raw >= half) { d = (int32_t)raw - (int32_t)(1u << c); carry = 1; }
+            else { d = (int32_t)raw; carry = 0; }
+            dg[(size_t)w * n + i] = (int16_t)d;
+        }
+    }
+    if (sampled) {                                       // uniform across the block
+        __syncthreads();
+        for (uint32_t b = threadIdx.x; b < 256; b += blockDim.x)
+            if (bins[b]) atomicAdd(&hist[b], bins[b] * weight);
     }
 }
 
@@ -514,9 +521,11 @@ KERNEL void __launch_bounds__(256) k_reduce_chunks(const unsigned char *__restri
 // reference's canonical R = 2^256 form (128 B) for the host epilogue.  blockDim.x == WSUM_BLOCK:
 // 128 quads, or 512 single lanes (72 KiB of LDS).
 template <class F, bool QUAD>
-KERNEL void __launch_bounds__(512) k_window_sum(const unsigned char *__restrict__ R, uint32_t nchunks, unsigned char *__restrict__ window_sums) {
+KERNEL void __launch_bounds__(512) k_window_sum(const unsigned char *__restrict__ R, uint32_t nchunks, unsigned char *__restrict__ window_sums,
+                                                const uint32_t *__restrict__ hist) {   // planning statistics (or null): copied behind the sums, one copy to the host for both
     DYN_SHARED(unsigned char, red);
     const uint32_t w = blockIdx.x;
+    if (hist && w == 0 && threadIdx.x < 256) reinterpret_cast<uint32_t *>(window_sums + (size_t)gridDim.x * 128)[threadIdx.x] = hist[threadIdx.x];
     const uint32_t qi = QUAD ? threadIdx.x >> 2 : threadIdx.x, nq = QUAD ? blockDim.x >> 2 : blockDim.x;
     Xyzz29<F> acc = xyzz29_identity<F>();
     for (uint32_t q = qi; q < nchunks; q += nq)

@@ -17,6 +17,11 @@ for n, kind in cases:
         for _ in range(9):
             t0 = time.perf_counter(); key.commit_device(d, n); ts.append((time.perf_counter() - t0) * 1e3)
         row.append(f"{sorted(ts)[4]:.3f}")
+        if c == 0:
+            import ctypes
+            pc, pw = ctypes.c_int32(), ctypes.c_int32()
+            lib.check(lib.c.mira_msm_last_plan(ctypes.byref(pc), ctypes.byref(pw)))
+            row[-1] += f"(c={pc.value})"
     lib.check(lib.c.mira_msm_set_window_bits(0))
     print(n, kind, " ".join(row), flush=True)
     key.close(); lib.free(d)

@@ -120,13 +120,16 @@ int mira_msm_last_plan(int32_t *window_bits, int32_t *num_windows);
  * the longest NTT line (log2) -- shorter lines make the two- and three-pass schedules reachable at
  * small sizes -- and whether lines of up to 256 points take the wave-level kernel (1: wherever it
  * can; 0: never; default: by size); the smallest commit of HOST scalars that is cut into point chunks so
- * that the copy of one chunk overlaps the kernels of the previous one.  value < 0 restores the default. */
+ * that the copy of one chunk overlaps the kernels of the previous one; the largest post-twiddle exponent
+ * range (log2) an NTT serves from one table -- beyond it pass 1 reads a table of n entries, or, above
+ * 2^24 points, multiplies two table entries.  value < 0 restores the default. */
 #define MIRA_TUNE_STAGED_MIN_N 0
 #define MIRA_TUNE_TABLE_MIN_N 1
 #define MIRA_TUNE_PLAN_HIST_MIN_N 2
 #define MIRA_TUNE_NTT_MAX_LOG_LINE 3
 #define MIRA_TUNE_NTT_WAVE 4
 #define MIRA_TUNE_HOST_CHUNK_MIN_N 5
+#define MIRA_TUNE_NTT_SINGLE_TW_LOG 6
 int mira_set_tuning(int knob, int64_t value);
 
 /* Read a range of the registered key back in the reference layout (cache file writing,

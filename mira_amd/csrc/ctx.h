@@ -89,13 +89,18 @@ struct Ctx {
     hipStream_t copy_stream = nullptr;   // host scalars travel here, chunk by chunk, beside the kernels of earlier chunks
     std::vector<hipEvent_t> copy_events;
     int32_t forced_c = 0;
-    int64_t tune[6] = {-1, -1, -1, -1, -1, -1};   // mira_set_tuning overrides, < 0 = default
+    int64_t tune[7] = {-1, -1, -1, -1, -1, -1, -1};   // mira_set_tuning overrides, < 0 = default
     Timing tm;
     // MSM workspace (grow-only, shared by all handles: calls are serialised by the ABI lock)
     DevBuf digits, counts, offsets, cursor, block_sums, sorted_idx, bucket_sums, part, coarse_offsets, fine_counts, fine_cursor;
     DevBuf head_part, tail_part, tail_key, heavy, heavy_out, chunks, window_sums, scalars_stage, consts;
     // NTT workspace
-    DevBuf ntt_tmp, ntt_stage, ntt_tables, ntt_consts;
+    DevBuf ntt_tmp, ntt_stage, ntt_consts;
+    static constexpr int NTT_SETS = 4;           // cached twiddle-table sets (ntt.hip)
+    DevBuf ntt_set[NTT_SETS];
+    std::string ntt_set_key[NTT_SETS];
+    uint64_t ntt_set_stamp[NTT_SETS] = {0, 0, 0, 0}, ntt_stamp = 0;
+    int ntt_set_cur = 0;
     DevBuf fold_consts;
     DevBuf graph_consts, graph_ws;
     DevBuf hist_dev;
@@ -104,7 +109,6 @@ struct Ctx {
     int32_t last_c = 0, last_w = 0;  // mira_msm_last_plan
     uint32_t hist_sel = 0;           // which of the two device histograms the next commit adds into
     unsigned char *out_host = nullptr; size_t out_host_cap = 0;   // pinned staging of window sums + statistics   // cross-term evaluator: staged program, intermediates[slot][lane]
-    std::string ntt_tables_key;
     uint64_t next_handle = 1;
 };
 extern Ctx g;

@@ -54,6 +54,20 @@ KERNEL void k_pow_table(const unsigned char *__restrict__ base, uint64_t stride,
     tw_store(table + (size_t)j * TW_BYTES, f29_unpack_canonical<F>(f29_canonical(f29_from_r256<F>(v))));
 }
 
+// full[line << log_len | k] = hi[e >> h] * lo[e & (2^h - 1)], e = line * k: the first post-twiddle of every
+// element of a transform, so that the pass multiplies by ONE table entry (the product costs a
+// multiplication per element in every transform; here once per table)
+template <class F>
+KERNEL void k_tw_full(const unsigned char *__restrict__ t_lo, const unsigned char *__restrict__ t_hi, uint32_t h, uint32_t log_len, uint64_t count,
+                      unsigned char *__restrict__ full) {
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count) return;
+    const uint64_t e = (idx >> log_len) * (idx & (((uint64_t)1 << log_len) - 1));
+    const Fe29<F> v = f29_mul(tw_load<F>(t_hi + (size_t)(e >> h) * TW_BYTES), tw_load<F>(t_lo + (size_t)(e & (((uint64_t)1 << h) - 1)) * TW_BYTES));
+    // the product of two multiplier-form entries (x 2^261)(y 2^261) / 2^261 is in multiplier form again
+    tw_store(full + (size_t)idx * TW_BYTES, f29_unpack_canonical<F>(f29_canonical(v)));
+}
+
 struct NttPass {
     uint32_t log_len;          // line length N = 1 << log_len (<= 4096)
     uint32_t nlines;           // number of lines
@@ -63,7 +77,7 @@ struct NttPass {
     uint64_t in_hi, in_lo, in_elem_stride;
     uint64_t out_hi, out_lo, out_elem_stride;
     uint32_t tw_shift;         // post-twiddle w^e = T_hi[e >> tw_shift] * T_lo[e & mask]; 0xFFFFFFFF = none
-    uint32_t tw_single;        // 1: the exponent range fits T_lo alone (w^e = T_lo[e], no product)
+    uint32_t tw_single;        // 1: the exponent range fits T_lo alone (w^e = T_lo[e], no product); 2: T_lo holds the twiddle of EVERY element, T_lo[line << log_len | k]
     uint32_t coop;             // k_ntt_wave: bit 0 / bit 1 = the lines of a workgroup are adjacent in the input / output
     uint32_t reserved;
 };
@@ -174,7 +188,7 @@ KERNEL void __launch_bounds__(1024) k_ntt_lines(const unsigned char *__restrict_
         for (uint32_t k = threadIdx.x; k < N; k += blockDim.x) {
             Fe29<F> v = L.load(k, bound);
             if (ps.tw_shift != 0xFFFFFFFFu) {
-                uint64_t e = (uint64_t)(line >> ps.tw_line_shift) * k;
+                uint64_t e = ps.tw_single == 2 ? (((uint64_t)line << ps.log_len) | k) : (uint64_t)(line >> ps.tw_line_shift) * k;
                 Fe29<F> tw = ps.tw_single ? tw_load<F>(t_lo + (size_t)e * TW_BYTES)
                                           : f29_mul(tw_load<F>(t_hi + (size_t)(e >> ps.tw_shift) * TW_BYTES), tw_load<F>(t_lo + (size_t)(e & lo_mask) * TW_BYTES));
                 v = f29_mul(v, tw);
@@ -279,7 +293,7 @@ template <class F> struct NttwIo {
     // times the final scale and canonical
     DEV Fe<typename F::Sat> finish(uint32_t line, uint32_t k, const Fe29<F> &x) const {
         if (ps.tw_shift != 0xFFFFFFFFu) {
-            const uint64_t e = (uint64_t)(line >> ps.tw_line_shift) * k;
+            const uint64_t e = ps.tw_single == 2 ? (((uint64_t)line << m) | k) : (uint64_t)(line >> ps.tw_line_shift) * k;
             const Fe29<F> tw = ps.tw_single ? tw_load<F>(t_lo + (size_t)e * TW_BYTES)
                                             : f29_mul(tw_load<F>(t_hi + (size_t)(e >> ps.tw_shift) * TW_BYTES), tw_load<F>(t_lo + (size_t)(e & lo_mask) * TW_BYTES));
             return f29_pack(f29_mul(x, tw));

@@ -137,6 +137,27 @@ def test_emu_ntt_pass_schedules(emu_lib, max_line, ks, wave):
         emu_lib.tune(_lib.TUNE_NTT_WAVE, -1)
 
 
+@pytest.mark.parametrize("wave", [1, 0])
+def test_emu_ntt_full_twiddle_table(emu_lib, wave):
+    """The first post-twiddle from a table of n entries (on the GPU: 2^17 .. 2^24 points; here
+    MIRA_TUNE_NTT_SINGLE_TW_LOG = 3 makes every split transform take it), beside a one-table and a
+    two-table second boundary; forward and inverse transforms of three sizes alternate through the
+    four cached table sets (one is evicted and rebuilt)."""
+    emu_lib.tune(_lib.TUNE_NTT_MAX_LOG_LINE, 3)
+    emu_lib.tune(_lib.TUNE_NTT_WAVE, wave)
+    emu_lib.tune(_lib.TUNE_NTT_SINGLE_TW_LOG, 3)
+    try:
+        for rep in range(2):
+            for k in (5, 8, 9):                              # two passes; three passes with a one-table / two-table second boundary
+                a = C.synth_scalars(0, 1 << k, seed=2500 + k + rep)
+                assert (F.fft(a, k, lib=emu_lib) == C.fft(a, k)).all(), k
+                assert (F.ifft(a, k, lib=emu_lib) == C.ifft(a, k)).all(), k
+    finally:
+        emu_lib.tune(_lib.TUNE_NTT_MAX_LOG_LINE, -1)
+        emu_lib.tune(_lib.TUNE_NTT_WAVE, -1)
+        emu_lib.tune(_lib.TUNE_NTT_SINGLE_TW_LOG, -1)
+
+
 @pytest.mark.parametrize("k", [6, 7, 8])
 def test_emu_ntt_wave_full_lines(emu_lib, k):
     """k_ntt_wave with lines of 64, 128 and 256 points (one to three register/LDS transposes), as a

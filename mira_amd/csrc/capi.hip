@@ -58,9 +58,9 @@ void tm_begin() {
     if (g.tm.enabled) {
         if (g.tm.ev.empty()) {
             g.tm.ev.resize(128);
-            for (auto &e : g.tm.ev) hipEventCreate(&e);
+            for (auto &e : g.tm.ev) (void)hipEventCreate(&e);
         }
-        hipEventRecord(g.tm.ev[0], g.stream);
+        (void)hipEventRecord(g.tm.ev[0], g.stream);
     }
 #endif
 }
@@ -68,7 +68,7 @@ void tm_mark(const char *name) {
     if (!g.tm.enabled) return;
     g.tm.names.push_back(name);
 #ifndef MIRA_CPU_EMU
-    if (g.tm.names.size() < g.tm.ev.size()) hipEventRecord(g.tm.ev[g.tm.names.size()], g.stream);
+    if (g.tm.names.size() < g.tm.ev.size()) (void)hipEventRecord(g.tm.ev[g.tm.names.size()], g.stream);
 #endif
 }
 void tm_end() {   // after stream sync
@@ -76,7 +76,7 @@ void tm_end() {   // after stream sync
     g.tm.ms.assign(g.tm.names.size(), 0.f);
 #ifndef MIRA_CPU_EMU
     for (size_t i = 0; i < g.tm.names.size() && i + 1 < g.tm.ev.size(); i++)
-        hipEventElapsedTime(&g.tm.ms[i], g.tm.ev[i], g.tm.ev[i + 1]);
+        (void)hipEventElapsedTime(&g.tm.ms[i], g.tm.ev[i], g.tm.ev[i + 1]);
 #endif
 }
 
@@ -503,7 +503,7 @@ int mira_set_stream(void *hip_stream) {
     if (rc) return rc;
 #ifndef MIRA_CPU_EMU
     if (hip_stream) {
-        if (g.own_stream && g.stream) { hipStreamSynchronize(g.stream); hipStreamDestroy(g.stream); }
+        if (g.own_stream && g.stream) { (void)hipStreamSynchronize(g.stream); (void)hipStreamDestroy(g.stream); }
         g.stream = reinterpret_cast<hipStream_t>(hip_stream); g.own_stream = false;
     } else if (!g.own_stream) {
         RT_CHECK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking)); g.own_stream = true;
@@ -549,8 +549,8 @@ int mira_msm_unregister(uint64_t handle) {
     std::lock_guard<std::mutex> lk(g_lock);
     auto it = g_bases.find(handle);
     if (it == g_bases.end()) { set_error("unknown bases handle"); return MIRA_E_BAD_ARG; }
-    if (it->second.owned && it->second.d) rt_free(it->second.d);
-    if (it->second.tables) rt_free(it->second.tables);
+    if (it->second.owned && it->second.d) (void)rt_free(it->second.d);
+    if (it->second.tables) (void)rt_free(it->second.tables);
     g_bases.erase(it);
     return MIRA_OK;
 }
@@ -839,7 +839,7 @@ int mira_dev_alloc(size_t bytes, void **d_out) {
     if (rt_malloc(d_out, std::max<size_t>(bytes, 64)) != hipSuccess || !*d_out) { set_error("device allocation failed"); return MIRA_E_ALLOC; }
     return MIRA_OK;
 }
-int mira_dev_free(void *d) { std::lock_guard<std::mutex> lk(g_lock); if (d) rt_free(d); return MIRA_OK; }
+int mira_dev_free(void *d) { std::lock_guard<std::mutex> lk(g_lock); if (d) (void)rt_free(d); return MIRA_OK; }
 int mira_dev_upload(void *d_dst, const void *h_src, size_t bytes) {
     std::lock_guard<std::mutex> lk(g_lock);
     int rc = ensure_ctx();

@@ -268,6 +268,18 @@ def test_emu_data_dependent_planning(emu_lib, tune):
     assert not key.commit(np.zeros((n, 4), dtype=np.uint64)).any()
     assert not key.commit(np.zeros((n, 4), dtype=np.uint64)).any()   # planned from an all-zero histogram
     assert (key.commit(sc) == want).all()
+    # mira_msm_last_plan: the planner's own choice, then a forced width
+    import ctypes
+    c, w = ctypes.c_int32(), ctypes.c_int32()
+    emu_lib.check(emu_lib.c.mira_msm_last_plan(ctypes.byref(c), ctypes.byref(w)))
+    assert 4 <= c.value <= 16 and w.value == -(-256 // c.value)
+    emu_lib.check(emu_lib.c.mira_msm_set_window_bits(11))
+    try:
+        assert (key.commit(sc) == want).all()
+        emu_lib.check(emu_lib.c.mira_msm_last_plan(ctypes.byref(c), ctypes.byref(w)))
+        assert (c.value, w.value) == (11, 24)
+    finally:
+        emu_lib.check(emu_lib.c.mira_msm_set_window_bits(0))
 
 
 def test_emu_staged_sort(emu_lib, tune):

@@ -136,13 +136,13 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, cons
         // single-level scatter otherwise (small inputs: the tile structure buys nothing there)
         if (staged) {
             if (p.shared)
-                LAUNCH_BARRIER((k_stage1<int16_t, true>), dim3(ceil_div(nc, STAGE_TILE), p.Wt), 1024, (size_t)STAGE_TILE * 8, st, reinterpret_cast<const int16_t *>(g.digits.p),
+                LAUNCH_BARRIER((k_stage1<int16_t, true, STAGE_TILE_PW>), dim3(ceil_div(nc, STAGE_TILE_PW), p.Wt), 1024, (size_t)STAGE_TILE_PW * 8, st, reinterpret_cast<const int16_t *>(g.digits.p),
                                     (uint32_t)nc, p.B, fine_bits, CB, idx_stride, idx_first, wgroup, reinterpret_cast<uint32_t *>(g.coarse_offsets.p), reinterpret_cast<U2 *>(g.part.p));
             else
-                LAUNCH_BARRIER((k_stage1<int16_t, false>), dim3(ceil_div(nc, STAGE_TILE), p.Wt), 1024, (size_t)STAGE_TILE * 8, st, reinterpret_cast<const int16_t *>(g.digits.p),
+                LAUNCH_BARRIER((k_stage1<int16_t, false, STAGE_TILE_PW>), dim3(ceil_div(nc, STAGE_TILE_PW), p.Wt), 1024, (size_t)STAGE_TILE_PW * 8, st, reinterpret_cast<const int16_t *>(g.digits.p),
                                     (uint32_t)nc, p.B, fine_bits, CB, 0u, 0u, 1u, reinterpret_cast<uint32_t *>(g.coarse_offsets.p), reinterpret_cast<U2 *>(g.part.p));
             tm_mark("sort_level1");
-            LAUNCH_BARRIER(k_stage2, ceil_div(entries, STAGE_TILE), 1024, (size_t)STAGE_TILE * 6, st, reinterpret_cast<const U2 *>(g.part.p),
+            LAUNCH_BARRIER((k_stage2<STAGE_TILE_PW, STAGE_MAX_KEYS2_PW>), ceil_div(entries, STAGE_TILE_PW), 1024, (size_t)STAGE_TILE_PW * 6, st, reinterpret_cast<const U2 *>(g.part.p),
                                 reinterpret_cast<const uint32_t *>(g.offsets.p) + p.NB, fine_bits, reinterpret_cast<uint32_t *>(g.cursor.p),
                                 reinterpret_cast<uint32_t *>(g.sorted_idx.p));
         } else
@@ -219,10 +219,11 @@ template <class F, class FS> static int curve_init() {
     // the LDS-staged histogram needs more than the 64 KiB default (128 KiB at c = 16)
     RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stage1<int16_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, STAGE_TILE * 8));   // + 10 KiB static
+    RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stage1<int16_t, false, STAGE_TILE_PW>), hipFuncAttributeMaxDynamicSharedMemorySize, STAGE_TILE_PW * 8));   // + 10 KiB static
     RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stage1<int32_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, STAGE_TILE * 8));
-    RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stage1<int16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, STAGE_TILE * 8));
-    RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stage2), hipFuncAttributeMaxDynamicSharedMemorySize, STAGE_TILE * 6));   // + 52 KiB static
+    RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stage1<int16_t, true, STAGE_TILE_PW>), hipFuncAttributeMaxDynamicSharedMemorySize, STAGE_TILE_PW * 8));
+    RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stage2<STAGE_TILE, STAGE_MAX_KEYS2>), hipFuncAttributeMaxDynamicSharedMemorySize, STAGE_TILE * 6));   // + 52 KiB static
+    RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stage2<STAGE_TILE_PW, STAGE_MAX_KEYS2_PW>), hipFuncAttributeMaxDynamicSharedMemorySize, STAGE_TILE_PW * 6));
 #endif
     return MIRA_OK;
 }
@@ -350,7 +351,7 @@ static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars
                    reinterpret_cast<const uint32_t *>(g.block_sums.p), reinterpret_cast<uint32_t *>(g.offsets.p), reinterpret_cast<uint32_t *>(g.fine_cursor.p),
                    no_u32, 0u, plan, lanes, Lmin, heavy_count, reinterpret_cast<unsigned char *>(g.bucket_sums.p));
     tm_mark("bucket_count_scan");
-    LAUNCH_BARRIER(k_stage2, ceil_div(entries, STAGE_TILE), 1024, (size_t)STAGE_TILE * 6, st, reinterpret_cast<const U2 *>(g.part.p), coarse_total,
+    LAUNCH_BARRIER((k_stage2<STAGE_TILE, STAGE_MAX_KEYS2>), ceil_div(entries, STAGE_TILE), 1024, (size_t)STAGE_TILE * 6, st, reinterpret_cast<const U2 *>(g.part.p), coarse_total,
                         TABLE_FINE_BITS, reinterpret_cast<uint32_t *>(g.fine_cursor.p), reinterpret_cast<uint32_t *>(g.sorted_idx.p));
     tm_mark("sort_level2");
     LAUNCH((k_accumulate<F, false>), ceil_div(T, 128), 128, 0, st, reinterpret_cast<const uint32_t *>(g.sorted_idx.p),

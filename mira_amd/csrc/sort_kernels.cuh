@@ -15,7 +15,11 @@
 #pragma once
 #include "field.cuh"
 
-static constexpr uint32_t STAGE_TILE = 16384;      // entries per workgroup tile
+static constexpr uint32_t STAGE_TILE = 16384;      // entries per workgroup tile (fixed-base tables: 2^19 .. 2^21 buckets)
+// The per-window path (<= 2^15 buckets per window) takes half-size tiles: 74 KiB of LDS instead of 148,
+// so TWO level-2 workgroups share a CU and one's loads overlap the other's ranking (level 1 + level 2
+// 0.49 -> 0.42 ms at 2^22 pairs, 0.14 -> 0.11 at 2^20).  Its tiles span ~64 buckets; 2048 keys are plenty.
+static constexpr uint32_t STAGE_TILE_PW = 8192, STAGE_MAX_KEYS2_PW = 2048;
 static constexpr uint32_t STAGE_MAX_BINS1 = 512;   // coarse bins per window handled in LDS
 static constexpr uint32_t STAGE_MAX_KEYS2 = 4096;  // bucket range one level-2 tile may span in LDS
 
@@ -48,19 +52,19 @@ DEV void block_excl_scan(const uint32_t *cnt, uint32_t *ofs, uint32_t *tmp /* bl
 // TABLE = true (fixed-base mode, table_kernels.cuh): the `wgroup` windows of one MSM share ONE bucket
 // set (MSM j = w / wgroup of a batch: y = j * B + bucket, cursors indexed by j and the coarse bin) and
 // x = (w % wgroup) * N + first + i, the index into the window tables (N = registered key length).
-template <class DIGIT, bool TABLE>
+template <class DIGIT, bool TABLE, uint32_t TILE = STAGE_TILE>
 KERNEL void __launch_bounds__(1024) k_stage1(const DIGIT *__restrict__ digits, uint32_t n, uint32_t B, uint32_t fine_bits, uint32_t CB,
                                               uint32_t N, uint32_t first, uint32_t wgroup, uint32_t *__restrict__ cursor1, U2 *__restrict__ part) {
     DYN_SHARED(U2, stage);
     __shared__ uint32_t cnt[STAGE_MAX_BINS1], lofs[STAGE_MAX_BINS1], gbase[STAGE_MAX_BINS1], tmp[1024], total_s;
     const uint32_t w = blockIdx.y;
-    const uint32_t base = blockIdx.x * STAGE_TILE, end = (base + STAGE_TILE < n) ? base + STAGE_TILE : n;
+    const uint32_t base = blockIdx.x * TILE, end = (base + TILE < n) ? base + TILE : n;
     const DIGIT *dw = digits + (size_t)w * n;
     const uint32_t set = TABLE ? w / wgroup : w;
     const uint32_t key_base = set * B, cur_base = set * CB, idx_base = TABLE ? (w % wgroup) * N + first : 0u;
     for (uint32_t b = threadIdx.x; b < CB; b += blockDim.x) cnt[b] = 0;
     __syncthreads();
-    constexpr int PER = STAGE_TILE / 1024;               // 16 points per lane: blockDim.x must be 1024 (the test emulation runs these kernels with all 1024 lanes too)
+    constexpr int PER = TILE / 1024;               // 16 points per lane: blockDim.x must be 1024 (the test emulation runs these kernels with all 1024 lanes too)
     DIGIT dreg[PER];                                     // the tile's digits stay in registers between the two passes
 #pragma unroll
     for (int k = 0; k < PER; k++) {
@@ -127,19 +131,20 @@ KERNEL void __launch_bounds__(1024) k_stage2_count(const U2 *__restrict__ part, 
 // have bucket ids in [key_lo, key_lo + STAGE_MAX_KEYS2) in the common case; entries outside that
 // range (sparse inputs spanning many coarse bins) are placed directly.
 // dynamic LDS: STAGE_TILE * 4 (staged x) + STAGE_TILE * 2 (staged local key).
+template <uint32_t TILE = STAGE_TILE, uint32_t KEYS = STAGE_MAX_KEYS2>
 KERNEL void __launch_bounds__(1024) k_stage2(const U2 *__restrict__ part, const uint32_t *__restrict__ total_ptr, uint32_t fine_bits,
                                               uint32_t *__restrict__ cursor2, uint32_t *__restrict__ sorted) {
     DYN_SHARED(uint32_t, stage_x);
-    uint16_t *stage_k = reinterpret_cast<uint16_t *>(stage_x + STAGE_TILE);
-    __shared__ uint32_t cnt[STAGE_MAX_KEYS2], lofs[STAGE_MAX_KEYS2], gbase[STAGE_MAX_KEYS2], tmp[1024], total_s;
+    uint16_t *stage_k = reinterpret_cast<uint16_t *>(stage_x + TILE);
+    __shared__ uint32_t cnt[KEYS], lofs[KEYS], gbase[KEYS], tmp[1024], total_s;
     const uint32_t total = *total_ptr;
-    const uint32_t base = blockIdx.x * STAGE_TILE;
+    const uint32_t base = blockIdx.x * TILE;
     if (base >= total) return;
-    const uint32_t end = (total - base > STAGE_TILE) ? base + STAGE_TILE : total;
+    const uint32_t end = (total - base > TILE) ? base + TILE : total;
     const uint32_t key_lo = (part[base].y >> fine_bits) << fine_bits;
-    for (uint32_t b = threadIdx.x; b < STAGE_MAX_KEYS2; b += blockDim.x) cnt[b] = 0;
+    for (uint32_t b = threadIdx.x; b < KEYS; b += blockDim.x) cnt[b] = 0;
     __syncthreads();
-    constexpr int PER = STAGE_TILE / 1024;
+    constexpr int PER = TILE / 1024;
     U2 ereg[PER];                                        // the tile's entries stay in registers between the two passes
 #pragma unroll
     for (int j = 0; j < PER; j++) {
@@ -149,11 +154,11 @@ KERNEL void __launch_bounds__(1024) k_stage2(const U2 *__restrict__ part, const 
 #pragma unroll
     for (int j = 0; j < PER; j++) {
         uint32_t k = ereg[j].y - key_lo;
-        if (ereg[j].y != 0xFFFFFFFFu && k < STAGE_MAX_KEYS2) atomicAdd(&cnt[k], 1u);
+        if (ereg[j].y != 0xFFFFFFFFu && k < KEYS) atomicAdd(&cnt[k], 1u);
     }
     __syncthreads();
-    block_excl_scan(cnt, lofs, tmp, STAGE_MAX_KEYS2, &total_s);
-    for (uint32_t b = threadIdx.x; b < STAGE_MAX_KEYS2; b += blockDim.x) {
+    block_excl_scan(cnt, lofs, tmp, KEYS, &total_s);
+    for (uint32_t b = threadIdx.x; b < KEYS; b += blockDim.x) {
         uint32_t c = cnt[b];
         gbase[b] = c ? atomicAdd(&cursor2[(size_t)key_lo + b], c) : 0;
         cnt[b] = lofs[b];
@@ -164,7 +169,7 @@ KERNEL void __launch_bounds__(1024) k_stage2(const U2 *__restrict__ part, const 
         U2 e = ereg[j];
         if (e.y == 0xFFFFFFFFu) continue;
         uint32_t k = e.y - key_lo;
-        if (k < STAGE_MAX_KEYS2) {
+        if (k < KEYS) {
             uint32_t q = atomicAdd(&cnt[k], 1u);
             stage_x[q] = e.x;
             stage_k[q] = (uint16_t)k;

@@ -43,7 +43,10 @@ while time.time() < t_end:
     n = rng.choice([1, 2, 3, 17, 64, 255, 1000, 4096, 5000, 1 << 14, 40000, 1 << 16, 100000, 1 << 17, 200000, 1 << 18])
     kind = rng.randrange(5)
     forced = rng.choice([0, 0, 0, 4, 5, 7, 9, 11, 12, 13, 14, 15, 16])
-    mode = rng.choice(["commit", "commit", "tables", "batch", "partials"])
+    mode = rng.choice(["commit", "commit", "tables", "batch", "partials", "tables_batch"])
+    staged_small, chunks_small = rng.random() < 0.3, rng.random() < 0.3      # the LDS-staged sort / host point chunks at small sizes too
+    lib.tune(_lib.TUNE_STAGED_MIN_N, 1 if staged_small else -1)
+    lib.tune(_lib.TUNE_HOST_CHUNK_MIN_N, 2048 if chunks_small else -1)
     bases = C.synth_bases(cid, n, seed=rng.getrandbits(16)) if n <= 4096 else None
     key = cm.CommitmentKey(cid, bases) if bases is not None else cm.CommitmentKey.synthetic(cid, n, seed=rng.getrandbits(16))
     if bases is None:
@@ -53,7 +56,7 @@ while time.time() < t_end:
     sc = scalars(cid, n, kind)
     want = C.msm_pippenger(cid, sc, bases)
     lib.check(lib.c.mira_msm_set_window_bits(forced))
-    desc = f"curve {cid} n {n} kind {kind} c {forced} {mode}"
+    desc = f"curve {cid} n {n} kind {kind} c {forced} {mode} staged {staged_small} chunks {chunks_small}"
     try:
         if mode == "commit":
             got = key.commit(sc)
@@ -61,8 +64,16 @@ while time.time() < t_end:
             assert (got == got2).all(), desc
         elif mode == "tables" and n <= (1 << 16):
             lib.check(lib.c.mira_msm_set_window_bits(0))
-            key.precompute()
+            key.precompute(rng.choice([16, 16, 20, 20, 22]))
             got = key.commit(sc)
+        elif mode == "tables_batch" and n <= (1 << 16):     # 16-bit shared-bucket tables, one bucket set per commitment
+            lib.check(lib.c.mira_msm_set_window_bits(0))
+            key.precompute(16)
+            m = max(1, n // 2)
+            vs = [sc[:m], scalars(cid, m, rng.randrange(3)), np.zeros((m, 4), dtype=np.uint64)]
+            res = key.commit_batch(vs)
+            assert (res[1] == C.msm_pippenger(cid, vs[1], bases[:m])).all() and not res[2].any(), desc
+            got, want = res[0], C.msm_pippenger(cid, vs[0], bases[:m])
         elif mode == "batch":
             m = max(1, n // 2)
             vs = [sc[:m], scalars(cid, m, rng.randrange(3))]
@@ -82,6 +93,7 @@ while time.time() < t_end:
         assert (got == want).all(), desc
     finally:
         lib.check(lib.c.mira_msm_set_window_bits(0))
+        lib.tune(_lib.TUNE_STAGED_MIN_N, -1); lib.tune(_lib.TUNE_HOST_CHUNK_MIN_N, -1)
         key.close()
     cases += 1
     if cases % 25 == 0:

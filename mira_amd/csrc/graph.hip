@@ -56,6 +56,10 @@ struct Program {
 };
 std::map<uint64_t, Program> g_programs;
 constexpr uint32_t GRAPH_MAX_BATCH = 16;           // graphs per launch
+// Intermediates kept in LDS per workgroup (9 KiB each at 256 lanes).  Measured at k = 17: with a batch
+// that fills the wave slots two slots are best (eleven graphs 1.98 -> 1.87 ms; eight cost occupancy, 2.14),
+// a lone graph of two workgroups per CU takes eight (0.280 -> 0.247 ms).
+constexpr uint32_t GRAPH_LDS_SLOTS_BATCH = 2, GRAPH_LDS_SLOTS_LONE = 8;
 
 size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
@@ -271,6 +275,32 @@ int graph_compile(int field, const mira_graph *gr, uint32_t num_challenges, uint
         }
     }
 
+    // Renumber the slots by how often the program touches them, most used first: the kernel keeps the
+    // lowest-numbered ones in LDS (GRAPH_LDS_SLOTS_*) and the rest in the global workspace.
+    {
+        auto words_of = [](uint32_t head) { const uint32_t op = head & 0xFFu; return op == GOP_MAC ? 7u : (op == GOP_ADD || op == GOP_SUB || op == GOP_MUL) ? 5u : 4u; };
+        auto nsrc_of = [](uint32_t head) { const uint32_t op = head & 0xFFu; return op == GOP_MAC ? 3u : (op == GOP_ADD || op == GOP_SUB || op == GOP_MUL) ? 2u : 1u; };
+        std::vector<uint64_t> uses(nslots, 0);
+        for (size_t pos = 0; pos < stream.size(); pos += words_of(stream[pos])) {
+            if (stream[pos + 1] != GRAPH_NO_SLOT) uses[stream[pos + 1]]++;
+            for (uint32_t k = 0; k < nsrc_of(stream[pos]); k++) {
+                const uint32_t w = stream[pos + 3 + k];
+                if ((w >> 29) == MIRA_SRC_INTERMEDIATE) uses[w & 0x1FFFFFFFu]++;
+            }
+        }
+        std::vector<uint32_t> order(nslots), rank(nslots);
+        for (uint32_t i = 0; i < nslots; i++) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return uses[a] > uses[b]; });
+        for (uint32_t i = 0; i < nslots; i++) rank[order[i]] = i;
+        for (size_t pos = 0; pos < stream.size(); pos += words_of(stream[pos])) {
+            if (stream[pos + 1] != GRAPH_NO_SLOT) stream[pos + 1] = rank[stream[pos + 1]];
+            for (uint32_t k = 0; k < nsrc_of(stream[pos]); k++) {
+                uint32_t &w = stream[pos + 3 + k];
+                if ((w >> 29) == MIRA_SRC_INTERMEDIATE) w = (MIRA_SRC_INTERMEDIATE << 29) | rank[w & 0x1FFFFFFFu];
+            }
+        }
+    }
+
     Program pg;
     pg.field = field; pg.ninstr = ninstr; pg.nslots = nslots; pg.num_challenges = num_challenges; pg.num_columns = num_columns;
     pg.num_rotations = gr->num_rotations; pg.num_calculations = n_in;
@@ -351,11 +381,21 @@ int graph_eval_batch(const uint64_t *handles, uint32_t count, const mira_eval_co
         GraphCol gc{reinterpret_cast<const unsigned char *>(columns[c].d_data), columns[c].kind, 0};
         memcpy(p0.h_dyn + p0.o_cols + (size_t)c * sizeof(GraphCol), &gc, sizeof gc);
     }
+#ifndef MIRA_CPU_EMU
+    static bool lds_ready = false;                           // eight LDS slots are 72 KiB, above the 64 KiB default
+    if (!lds_ready) {
+        RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_graph_eval<Fq29>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GRAPH_LDS_SLOTS_LONE * 9 * block * 4)));
+        RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_graph_eval<Fr29>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GRAPH_LDS_SLOTS_LONE * 9 * block * 4)));
+        lds_ready = true;
+    }
+#endif
     tm_begin();
     for (uint32_t done = 0; done < count; done += GRAPH_MAX_BATCH) {
         const uint32_t cnt = std::min<uint32_t>(GRAPH_MAX_BATCH, count - done);
         if (done) RT_CHECK(rt_sync(g.stream));               // the previous launch's copy still reads the pinned staging
-        uint32_t live = 0, max_slots = 1;
+        uint32_t live = 0, max_slots = 1, live_guess = 0;
+        for (uint32_t k = 0; k < cnt; k++) live_guess += pgs[done + k]->num_calculations != 0;
+        const uint32_t lds_slots = (uint64_t)grid * live_guess <= 512 ? GRAPH_LDS_SLOTS_LONE : GRAPH_LDS_SLOTS_BATCH;
         for (uint32_t k = 0; k < cnt; k++) {
             Program &pg = *pgs[done + k];
             if (pg.num_calculations == 0) {                  // Ok(F::ZERO), graph_evaluator.rs:386-389
@@ -364,7 +404,8 @@ int graph_eval_batch(const uint64_t *handles, uint32_t count, const mira_eval_co
             }
             const unsigned char *st = reinterpret_cast<const unsigned char *>(pg.d_static);
             GraphJob job{reinterpret_cast<const uint32_t *>(st + pg.o_code), reinterpret_cast<const uint32_t *>(st + pg.o_const),
-                         reinterpret_cast<const int32_t *>(st + pg.o_rot), reinterpret_cast<unsigned char *>(d_outs[done + k]), pg.ninstr, 0};
+                         reinterpret_cast<const int32_t *>(st + pg.o_rot), reinterpret_cast<unsigned char *>(d_outs[done + k]), pg.ninstr,
+                         std::min<uint32_t>(pg.nslots, lds_slots)};
             memcpy(p0.h_dyn + p0.o_jobs + (size_t)live * sizeof(GraphJob), &job, sizeof job);
             max_slots = std::max(max_slots, pg.nslots);
             live++;
@@ -375,10 +416,10 @@ int graph_eval_batch(const uint64_t *handles, uint32_t count, const mira_eval_co
             RT_CHECK(rt_h2d(p0.dyn.p, p0.h_dyn, p0.dyn_bytes, g.stream));
             const unsigned char *dy = reinterpret_cast<const unsigned char *>(p0.dyn.p);
             if (p0.field == MIRA_FIELD_FQ)
-                LAUNCH(k_graph_eval<Fq29>, dim3(grid, live), block, 0, g.stream, reinterpret_cast<const GraphJob *>(dy + p0.o_jobs), reinterpret_cast<const uint32_t *>(dy + p0.o_chal),
+                LAUNCH(k_graph_eval<Fq29>, dim3(grid, live), block, (size_t)lds_slots * 9 * block * 4, g.stream, reinterpret_cast<const GraphJob *>(dy + p0.o_jobs), reinterpret_cast<const uint32_t *>(dy + p0.o_chal),
                        reinterpret_cast<const GraphCol *>(dy + p0.o_cols), (uint64_t)num_rows, reinterpret_cast<uint32_t *>(g.graph_ws.p), (uint64_t)ws_stride);
             else
-                LAUNCH(k_graph_eval<Fr29>, dim3(grid, live), block, 0, g.stream, reinterpret_cast<const GraphJob *>(dy + p0.o_jobs), reinterpret_cast<const uint32_t *>(dy + p0.o_chal),
+                LAUNCH(k_graph_eval<Fr29>, dim3(grid, live), block, (size_t)lds_slots * 9 * block * 4, g.stream, reinterpret_cast<const GraphJob *>(dy + p0.o_jobs), reinterpret_cast<const uint32_t *>(dy + p0.o_chal),
                        reinterpret_cast<const GraphCol *>(dy + p0.o_cols), (uint64_t)num_rows, reinterpret_cast<uint32_t *>(g.graph_ws.p), (uint64_t)ws_stride);
         }
     }

@@ -53,7 +53,7 @@ struct GraphJob {
     const uint32_t *code, *consts29;
     const int32_t *rotations;
     unsigned char *out;
-    uint32_t ninstr, pad;
+    uint32_t ninstr, nlds;                               // slots below nlds live in LDS (the compiler numbers the most used ones lowest)
 };
 
 // grid = (row blocks, graphs of the batch): a fold step's handful of graphs over 2^17 rows are two waves
@@ -62,7 +62,9 @@ template <class F>
 KERNEL void __launch_bounds__(256) k_graph_eval(const GraphJob *__restrict__ jobs, const uint32_t *__restrict__ challenges29,
                          const GraphCol *__restrict__ cols, uint64_t nrows, uint32_t *__restrict__ ws_all, uint64_t ws_stride) {
     using S = typename F::Sat;
+    DYN_SHARED(uint32_t, lds);                           // lds[slot][limb][lane of the workgroup]
     const GraphJob job = jobs[blockIdx.y];
+    const uint32_t nlds = job.nlds;
     const uint32_t *__restrict__ code = job.code, *__restrict__ consts29 = job.consts29;
     const int32_t *__restrict__ rotations = job.rotations;
     unsigned char *__restrict__ out = job.out;
@@ -81,8 +83,13 @@ KERNEL void __launch_bounds__(256) k_graph_eval(const GraphJob *__restrict__ job
 #pragma unroll
                 for (int k = 0; k < 9; k++) r.l[k] = p[k];
             } else if (kind == MIRA_SRC_INTERMEDIATE) {
+                if (payload < nlds) {                        // wave-uniform
 #pragma unroll
-                for (int k = 0; k < 9; k++) r.l[k] = ws[((size_t)payload * 9 + k) * T + lane];
+                    for (int k = 0; k < 9; k++) r.l[k] = lds[(payload * 9 + k) * blockDim.x + threadIdx.x];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 9; k++) r.l[k] = ws[((size_t)payload * 9 + k) * T + lane];
+                }
             } else {
                 const GraphCol c = cols[payload & 0xFFFFFu];
                 int64_t rr = ((int64_t)row + rotations[payload >> 20]) % (int64_t)nrows;   // rem_euclid, graph_evaluator.rs:51-53
@@ -113,8 +120,13 @@ KERNEL void __launch_bounds__(256) k_graph_eval(const GraphJob *__restrict__ job
                 pc += 4;
             }
             if (dst != GRAPH_NO_SLOT) {                      // no slot: nobody reads it again
+                if (dst < nlds) {
 #pragma unroll
-                for (int k = 0; k < 9; k++) ws[((size_t)dst * 9 + k) * T + lane] = v.l[k];
+                    for (int k = 0; k < 9; k++) lds[(dst * 9 + k) * blockDim.x + threadIdx.x] = v.l[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 9; k++) ws[((size_t)dst * 9 + k) * T + lane] = v.l[k];
+                }
             }
         }
         fe_store(out + row * 32, f29_to_r256(v));

@@ -28,11 +28,18 @@ int operand_count(uint32_t op, uint32_t nparts) {
     }
 }
 
-// reference form (x * 2^256, 4 x u64) -> the multiplier form of the kernel (x * 2^261, 9 x 29-bit limbs, canonical)
-template <class FP> void to_limbs29(const uint64_t in[4], uint32_t out[9]) {
+// Forms.  The kernel's multiplier divides by 2^261, so a value x is carried as x * 2^(261 - 5 f) for some
+// integer f, its FORM: f = 0 is the multiplier's own Montgomery form (closed under multiplication),
+// f = 1 is the reference's memory layout x * 2^256 -- a column as it is read, no lifting product --
+// and the product of forms f1 and f2 has form f1 + f2; sums need equal forms.  Constants and
+// challenges are converted on the host to whatever form their use wants.
+// reference form (x * 2^256, 4 x u64) -> x * 2^(261 - 5 form) as 9 x 29-bit limbs, canonical
+template <class FP> void to_limbs29(const uint64_t in[4], int form, uint32_t out[9]) {
     hostf::HFe<FP> s;
     memcpy(s.l, in, 32);
-    s = hostf::mul(s, hostf::from_u64<FP>(32));
+    static hostf::HFe<FP> p32 = hostf::from_u64<FP>(32), i32 = hostf::inv(hostf::from_u64<FP>(32));
+    for (int k = form; k < 1; k++) s = hostf::mul(s, p32);       // 2^256 -> 2^(256 + 5 (1 - form))
+    for (int k = 1; k < form; k++) s = hostf::mul(s, i32);
     for (int i = 0; i < 9; i++) {
         const int bit = 29 * i, w = bit / 64, sh = bit % 64;
         uint64_t v = s.l[w] >> sh;
@@ -40,14 +47,18 @@ template <class FP> void to_limbs29(const uint64_t in[4], uint32_t out[9]) {
         out[i] = (uint32_t)(v & 0x1FFFFFFFu);
     }
 }
-void to_limbs29(int field, const uint64_t in[4], uint32_t out[9]) {
-    if (field == MIRA_FIELD_FQ) to_limbs29<FqP>(in, out); else to_limbs29<FrP>(in, out);
+void to_limbs29(int field, const uint64_t in[4], int form, uint32_t out[9]) {
+    if (field == MIRA_FIELD_FQ) to_limbs29<FqP>(in, form, out); else to_limbs29<FrP>(in, form, out);
+}
+void one_raw(int field, uint64_t out[4]) {                      // 1 in the reference form
+    if (field == MIRA_FIELD_FQ) { auto o = hostf::one<FqP>(); memcpy(out, o.l, 32); } else { auto o = hostf::one<FrP>(); memcpy(out, o.l, 32); }
 }
 
 struct Program {
     int field = 0;
     uint32_t ninstr = 0, nslots = 0, num_challenges = 0, num_columns = 0, num_rotations = 0, num_calculations = 0;
     std::vector<uint32_t> used_columns;        // column indices the code reads
+    std::vector<std::pair<uint32_t, int>> chal_vars;   // (challenge, form) of every challenge operand: converted per evaluation
     void *d_static = nullptr;                  // code | constants | rotations
     size_t o_code = 0, o_const = 0, o_rot = 0;
     DevBuf dyn;                                // challenges | column table of the current evaluation
@@ -62,6 +73,16 @@ constexpr uint32_t GRAPH_MAX_BATCH = 16;           // graphs per launch
 constexpr uint32_t GRAPH_LDS_SLOTS_BATCH = 2, GRAPH_LDS_SLOTS_LONE = 8;
 
 size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+int ensure_dyn(Program &pg, size_t bytes) {
+    if (bytes <= pg.dyn_bytes && pg.h_dyn) return MIRA_OK;
+    if (pg.h_dyn) (void)rt_host_free(pg.h_dyn);
+    pg.h_dyn = nullptr; pg.dyn_bytes = 0;
+    int rc = pg.dyn.ensure(bytes);
+    if (rc) return rc;
+    if (rt_host_alloc(reinterpret_cast<void **>(&pg.h_dyn), bytes) != hipSuccess) { pg.h_dyn = nullptr; set_error("pinned allocation for the compiled graph failed"); return MIRA_E_ALLOC; }
+    pg.dyn_bytes = bytes;
+    return MIRA_OK;
+}
 
 }   // namespace
 
@@ -111,6 +132,34 @@ int graph_compile(int field, const mira_graph *gr, uint32_t num_challenges, uint
     }
     if (pos != gr->code_words) { set_error("graph code has trailing words"); return MIRA_E_BAD_ARG; }
 
+    // Constants and challenges that the reference copies into intermediates (Store, graph_evaluator.rs:261-279)
+    // are read at their uses instead: as direct operands the host can hand each use the form it wants.
+    {
+        std::vector<uint32_t> alias(n_in, 0xFFFFFFFFu), new_index(n_in, 0);
+        for (uint32_t i = 0; i + 1 < n_in; i++) {                // the last calculation is the result: it stays
+            const uint32_t w = srcs[calcs[i].first_src];
+            if (calcs[i].op == MIRA_OP_STORE && ((w >> 29) == MIRA_SRC_CONSTANT || (w >> 29) == MIRA_SRC_CHALLENGE)) alias[i] = w;
+        }
+        std::vector<Calc> calcs2;
+        std::vector<uint32_t> srcs2;
+        for (uint32_t i = 0; i < n_in; i++) {
+            if (alias[i] != 0xFFFFFFFFu) continue;
+            new_index[i] = (uint32_t)calcs2.size();
+            calcs2.push_back(Calc{calcs[i].op, calcs[i].nparts, srcs2.size(), calcs[i].nsrc});
+            for (size_t k = 0; k < calcs[i].nsrc; k++) {
+                uint32_t w = srcs[calcs[i].first_src + k];
+                if ((w >> 29) == MIRA_SRC_INTERMEDIATE) {
+                    const uint32_t t = w & 0x1FFFFFFFu;
+                    w = alias[t] != 0xFFFFFFFFu ? alias[t] : ((MIRA_SRC_INTERMEDIATE << 29) | new_index[t]);
+                }
+                srcs2.push_back(w);
+            }
+        }
+        calcs.swap(calcs2);
+        srcs.swap(srcs2);
+    }
+    const uint32_t n_mid = (uint32_t)calcs.size();
+
     // Multiply-accumulate fusion.  Gates are sums of products: `acc = acc + c_i * x_i` flattens to MUL, ADD
     // pairs whose product is read once, by the ADD.  Folding the MUL into the ADD (one instruction
     // addend + p * q) halves the instruction count of such chains, and the running sum then stays in the
@@ -118,15 +167,15 @@ int graph_compile(int field, const mira_graph *gr, uint32_t num_challenges, uint
     // product is computed.  Not when an operand of the MUL is itself a forwarded value (it would need
     // a slot instead); values are exact field elements, so regrouping changes no result.
     {
-        std::vector<uint32_t> nuses(n_in, 0);
-        for (uint32_t i = 0; i < n_in; i++)
+        std::vector<uint32_t> nuses(n_mid, 0);
+        for (uint32_t i = 0; i < n_mid; i++)
             for (size_t k = 0; k < calcs[i].nsrc; k++) {
                 const uint32_t w = srcs[calcs[i].first_src + k];
                 if ((w >> 29) == MIRA_SRC_INTERMEDIATE) nuses[w & 0x1FFFFFFFu]++;
             }
-        std::vector<uint32_t> absorbed(n_in, 0xFFFFFFFFu);          // MUL j -> the ADD that takes it
-        std::vector<int> takes(n_in, -1);                            // ADD i -> which of its operands is the absorbed MUL
-        for (uint32_t i = 0; i < n_in; i++) {
+        std::vector<uint32_t> absorbed(n_mid, 0xFFFFFFFFu);          // MUL j -> the ADD that takes it
+        std::vector<int> takes(n_mid, -1);                            // ADD i -> which of its operands is the absorbed MUL
+        for (uint32_t i = 0; i < n_mid; i++) {
             if (calcs[i].op != MIRA_OP_ADD) continue;
             int best = -1;
             uint32_t best_j = 0;
@@ -144,11 +193,11 @@ int graph_compile(int field, const mira_graph *gr, uint32_t num_challenges, uint
             }
             if (best >= 0) { takes[i] = best; absorbed[best_j] = i; }
         }
-        std::vector<uint32_t> new_index(n_in, 0);
+        std::vector<uint32_t> new_index(n_mid, 0);
         std::vector<Calc> calcs2;
         std::vector<uint32_t> srcs2;
         auto remap = [&](uint32_t w) { return (w >> 29) == MIRA_SRC_INTERMEDIATE ? ((MIRA_SRC_INTERMEDIATE << 29) | new_index[w & 0x1FFFFFFFu]) : w; };
-        for (uint32_t i = 0; i < n_in; i++) {
+        for (uint32_t i = 0; i < n_mid; i++) {
             if (absorbed[i] != 0xFFFFFFFFu) continue;
             new_index[i] = (uint32_t)calcs2.size();
             if (takes[i] >= 0) {
@@ -167,13 +216,100 @@ int graph_compile(int field, const mira_graph *gr, uint32_t num_challenges, uint
     }
     const uint32_t n = (uint32_t)calcs.size();
 
+    // ---- forms (see to_limbs29): which form should every calculation's value have, so that as few
+    // conversions (one multiplication each) as possible are needed?  Columns are form 1, constants and
+    // challenges are free, a product's form is the sum of its factors' forms, a sum's operands must agree,
+    // and the result may leave in any form (the last instruction converts and reduces it anyway).
+    // Values whose form can still slide -- products with a free factor, and sums of such -- are elements
+    // of a union-find with potentials: form = value(element) + offset; meeting a fixed form pins a whole
+    // group.  What cannot be reconciled (a shared subexpression wanted in two forms, ...) is converted
+    // where it is used.
+    struct Desc { int kind, f; uint32_t e; };                // kind 0: free (constant / challenge), 1: fixed form f, 2: sliding, form = val(e) + f
+    std::vector<uint32_t> uf_parent;
+    std::vector<int> uf_pot, uf_var;                         // pot = val(x) - val(parent); var of a resolved root
+    std::vector<char> uf_res;
+    auto uf_new = [&]() { uf_parent.push_back((uint32_t)uf_parent.size()); uf_pot.push_back(0); uf_var.push_back(0); uf_res.push_back(0); return (uint32_t)uf_parent.size() - 1; };
+    auto uf_find = [&](uint32_t x, int &pot) {                 // root of x, pot = val(x) - val(root)
+        pot = 0;
+        uint32_t r = x;
+        while (uf_parent[r] != r) { pot += uf_pot[r]; r = uf_parent[r]; }
+        uint32_t y = x; int acc = pot;                       // path compression
+        while (uf_parent[y] != y) { const uint32_t nx = uf_parent[y]; const int py = uf_pot[y]; uf_parent[y] = r; uf_pot[y] = acc; acc -= py; y = nx; }
+        return r;
+    };
+    auto uf_pin = [&](uint32_t e, int value) {                 // val(e) := value unless the group is pinned already
+        int pot; const uint32_t r = uf_find(e, pot);
+        if (!uf_res[r]) { uf_res[r] = 1; uf_var[r] = value - pot; }
+    };
+    auto uf_pinned = [&](uint32_t e, int &value) { int pot; const uint32_t r = uf_find(e, pot); value = uf_var[r] + pot; return (bool)uf_res[r]; };
+    auto uf_unite = [&](uint32_t a2, uint32_t b2, int d) {      // val(b2) = val(a2) + d, if both groups can still move
+        int pa, pb; const uint32_t ra = uf_find(a2, pa), rb = uf_find(b2, pb);
+        if (ra == rb) return;
+        if (uf_res[ra] && uf_res[rb]) return;
+        if (uf_res[rb]) { uf_parent[ra] = rb; uf_pot[ra] = pb - d - pa; }       // val(ra) = val(rb) + pb - d - pa
+        else { uf_parent[rb] = ra; uf_pot[rb] = pa + d - pb; }
+    };
+    auto final_form = [&](const Desc &x) { if (x.kind == 1) return x.f; int v; uf_pinned(x.e, v); return v + x.f; };   // unpinned groups sit at var 0
+    auto as_fixed = [&](Desc &x, int want) {                  // pin a sliding value so that its form is `want` (if still possible)
+        if (x.kind == 2) { uf_pin(x.e, want - x.f); x = Desc{1, final_form(x), 0}; }
+    };
+    auto add_rule = [&](Desc x, Desc y) -> Desc {
+        if (x.kind == 0 && y.kind == 0) return Desc{2, 0, uf_new()};
+        if (x.kind == 0) return y;
+        if (y.kind == 0) return x;
+        int v;
+        if (x.kind == 2 && uf_pinned(x.e, v)) x = Desc{1, v + x.f, 0};
+        if (y.kind == 2 && uf_pinned(y.e, v)) y = Desc{1, v + y.f, 0};
+        if (x.kind == 1 && y.kind == 1) return x;
+        if (x.kind == 1) { as_fixed(y, x.f); return x; }
+        if (y.kind == 1) { as_fixed(x, y.f); return y; }
+        uf_unite(x.e, y.e, x.f - y.f);                         // val(y.e) + y.f = val(x.e) + x.f
+        return x;
+    };
+    auto mul_rule = [&](Desc x, Desc y) -> Desc {
+        if (x.kind == 0 || y.kind == 0) return Desc{2, 0, uf_new()};           // a free factor: the product can have any form
+        int v;
+        if (x.kind == 2 && uf_pinned(x.e, v)) x = Desc{1, v + x.f, 0};
+        if (y.kind == 2 && uf_pinned(y.e, v)) y = Desc{1, v + y.f, 0};
+        if (x.kind == 2 && y.kind == 2) as_fixed(y, 0);
+        if (x.kind == 1 && y.kind == 1) return Desc{1, x.f + y.f, 0};
+        if (x.kind == 1) return Desc{2, y.f + x.f, y.e};
+        return Desc{2, x.f + y.f, x.e};
+    };
+    std::vector<Desc> desc(n);
+    auto operand_desc = [&](uint32_t w) -> Desc {
+        const uint32_t kind = w >> 29;
+        if (kind == MIRA_SRC_INTERMEDIATE) return desc[w & 0x1FFFFFFFu];
+        if (kind == MIRA_SRC_COLUMN) return Desc{1, 1, 0};
+        return Desc{0, 0, 0};
+    };
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t *w = srcs.data() + calcs[i].first_src;
+        Desc r;
+        switch (calcs[i].op) {
+            case MIRA_OP_ADD: case MIRA_OP_SUB: r = add_rule(operand_desc(w[0]), operand_desc(w[1])); break;
+            case MIRA_OP_MUL: r = mul_rule(operand_desc(w[0]), operand_desc(w[1])); break;
+            case MIRA_OP_SQUARE: { Desc x = operand_desc(w[0]); if (x.kind == 0) r = Desc{2, 0, uf_new()}; else { as_fixed(x, 0); r = Desc{1, 2 * final_form(x), 0}; } break; }
+            case MIRA_OP_DOUBLE: case MIRA_OP_NEGATE: case MIRA_OP_STORE: { Desc x = operand_desc(w[0]); r = x.kind == 0 ? Desc{2, 0, uf_new()} : x; break; }
+            case OP_MAC_INTERNAL: r = add_rule(operand_desc(w[0]), mul_rule(operand_desc(w[1]), operand_desc(w[2]))); break;
+            default:                                             // HORNER: value = value * factor + part
+                r = operand_desc(w[0]);
+                if (r.kind == 0) r = Desc{2, 0, uf_new()};
+                for (uint32_t k = 0; k < calcs[i].nparts; k++) r = add_rule(mul_rule(r, operand_desc(w[1])), operand_desc(w[2 + k]));
+                break;
+        }
+        desc[i] = r;
+    }
+    std::vector<int> form_of(n);
+    for (uint32_t i = 0; i < n; i++) form_of[i] = final_form(desc[i]);
+
     // readers of every intermediate; the final calculation's value leaves through `out`
     std::vector<uint32_t> last_use(n, 0), first_use(n, 0xFFFFFFFFu);
     for (uint32_t i = 0; i < n; i++)
         for (size_t k = 0; k < calcs[i].nsrc; k++) {
-            const uint32_t s = srcs[calcs[i].first_src + k];
-            if ((s >> 29) != MIRA_SRC_INTERMEDIATE) continue;
-            const uint32_t t = s & 0x1FFFFFFFu;
+            const uint32_t s2 = srcs[calcs[i].first_src + k];
+            if ((s2 >> 29) != MIRA_SRC_INTERMEDIATE) continue;
+            const uint32_t t = s2 & 0x1FFFFFFFu;
             last_use[t] = i;
             if (first_use[t] == 0xFFFFFFFFu) first_use[t] = i;
         }
@@ -181,7 +317,15 @@ int graph_compile(int field, const mira_graph *gr, uint32_t num_challenges, uint
     // from their definition to their last reader.  (HORNER expands to several instructions, each of
     // which moves the forwarding register on: its operands always come from slots.)
     auto used = [&](uint32_t t) { return first_use[t] != 0xFFFFFFFFu; };
-    auto forwarded = [&](uint32_t t) { return used(t) && first_use[t] == t + 1 && last_use[t] == t + 1 && calcs[t + 1].op != MIRA_OP_HORNER; };
+    auto reads_of = [&](uint32_t i, uint32_t t) {              // how often calculation i reads intermediate t
+        uint32_t c = 0;
+        for (size_t k = 0; k < calcs[i].nsrc; k++) c += srcs[calcs[i].first_src + k] == ((MIRA_SRC_INTERMEDIATE << 29) | t);
+        return c;
+    };
+    // (read ONCE: a form conversion of one operand moves the forwarding register on, a second read would see the converted value)
+    auto forwarded = [&](uint32_t t) {
+        return used(t) && first_use[t] == t + 1 && last_use[t] == t + 1 && calcs[t + 1].op != MIRA_OP_HORNER && reads_of(t + 1, t) == 1;
+    };
     std::vector<uint32_t> slot_of(n, GRAPH_NO_SLOT), free_slots, stream;
     std::vector<double> bound_of(n, 0.0);                    // proven bound of every calculation's value, in multiples of P
     std::vector<std::vector<uint32_t>> dying(n);
@@ -195,7 +339,7 @@ int graph_compile(int field, const mira_graph *gr, uint32_t num_challenges, uint
         uint32_t K = 0;
         double rb = 0;
         const bool binary = op == GOP_ADD || op == GOP_SUB || op == GOP_MUL;
-        auto bias = [](double b) { return b < 1.99 ? 2u : b < 3.99 ? 4u : b < 7.99 ? 8u : 16u; };   // f29_sub<K> needs the subtrahend below K P
+        auto bias = [](double b2) { return b2 < 1.99 ? 2u : b2 < 3.99 ? 4u : b2 < 7.99 ? 8u : 16u; };   // f29_sub<K> needs the subtrahend below K P
         switch (op) {
             case GOP_ADD: rb = ba + bb; break;
             case GOP_SUB: K = bias(bb); rb = ba + K; break;
@@ -229,41 +373,132 @@ int graph_compile(int field, const mira_graph *gr, uint32_t num_challenges, uint
         return bp * bq / 168.9 + 1.0 + bc;
     };
     const uint32_t PREV = GRAPH_SRC_PREV << 29;
+    // constants in the forms their uses want: pool entry = (constant index, or -1 for the number one; form)
+    std::vector<std::pair<int, int>> pool;
+    auto pool_word = [&](int ci, int form) {
+        for (size_t k = 0; k < pool.size(); k++)
+            if (pool[k].first == ci && pool[k].second == form) return (uint32_t)((MIRA_SRC_CONSTANT << 29) | k);
+        pool.push_back({ci, form});
+        return (uint32_t)((MIRA_SRC_CONSTANT << 29) | (pool.size() - 1));
+    };
+    std::vector<std::pair<uint32_t, int>> chal_vars;
+    auto chal_word = [&](uint32_t ch, int form) {
+        for (size_t k = 0; k < chal_vars.size(); k++)
+            if (chal_vars[k].first == ch && chal_vars[k].second == form) return (uint32_t)((MIRA_SRC_CHALLENGE << 29) | k);
+        chal_vars.push_back({ch, form});
+        return (uint32_t)((MIRA_SRC_CHALLENGE << 29) | (chal_vars.size() - 1));
+    };
+    // an operand as the emitter sees it: the word the kernel fetches, a proven bound, and its form (free: any)
+    struct Opnd { uint32_t w; double b; int f; bool free, prev; };
+    auto materialise = [&](Opnd &x, int form) {               // a free operand in the given form
+        if (!x.free) return;
+        const uint32_t kind = x.w >> 29, id = x.w & 0x1FFFFFFFu;
+        x.w = kind == MIRA_SRC_CONSTANT ? pool_word((int)id, form) : chal_word(id, form);
+        x.f = form; x.free = false;
+    };
+    auto convert_prev = [&](double b, int from, int to) -> double {   // the forwarded value into another form: times the number one in form to - from
+        return from == to ? b : emit(GOP_MUL, PREV, b, pool_word(-1, to - from), 1.0);
+    };
+    auto convert = [&](Opnd &x, int to) {                     // any fixed operand into form `to`: the result is the forwarded value
+        x.b = emit(GOP_MUL, x.w, x.b, pool_word(-1, to - x.f), 1.0);
+        x.w = PREV; x.prev = true; x.f = to;
+    };
+    // x (+ / -) y in form `target`; returns the bound, the value is the forwarded one
+    auto emit_addsub = [&](uint32_t op, Opnd x, Opnd y, int target) -> double {
+        int F;
+        if (x.free && y.free) F = target;
+        else if (x.free) F = y.f;
+        else if (y.free) F = x.f;
+        else if (x.f == y.f) F = x.f;
+        else if (x.prev) { convert(x, y.f); F = y.f; }        // never convert the OTHER operand while one sits in the forwarding register
+        else if (y.prev) { convert(y, x.f); F = x.f; }
+        else { convert(y, x.f); F = x.f; }
+        materialise(x, F); materialise(y, F);
+        return convert_prev(emit(op, x.w, x.b, y.w, y.b), F, target);
+    };
+    auto emit_mul = [&](Opnd x, Opnd y, int target) -> double {
+        if (x.free && y.free) { materialise(x, target); materialise(y, 0); }
+        else if (x.free) materialise(x, target - y.f);
+        else if (y.free) materialise(y, target - x.f);
+        return convert_prev(emit(GOP_MUL, x.w, x.b, y.w, y.b), x.f + y.f, target);
+    };
     for (uint32_t i = 0; i < n; i++) {
         // resolve the operands: intermediates become slots or the forwarded register
-        std::vector<uint32_t> s(calcs[i].nsrc);
-        std::vector<double> b(calcs[i].nsrc);
+        std::vector<Opnd> o(calcs[i].nsrc);
         for (size_t k = 0; k < calcs[i].nsrc; k++) {
-            uint32_t w = srcs[calcs[i].first_src + k];
-            if ((w >> 29) == MIRA_SRC_INTERMEDIATE) {
+            const uint32_t w = srcs[calcs[i].first_src + k];
+            const uint32_t kind = w >> 29;
+            if (kind == MIRA_SRC_INTERMEDIATE) {
                 const uint32_t t = w & 0x1FFFFFFFu;
-                b[k] = bound_of[t];
-                w = forwarded(t) ? PREV : ((MIRA_SRC_INTERMEDIATE << 29) | slot_of[t]);
+                o[k] = Opnd{forwarded(t) ? PREV : ((MIRA_SRC_INTERMEDIATE << 29) | slot_of[t]), bound_of[t], form_of[t], false, forwarded(t)};
+            } else if (kind == MIRA_SRC_COLUMN) {
+                o[k] = Opnd{w, 1.0, 1, false, false};         // canonical, in the reference's form
             } else {
-                b[k] = (w >> 29) == MIRA_SRC_COLUMN ? 1.01 : 1.0;   // a lifted column is < 1.006 P; constants and challenges are canonical
+                o[k] = Opnd{w, 1.0, 0, true, false};          // constants and challenges are canonical in whatever form they are asked for
             }
-            s[k] = w;
         }
+        const int T = form_of[i];
         double rb;
         switch (calcs[i].op) {
-            case MIRA_OP_ADD: rb = emit(GOP_ADD, s[0], b[0], s[1], b[1]); break;
-            case MIRA_OP_SUB: rb = emit(GOP_SUB, s[0], b[0], s[1], b[1]); break;
-            case MIRA_OP_MUL: rb = emit(GOP_MUL, s[0], b[0], s[1], b[1]); break;
-            case MIRA_OP_SQUARE: rb = emit(GOP_SQR, s[0], b[0], 0, 0); break;
-            case MIRA_OP_DOUBLE: rb = emit(GOP_DBL, s[0], b[0], 0, 0); break;
-            case MIRA_OP_NEGATE: rb = emit(GOP_NEG, s[0], b[0], 0, 0); break;
-            case MIRA_OP_STORE: rb = emit(GOP_COPY, s[0], b[0], 0, 0); break;
-            case OP_MAC_INTERNAL: rb = emit_mac(s[0], b[0], s[1], b[1], s[2], b[2]); break;
-            default:                                         // HORNER: start, factor, parts[] (graph_evaluator.rs:148-155): value = value * factor + part
-                rb = emit(GOP_COPY, s[0], b[0], 0, 0);
-                for (uint32_t k = 0; k < calcs[i].nparts; k++) {
-                    rb = emit(GOP_MUL, PREV, rb, s[1], b[1]);
-                    rb = emit(GOP_ADD, PREV, rb, s[2 + k], b[2 + k]);
-                    if (rb > GRAPH_MAX_BOUND) rb = emit(GOP_NORM, PREV, rb, 0, 0);
+            case MIRA_OP_ADD: rb = emit_addsub(GOP_ADD, o[0], o[1], T); break;
+            case MIRA_OP_SUB: rb = emit_addsub(GOP_SUB, o[0], o[1], T); break;
+            case MIRA_OP_MUL: rb = emit_mul(o[0], o[1], T); break;
+            case MIRA_OP_SQUARE:
+                if (o[0].free) materialise(o[0], T % 2 == 0 ? T / 2 : 0);
+                rb = convert_prev(emit(GOP_SQR, o[0].w, o[0].b, 0, 0), 2 * o[0].f, T);
+                break;
+            case MIRA_OP_DOUBLE: case MIRA_OP_NEGATE: case MIRA_OP_STORE: {
+                materialise(o[0], T);
+                const uint32_t gop = calcs[i].op == MIRA_OP_DOUBLE ? GOP_DBL : calcs[i].op == MIRA_OP_NEGATE ? GOP_NEG : GOP_COPY;
+                rb = convert_prev(emit(gop, o[0].w, o[0].b, 0, 0), o[0].f, T);
+                break;
+            }
+            case OP_MAC_INTERNAL: {                              // o[0] + o[1] * o[2]
+                Opnd c = o[0], pq = o[1], q = o[2];
+                const bool free_factor = pq.free || q.free;
+                const int fp = free_factor ? 0 : pq.f + q.f;     // the product's form, if it is not ours to choose
+                if (c.free) {                                    // a constant addend takes the product's form
+                    const int F = free_factor ? T : fp;
+                    if (pq.free && q.free) { materialise(pq, F); materialise(q, 0); }
+                    else if (pq.free) materialise(pq, F - q.f);
+                    else if (q.free) materialise(q, F - pq.f);
+                    materialise(c, F);
+                    rb = convert_prev(emit_mac(c.w, c.b, pq.w, pq.b, q.w, q.b), F, T);
+                } else if (free_factor) {                        // the free factor makes the product meet the addend
+                    if (pq.free && q.free) { materialise(pq, c.f); materialise(q, 0); }
+                    else if (pq.free) materialise(pq, c.f - q.f);
+                    else materialise(q, c.f - pq.f);
+                    rb = convert_prev(emit_mac(c.w, c.b, pq.w, pq.b, q.w, q.b), c.f, T);
+                } else if (fp == c.f) {
+                    rb = convert_prev(emit_mac(c.w, c.b, pq.w, pq.b, q.w, q.b), fp, T);
+                } else if (c.prev) {                             // the addend is the forwarded value: bring IT to the product's form
+                    convert(c, fp);
+                    rb = convert_prev(emit_mac(c.w, c.b, pq.w, pq.b, q.w, q.b), fp, T);
+                } else {                                         // product first (a factor may be the forwarded value), then the sum
+                    const double bp = emit(GOP_MUL, pq.w, pq.b, q.w, q.b);
+                    rb = emit_addsub(GOP_ADD, Opnd{PREV, bp, fp, false, true}, c, T);
                 }
                 break;
+            }
+            default: {                                           // HORNER: start, factor, parts[] (graph_evaluator.rs:148-155): value = value * factor + part
+                materialise(o[0], T);
+                rb = emit(GOP_COPY, o[0].w, o[0].b, 0, 0);
+                int fv = o[0].f;
+                for (uint32_t k = 0; k < calcs[i].nparts; k++) {
+                    Opnd part = o[2 + k];
+                    const int want = part.free ? T : part.f;     // the product in the form of the part it meets
+                    rb = emit_mul(Opnd{PREV, rb, fv, false, true}, o[1], o[1].free ? want : fv + o[1].f);
+                    fv = o[1].free ? want : fv + o[1].f;
+                    rb = emit_addsub(GOP_ADD, Opnd{PREV, rb, fv, false, true}, part, part.free ? fv : part.f);
+                    fv = part.free ? fv : part.f;
+                    if (rb > GRAPH_MAX_BOUND) rb = emit(GOP_NORM, PREV, rb, 0, 0);
+                }
+                rb = convert_prev(rb, fv, T);
+                break;
+            }
         }
         if (rb > GRAPH_MAX_BOUND) rb = emit(GOP_NORM, PREV, rb, 0, 0);   // keep the invariant: stored and forwarded values < 12 P
+        if (i + 1 == n) rb = emit(GOP_MUL, PREV, rb, pool_word(-1, 1 - T), 1.0);   // the result: into the reference's form, below 2 P (the kernel stores it canonical)
         bound_of[i] = rb;
         // operands are in registers before the result is written: a slot that dies here can take it
         for (uint32_t t : dying[i]) free_slots.push_back(slot_of[t]);
@@ -309,24 +544,27 @@ int graph_compile(int field, const mira_graph *gr, uint32_t num_challenges, uint
     // static part on the device: code | constants (9 x 29-bit limbs, multiplier form) | rotations
     pg.o_code = 0;
     pg.o_const = align16(stream.size() * 4);
-    pg.o_rot = align16(pg.o_const + (size_t)gr->num_constants * 36);
+    pg.o_rot = align16(pg.o_const + pool.size() * 36);
+    pg.chal_vars = chal_vars;
     const size_t total = align16(pg.o_rot + (size_t)gr->num_rotations * 4) + 16;
     std::vector<unsigned char> stage(total, 0);
     memcpy(stage.data() + pg.o_code, stream.data(), stream.size() * 4);
-    for (uint32_t k = 0; k < gr->num_constants; k++)
-        to_limbs29(field, gr->constants + (size_t)k * 4, reinterpret_cast<uint32_t *>(stage.data() + pg.o_const) + (size_t)k * 9);
+    uint64_t one_r[4];
+    one_raw(field, one_r);
+    for (size_t k = 0; k < pool.size(); k++)
+        to_limbs29(field, pool[k].first < 0 ? one_r : gr->constants + (size_t)pool[k].first * 4, pool[k].second,
+                   reinterpret_cast<uint32_t *>(stage.data() + pg.o_const) + k * 9);
     if (gr->num_rotations) memcpy(stage.data() + pg.o_rot, gr->rotations, (size_t)gr->num_rotations * 4);
     if (rt_malloc(&pg.d_static, total) != hipSuccess || !pg.d_static) { set_error("device allocation for the compiled graph failed"); return MIRA_E_ALLOC; }
     RT_CHECK(rt_h2d(pg.d_static, stage.data(), total, g.stream));
     RT_CHECK(rt_sync(g.stream));                             // `stage` is pageable host memory about to go out of scope
-    // dynamic part of an evaluation: challenges | column table, staged in pinned host memory
-    pg.o_chal = 0;
-    pg.o_cols = align16((size_t)num_challenges * 36);
-    pg.o_jobs = align16(pg.o_cols + (size_t)num_columns * sizeof(GraphCol));
-    pg.dyn_bytes = align16(pg.o_jobs + (size_t)GRAPH_MAX_BATCH * sizeof(GraphJob)) + 16;
-    int rc = pg.dyn.ensure(pg.dyn_bytes);
-    if (rc == MIRA_OK && rt_host_alloc(reinterpret_cast<void **>(&pg.h_dyn), pg.dyn_bytes) != hipSuccess) { set_error("pinned allocation for the compiled graph failed"); rc = MIRA_E_ALLOC; }
-    if (rc) { (void)rt_free(pg.d_static); if (pg.dyn.p) (void)rt_free(pg.dyn.p); return rc; }
+    // dynamic part of an evaluation: column table | job table | the challenges of every program of the batch in the forms
+    // it reads them, staged in pinned host memory (grown by the evaluation that needs more)
+    pg.o_cols = 0;
+    pg.o_jobs = align16((size_t)num_columns * sizeof(GraphCol));
+    pg.o_chal = align16(pg.o_jobs + (size_t)GRAPH_MAX_BATCH * sizeof(GraphJob));
+    int rc = ensure_dyn(pg, pg.o_chal + (chal_vars.size() + 8) * 36 * 4);
+    if (rc) { (void)rt_free(pg.d_static); return rc; }
     *handle_out = g.next_handle++;
     g_programs[*handle_out] = pg;
     return MIRA_OK;
@@ -373,10 +611,17 @@ int graph_eval_batch(const uint64_t *handles, uint32_t count, const mira_eval_co
     const uint32_t block = 256;
     const uint32_t grid = (uint32_t)std::min<size_t>((num_rows + block - 1) / block, 256 * 4);
     const size_t T = (size_t)grid * block;
-    Program &p0 = *pgs[0];                                   // its staging carries the batch's challenges, column table and job table
-    // the call's challenges (lifted to the multiplier form) and column pointers: one small copy from pinned memory
-    for (uint32_t k = 0; k < num_challenges; k++)
-        to_limbs29(p0.field, challenges + (size_t)k * 4, reinterpret_cast<uint32_t *>(p0.h_dyn + p0.o_chal) + (size_t)k * 9);
+    Program &p0 = *pgs[0];                                   // its staging carries the batch's column table, job table and challenges
+    {
+        size_t worst = 0;                                    // challenge entries of the largest launch
+        for (uint32_t done = 0; done < count; done += GRAPH_MAX_BATCH) {
+            size_t w = 0;
+            for (uint32_t k = done; k < std::min<uint32_t>(count, done + GRAPH_MAX_BATCH); k++) w += pgs[k]->chal_vars.size();
+            worst = std::max(worst, w);
+        }
+        if ((rc = ensure_dyn(p0, p0.o_chal + (worst + 1) * 36))) return rc;
+    }
+    // the call's column pointers and challenges (each in the forms its program reads it): one small copy from pinned memory
     for (uint32_t c = 0; c < num_columns; c++) {
         GraphCol gc{reinterpret_cast<const unsigned char *>(columns[c].d_data), columns[c].kind, 0};
         memcpy(p0.h_dyn + p0.o_cols + (size_t)c * sizeof(GraphCol), &gc, sizeof gc);
@@ -394,6 +639,7 @@ int graph_eval_batch(const uint64_t *handles, uint32_t count, const mira_eval_co
         const uint32_t cnt = std::min<uint32_t>(GRAPH_MAX_BATCH, count - done);
         if (done) RT_CHECK(rt_sync(g.stream));               // the previous launch's copy still reads the pinned staging
         uint32_t live = 0, max_slots = 1, live_guess = 0;
+        size_t chal_at = 0;
         for (uint32_t k = 0; k < cnt; k++) live_guess += pgs[done + k]->num_calculations != 0;
         const uint32_t lds_slots = (uint64_t)grid * live_guess <= 512 ? GRAPH_LDS_SLOTS_LONE : GRAPH_LDS_SLOTS_BATCH;
         for (uint32_t k = 0; k < cnt; k++) {
@@ -403,9 +649,13 @@ int graph_eval_batch(const uint64_t *handles, uint32_t count, const mira_eval_co
                 continue;
             }
             const unsigned char *st = reinterpret_cast<const unsigned char *>(pg.d_static);
+            for (size_t v = 0; v < pg.chal_vars.size(); v++)
+                to_limbs29(p0.field, challenges + (size_t)pg.chal_vars[v].first * 4, pg.chal_vars[v].second, reinterpret_cast<uint32_t *>(p0.h_dyn + p0.o_chal) + (chal_at + v) * 9);
             GraphJob job{reinterpret_cast<const uint32_t *>(st + pg.o_code), reinterpret_cast<const uint32_t *>(st + pg.o_const),
+                         reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(p0.dyn.p) + p0.o_chal) + chal_at * 9,
                          reinterpret_cast<const int32_t *>(st + pg.o_rot), reinterpret_cast<unsigned char *>(d_outs[done + k]), pg.ninstr,
                          std::min<uint32_t>(pg.nslots, lds_slots)};
+            chal_at += pg.chal_vars.size();
             memcpy(p0.h_dyn + p0.o_jobs + (size_t)live * sizeof(GraphJob), &job, sizeof job);
             max_slots = std::max(max_slots, pg.nslots);
             live++;
@@ -416,10 +666,10 @@ int graph_eval_batch(const uint64_t *handles, uint32_t count, const mira_eval_co
             RT_CHECK(rt_h2d(p0.dyn.p, p0.h_dyn, p0.dyn_bytes, g.stream));
             const unsigned char *dy = reinterpret_cast<const unsigned char *>(p0.dyn.p);
             if (p0.field == MIRA_FIELD_FQ)
-                LAUNCH(k_graph_eval<Fq29>, dim3(grid, live), block, (size_t)lds_slots * 9 * block * 4, g.stream, reinterpret_cast<const GraphJob *>(dy + p0.o_jobs), reinterpret_cast<const uint32_t *>(dy + p0.o_chal),
+                LAUNCH(k_graph_eval<Fq29>, dim3(grid, live), block, (size_t)lds_slots * 9 * block * 4, g.stream, reinterpret_cast<const GraphJob *>(dy + p0.o_jobs),
                        reinterpret_cast<const GraphCol *>(dy + p0.o_cols), (uint64_t)num_rows, reinterpret_cast<uint32_t *>(g.graph_ws.p), (uint64_t)ws_stride);
             else
-                LAUNCH(k_graph_eval<Fr29>, dim3(grid, live), block, (size_t)lds_slots * 9 * block * 4, g.stream, reinterpret_cast<const GraphJob *>(dy + p0.o_jobs), reinterpret_cast<const uint32_t *>(dy + p0.o_chal),
+                LAUNCH(k_graph_eval<Fr29>, dim3(grid, live), block, (size_t)lds_slots * 9 * block * 4, g.stream, reinterpret_cast<const GraphJob *>(dy + p0.o_jobs),
                        reinterpret_cast<const GraphCol *>(dy + p0.o_cols), (uint64_t)num_rows, reinterpret_cast<uint32_t *>(g.graph_ws.p), (uint64_t)ws_stride);
         }
     }

@@ -13,10 +13,12 @@
 // multiplication).  Values are "loose" between calculations; the host COMPILES the program
 // (graph.hip) with a proven bound for every value -- invariant: whatever is stored or forwarded is
 // < 12 P, so any two values may be multiplied (144 <= 168) -- and inserts a normalising
-// multiplication by one where a chain of additions would leave the budget.  Columns arrive in the
-// reference's R = 2^256 Montgomery form and are lifted to R' = 2^261 when read (one
-// multiplication); the result leaves canonical in the reference's form.  Field results are exact,
-// so every value equals the reference's bit for bit whatever the order of rows.
+// multiplication by one where a chain of additions would leave the budget.  Columns are read as they lie
+// in memory (x * 2^256, no lifting product): the compiler tracks for every value the power of two it
+// carries (its "form", graph.hip), hands constants and challenges over in the form each use wants,
+// and converts where forms cannot be made to agree; the program's last instruction leaves the result
+// as x * 2^256 below 2 P and the kernel stores it canonical.  Field results are exact, so every value
+// equals the reference's bit for bit whatever the order of rows.
 #pragma once
 #include "field29.cuh"
 #include "../../include/mira_gpu.h"
@@ -50,7 +52,7 @@ template <class F> DEV Fe29<F> graph_sub(const Fe29<F> &a, const Fe29<F> &b, uin
 // one compiled graph of a batch: the graphs of a batch (the d - 1 cross-term expressions of a fold
 // step, src/nifs/vanilla/mod.rs:100-121) read the same columns and challenges
 struct GraphJob {
-    const uint32_t *code, *consts29;
+    const uint32_t *code, *consts29, *challenges29;      // constants and this evaluation's challenges, each in the forms the program reads them
     const int32_t *rotations;
     unsigned char *out;
     uint32_t ninstr, nlds;                               // slots below nlds live in LDS (the compiler numbers the most used ones lowest)
@@ -59,13 +61,13 @@ struct GraphJob {
 // grid = (row blocks, graphs of the batch): a fold step's handful of graphs over 2^17 rows are two waves
 // per SIMD each -- launched together they fill the wave slots (82 VGPRs: six per SIMD)
 template <class F>
-KERNEL void __launch_bounds__(256) k_graph_eval(const GraphJob *__restrict__ jobs, const uint32_t *__restrict__ challenges29,
+KERNEL void __launch_bounds__(256) k_graph_eval(const GraphJob *__restrict__ jobs,
                          const GraphCol *__restrict__ cols, uint64_t nrows, uint32_t *__restrict__ ws_all, uint64_t ws_stride) {
     using S = typename F::Sat;
     DYN_SHARED(uint32_t, lds);                           // lds[slot][limb][lane of the workgroup]
     const GraphJob job = jobs[blockIdx.y];
     const uint32_t nlds = job.nlds;
-    const uint32_t *__restrict__ code = job.code, *__restrict__ consts29 = job.consts29;
+    const uint32_t *__restrict__ code = job.code, *__restrict__ consts29 = job.consts29, *__restrict__ challenges29 = job.challenges29;
     const int32_t *__restrict__ rotations = job.rotations;
     unsigned char *__restrict__ out = job.out;
     const uint32_t ninstr = job.ninstr;
@@ -94,8 +96,16 @@ KERNEL void __launch_bounds__(256) k_graph_eval(const GraphJob *__restrict__ job
                 const GraphCol c = cols[payload & 0xFFFFFu];
                 int64_t rr = ((int64_t)row + rotations[payload >> 20]) % (int64_t)nrows;   // rem_euclid, graph_evaluator.rs:51-53
                 if (rr < 0) rr += (int64_t)nrows;
-                if (c.kind == MIRA_COL_BOOL) r = c.p[rr] ? f29_one<F>() : f29_zero<F>();   // selector, src/plonk/eval.rs:62
-                else r = f29_from_r256<F>(fe_load<S>(c.p + (size_t)rr * 32));
+                // a column enters as it lies in memory -- x * 2^256, "form 1" of the compiler (graph.hip), no lifting
+                // product -- and a selector as the number one in that form (src/plonk/eval.rs:62)
+                if (c.kind == MIRA_COL_BOOL) {
+                    Fe<S> one_r;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) one_r.l[k] = c.p[rr] ? S::R1[k] : 0u;
+                    r = f29_unpack_canonical<F>(one_r);
+                } else {
+                    r = f29_unpack_canonical<F>(fe_load<S>(c.p + (size_t)rr * 32));
+                }
             }
             F29_SET(r, (double)bound / 256.0);
             (void)bound;
@@ -129,6 +139,6 @@ KERNEL void __launch_bounds__(256) k_graph_eval(const GraphJob *__restrict__ job
                 }
             }
         }
-        fe_store(out + row * 32, f29_to_r256(v));
+        fe_store(out + row * 32, reduce_once(f29_pack(v)));     // the program's last instruction left x * 2^256 below 2 P
     }
 }

@@ -14,6 +14,7 @@ static constexpr uint32_t FIXUP_HEAVY_GRID = 4096;   // waves of stage A (a quar
 
 // quads for the bucket reduction while its work items number less than ~1.5 waves per SIMD (the
 // chain of dependent additions is what takes the time there); single lanes beyond (throughput)
+static constexpr uint32_t SCAN_SOLO_TILES = 2;      // up to 4096 bucket counters: k_scan_c<true> (measured: 14 -> 7 us for one tile, 15 -> 13 for two, 16 -> 30 for seven)
 static inline bool reduce_with_quads(uint64_t work_items) { return work_items * 4 <= 98304; }
 
 // Host scalars (commit(&self, v: &[C::Scalar]) hands over host memory, src/commitment.rs:78) are
@@ -124,13 +125,20 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, cons
         LAUNCH_BARRIER_FLEX(k_hist, dim3(ntiles, p.Wt), 1024, (size_t)p.B * 4, st, reinterpret_cast<const int16_t *>(g.digits.p), (uint32_t)nc,
                        p.B, tile, reinterpret_cast<uint32_t *>(g.counts.p), wgroup);
         tm_mark("hist");
+        if (scan_blocks <= SCAN_SOLO_TILES) {                 // few buckets: one workgroup scans them all, one launch instead of three
+            LAUNCH_BARRIER(k_scan_c<true>, 1, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.counts.p), p.NB,
+                           reinterpret_cast<const uint32_t *>(g.block_sums.p), reinterpret_cast<uint32_t *>(g.offsets.p),
+                           reinterpret_cast<uint32_t *>(g.cursor.p), staged ? reinterpret_cast<uint32_t *>(g.coarse_offsets.p) : no_u32, fine_bits,
+                           plan, p.lanes, p.L, heavy_count, add ? no_u8 : reinterpret_cast<unsigned char *>(g.bucket_sums.p));
+        } else {
         LAUNCH_BARRIER(k_scan_a, scan_blocks, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.counts.p), p.NB,
                        reinterpret_cast<uint32_t *>(g.block_sums.p));
         LAUNCH_BARRIER(k_scan_b, 1, 1024, 0, st, reinterpret_cast<uint32_t *>(g.block_sums.p), scan_blocks);
-        LAUNCH_BARRIER(k_scan_c, scan_blocks, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.counts.p), p.NB,
+        LAUNCH_BARRIER(k_scan_c<false>, scan_blocks, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.counts.p), p.NB,
                        reinterpret_cast<const uint32_t *>(g.block_sums.p), reinterpret_cast<uint32_t *>(g.offsets.p),
                        reinterpret_cast<uint32_t *>(g.cursor.p), staged ? reinterpret_cast<uint32_t *>(g.coarse_offsets.p) : no_u32, fine_bits,
                        plan, p.lanes, p.L, heavy_count, add ? no_u8 : reinterpret_cast<unsigned char *>(g.bucket_sums.p));
+        }
         tm_mark("scan");
         // sort: LDS-staged two-level partition for large inputs (bursts of consecutive entries), the
         // single-level scatter otherwise (small inputs: the tile structure buys nothing there)
@@ -331,7 +339,7 @@ static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars
     tm_mark("hist");
     LAUNCH_BARRIER(k_scan_a, 1, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.counts.p), TABLE_CB, reinterpret_cast<uint32_t *>(g.block_sums.p));
     LAUNCH_BARRIER(k_scan_b, 1, 1024, 0, st, reinterpret_cast<uint32_t *>(g.block_sums.p), 1u);
-    LAUNCH_BARRIER(k_scan_c, 1, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.counts.p), TABLE_CB,
+    LAUNCH_BARRIER(k_scan_c<false>, 1, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.counts.p), TABLE_CB,
                    reinterpret_cast<const uint32_t *>(g.block_sums.p), reinterpret_cast<uint32_t *>(g.coarse_offsets.p),
                    reinterpret_cast<uint32_t *>(g.cursor.p), no_u32, 0u, no_u32, 0u, 0u, no_u32, no_u8);
     tm_mark("scan");
@@ -347,7 +355,7 @@ static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars
     const uint32_t fscan = ceil_div(TABLE_B, SCAN_TILE);
     LAUNCH_BARRIER(k_scan_a, fscan, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.fine_counts.p), TABLE_B, reinterpret_cast<uint32_t *>(g.block_sums.p));
     LAUNCH_BARRIER(k_scan_b, 1, 1024, 0, st, reinterpret_cast<uint32_t *>(g.block_sums.p), fscan);
-    LAUNCH_BARRIER(k_scan_c, fscan, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.fine_counts.p), TABLE_B,
+    LAUNCH_BARRIER(k_scan_c<false>, fscan, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.fine_counts.p), TABLE_B,
                    reinterpret_cast<const uint32_t *>(g.block_sums.p), reinterpret_cast<uint32_t *>(g.offsets.p), reinterpret_cast<uint32_t *>(g.fine_cursor.p),
                    no_u32, 0u, plan, lanes, Lmin, heavy_count, reinterpret_cast<unsigned char *>(g.bucket_sums.p));
     tm_mark("bucket_count_scan");

@@ -146,46 +146,61 @@ KERNEL void k_scan_b(uint32_t *__restrict__ block_sums, uint32_t nblocks) {
 //   plan     {L, T} of k_accumulate -- segment length chosen once the number of non-zero digits is
 //            known: exactly one segment per resident lane (every SIMD slot busy for the whole kernel
 //            and all lanes finishing together), never shorter than min_L -- and heavy_ctr cleared
+// SOLO: ONE workgroup walks all the tiles itself, carrying the running total -- for small bucket counts
+// (a commit of 2^17 pairs under 8-bit windows has 4096 buckets) one launch instead of three.
+template <bool SOLO = false>
 KERNEL void k_scan_c(const uint32_t *__restrict__ counts, uint32_t NB, const uint32_t *__restrict__ block_sums,
                      uint32_t *__restrict__ offsets, uint32_t *__restrict__ cursor, uint32_t *__restrict__ cursor1, uint32_t fine_bits,
                      uint32_t *__restrict__ plan, uint32_t resident_lanes, uint32_t min_L, uint32_t *__restrict__ heavy_ctr,
                      unsigned char *__restrict__ bucket_sums) {
-    __shared__ uint32_t buf[SCAN_BLOCK];
-    uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
-    uint32_t loc[SCAN_ITEMS], s = 0;
-    for (int k = 0; k < SCAN_ITEMS; k++) {
-        loc[k] = (base + k < NB) ? counts[base + k] : 0;
-        s += loc[k];
-    }
-    buf[threadIdx.x] = s;
-    __syncthreads();
-    for (uint32_t off = 1; off < SCAN_BLOCK; off <<= 1) {
-        uint32_t add = threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
-        __syncthreads();
-        buf[threadIdx.x] += add;
+    __shared__ uint32_t buf[SCAN_BLOCK], carry_s;
+    const uint32_t ntiles = (NB + SCAN_TILE - 1) / SCAN_TILE;
+    if (SOLO) {
+        if (threadIdx.x == 0) carry_s = 0;
         __syncthreads();
     }
-    uint32_t run = block_sums[blockIdx.x] + buf[threadIdx.x] - s;
-    for (int k = 0; k < SCAN_ITEMS; k++) {
-        if (base + k < NB) {
-            offsets[base + k] = run; cursor[base + k] = run;
-            if (cursor1 && ((base + k) & ((1u << fine_bits) - 1u)) == 0) cursor1[(base + k) >> fine_bits] = run;
-            if (bucket_sums && loc[k] == 0) {
-                uint32_t *zz = reinterpret_cast<uint32_t *>(bucket_sums + (size_t)(base + k) * XYZZ29_BYTES) + 18;
+    for (uint32_t tile = SOLO ? 0 : blockIdx.x; tile < (SOLO ? ntiles : blockIdx.x + 1); tile++) {
+        uint32_t base = tile * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+        uint32_t loc[SCAN_ITEMS], s = 0;
+        for (int k = 0; k < SCAN_ITEMS; k++) {
+            loc[k] = (base + k < NB) ? counts[base + k] : 0;
+            s += loc[k];
+        }
+        buf[threadIdx.x] = s;
+        __syncthreads();
+        for (uint32_t off = 1; off < SCAN_BLOCK; off <<= 1) {
+            uint32_t add = threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += add;
+            __syncthreads();
+        }
+        uint32_t run = (SOLO ? carry_s : block_sums[tile]) + buf[threadIdx.x] - s;
+        for (int k = 0; k < SCAN_ITEMS; k++) {
+            if (base + k < NB) {
+                offsets[base + k] = run; cursor[base + k] = run;
+                if (cursor1 && ((base + k) & ((1u << fine_bits) - 1u)) == 0) cursor1[(base + k) >> fine_bits] = run;
+                if (bucket_sums && loc[k] == 0) {
+                    uint32_t *zz = reinterpret_cast<uint32_t *>(bucket_sums + (size_t)(base + k) * XYZZ29_BYTES) + 18;
 #pragma unroll
-                for (int q = 0; q < 9; q++) zz[q] = 0;
+                    for (int q = 0; q < 9; q++) zz[q] = 0;
+                }
+            }
+            run += loc[k];
+            if (base + k == NB - 1) {
+                offsets[NB] = run;
+                if (plan) {
+                    uint32_t L = (uint32_t)(((uint64_t)run + resident_lanes - 1) / resident_lanes);
+                    if (L < min_L) L = min_L;
+                    plan[0] = L;
+                    plan[1] = (uint32_t)(((uint64_t)run + L - 1) / L);
+                    heavy_ctr[0] = 0; heavy_ctr[1] = 0;
+                }
             }
         }
-        run += loc[k];
-        if (base + k == NB - 1) {
-            offsets[NB] = run;
-            if (plan) {
-                uint32_t L = (uint32_t)(((uint64_t)run + resident_lanes - 1) / resident_lanes);
-                if (L < min_L) L = min_L;
-                plan[0] = L;
-                plan[1] = (uint32_t)(((uint64_t)run + L - 1) / L);
-                heavy_ctr[0] = 0; heavy_ctr[1] = 0;
-            }
+        if (SOLO) {
+            __syncthreads();
+            if (threadIdx.x == SCAN_BLOCK - 1) carry_s += buf[threadIdx.x];
+            __syncthreads();
         }
     }
 }

@@ -1,8 +1,10 @@
 // Host side of the cross-term evaluator (graph_kernels.cuh).  A flattened GraphEvaluator
-// (include/mira_gpu.h) is COMPILED once per circuit -- validated, its intermediates given workspace
-// slots, every value given a proven bound, the instruction stream and constants uploaded -- and the
-// handle is then evaluated for any number of (columns, challenges) pairs with one small upload and
-// one launch each.
+// (include/mira_gpu.h) is COMPILED once per circuit -- validated; constants read at their uses; products
+// folded into the sums that take them; the power of two every value carries chosen so that no column
+// has to be lifted into the multiplier's form; intermediates given workspace slots, the most used ones
+// in LDS; every value given a proven bound; the instruction stream and constants uploaded -- and the
+// handle is then evaluated for any number of (columns, challenges) pairs, alone or with the other graphs
+// of a fold step, with one small upload and one launch.
 #include "ctx.h"
 #include "graph_kernels.cuh"
 #include "host_field.hpp"

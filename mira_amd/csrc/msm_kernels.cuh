@@ -96,10 +96,20 @@ KERNEL void k_hist(const int16_t *__restrict__ digits, uint32_t n, uint32_t B, u
     __syncthreads();
     const uint32_t base = blockIdx.x * tile, end = (base + tile < n) ? base + tile : n;
     const int16_t *dw = digits + (size_t)w * n;
-    for (uint32_t i = base + threadIdx.x; i < end; i += blockDim.x) {
-        int32_t d = dw[i];
-        if (d != 0) atomicAdd(&bins[(uint32_t)(d < 0 ? -d : d) - 1], 1u);
+    auto count = [&](int32_t d) { if (d != 0) atomicAdd(&bins[(uint32_t)(d < 0 ? -d : d) - 1], 1u); };
+    // four digits per 8-byte load where the window's digits are 8-byte aligned (n a multiple of 4; tiles are
+    // multiples of 1024): a quarter of the load instructions (2-byte loads: 1.4 TB/s)
+    uint32_t i0 = base;
+    if (((reinterpret_cast<uintptr_t>(dw + base)) & 7u) == 0) {
+        const uint32_t groups = (end - base) / 4;
+        const U2 *dv = reinterpret_cast<const U2 *>(dw + base);
+        for (uint32_t q = threadIdx.x; q < groups; q += blockDim.x) {
+            const U2 v = dv[q];
+            count((int16_t)(v.x & 0xFFFFu)); count((int16_t)(v.x >> 16)); count((int16_t)(v.y & 0xFFFFu)); count((int16_t)(v.y >> 16));
+        }
+        i0 = base + groups * 4;
     }
+    for (uint32_t i = i0 + threadIdx.x; i < end; i += blockDim.x) count(dw[i]);
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) {
         uint32_t cnt = bins[b];

@@ -299,6 +299,21 @@ def test_emu_staged_sort(emu_lib, tune):
             emu_lib.check(emu_lib.c.mira_msm_set_window_bits(0))
 
 
+def test_emu_staged_sort_full_tiles(emu_lib, tune):
+    """Whole 8192-entry sort tiles beside a ragged one, and k_hist's four-digits-per-load path (taken
+    where a window's digits are 8-byte aligned: n is odd, so only every fourth window is)."""
+    tune(_lib.TUNE_STAGED_MIN_N, 1)
+    cid, n, c = 0, 8192 + 77, 12
+    key = cm.CommitmentKey.synthetic(cid, n, seed=66, lib=emu_lib)
+    bs = key.download()
+    emu_lib.check(emu_lib.c.mira_msm_set_window_bits(c))
+    try:
+        sc = C.synth_scalars(cid, n, seed=67, kind=1)
+        assert (key.commit(sc) == C.commit(cid, bs, sc)).all()
+    finally:
+        emu_lib.check(emu_lib.c.mira_msm_set_window_bits(0))
+
+
 def test_emu_host_scalars_in_chunks(emu_lib, tune):
     """Host scalars cut into point chunks (copy of one chunk beside the kernels of the previous one on
     the GPU): every chunk adds its bucket sums to those before.  Same commitments as the one-chunk

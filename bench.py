@@ -176,8 +176,11 @@ def main():
     stage_acc = {}
     sync_all()
     t0 = time.perf_counter()
+    step_walls = []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         result = step()
+        step_walls.append((time.perf_counter() - ts) * 1e3)     # a commit is synchronous: this is the step's own wall time
         for name, ms in lib.timings():
             stage_acc[name] = stage_acc.get(name, 0.0) + ms
     sync_all()
@@ -199,6 +202,7 @@ def main():
     out = {
         "metric": "bn256_g1_msm_throughput", "value": round(value, 3), "unit": "M scalar-point pairs/s",
         "n_gpus": n_gpus, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "step_ms": {"median": round(sorted(step_walls)[len(step_walls) // 2], 4), "min": round(min(step_walls), 4), "max": round(max(step_walls), 4)},   # this rank's steps; `value` is from the whole timed region
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u256 mod p (9 x 29-bit limbs in u32/u64, Montgomery)",
         "data": ("synthetic -- CPU EMULATION REHEARSAL of the launch path, not a measurement" if args.emulate else
                  "synthetic -- REHEARSAL: every rank on GPU 0, gloo exchange; not a measurement" if args.rehearse_one_gpu else "synthetic"),

@@ -178,8 +178,13 @@ KERNEL void __launch_bounds__(1024) k_ntt_lines(const unsigned char *__restrict_
                                                : tw_load<F>(line_tw + (size_t)(j << (ps.log_len - 1 - s)) * TW_BYTES);
                     v = f29_mul(v, tw);
                 }
-                L.store(i0, f29_add(u, v));
-                L.store(i1, f29_sub<3>(u, v));
+                // uncarried sums (field29.cuh, as in k_ntt_wave): v is a multiplier result or an unpacked value, so
+                // limbs grow by < 2^30 per layer; every second layer carries (an even layer leaves limbs
+                // < 1.5 * 2^30, which the next layer's product and the post-twiddle product accept)
+                Fe29<F> a2 = f29_add_nc(u, v), b2 = f29_sub_nc<3>(u, v);
+                if (s & 1u) { a2 = f29_carry(a2); b2 = f29_carry(b2); }
+                L.store(i0, a2);
+                L.store(i1, b2);
             }
             __syncthreads();
         }

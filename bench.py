@@ -220,6 +220,9 @@ def main():
                      "alu": None if t_acc <= 0 else {
                          "achieved_G_modmul_per_s": round(10 * adds_per_pair * n / (t_acc * 1e-3) / 1e9, 1), "microbench_peak_G_modmul_per_s": 171.0,
                          "frac": round(10 * adds_per_pair * n / (t_acc * 1e-3) / 1e9 / 171.0, 3),
+                         "peak_issue_derived": {"G_modmul_per_s_mads_only": round(PEAK_ISSUE_MAD_ONLY, 1), "G_modmul_per_s_all_valu": round(PEAK_ISSUE_ALL, 1),
+                                                "frac_of_all_valu": round(10 * adds_per_pair * n / (t_acc * 1e-3) / 1e9 / PEAK_ISSUE_ALL, 3),
+                                                "how": "1024 SIMDs x 64 lanes x 2.4 GHz / (162 v_mad_u64_u32 x 4.76 cyc [+ 85 other VALU x 2.08 cyc]) per f29_mul"},
                          "note": f"{adds_per_pair} mixed XYZZ additions x 10 field multiplications per pair; peak = f29_mul microbenchmark "
                                  "(profiles/r01_b_microbench_f29.txt)"},
                      "note": "integer-ALU bound (about 160 modular multiplications per pair); see DESIGN.md section 4"},
@@ -299,15 +302,28 @@ def multi_gpu_extras(lib, cm, dist, rank, n_gpus, total_log_n, args):
     return ex
 
 
-def load_traffic(log_n):
-    """HBM bytes per k_accumulate launch from the committed PMC profile (collected in a separate
-    rocprofv3 --pmc pass, corrected as MI355X_MICROARCH.md prescribes), or null."""
+def load_traffic_key(key):
+    """HBM bytes from the committed PMC profile (collected in separate rocprofv3 --pmc passes,
+    corrected as MI355X_MICROARCH.md prescribes), or null."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(f"k_accumulate_2p{log_n}")
+            return json.load(f).get(key)
     except Exception:
         return None
+
+
+def load_traffic(log_n):
+    return load_traffic_key(f"k_accumulate_2p{log_n}")
+
+
+# Issue-derived ceiling of the field multiplier: one f29_mul is 162 v_mad_u64_u32 (81 products + 81 reduction
+# products) and about 85 other VALU instructions; v_mad_u64_u32 issues once per 4.76 cycles per SIMD with all wave
+# slots full, a simple VALU instruction once per 2.08 (profiles/r01_a_microbench.txt); 1024 SIMDs x 64 lanes at
+# the 2.4 GHz maximum clock (the chip sustains about 2.1 GHz under this load: the kernel can never reach it).
+MODMUL_MADS, MODMUL_OTHER, MAD_CYC, VALU_CYC, MAX_CLOCK_GHZ = 162, 85, 4.76, 2.08, 2.4
+PEAK_ISSUE_MAD_ONLY = 1024 * 64 * MAX_CLOCK_GHZ / (MODMUL_MADS * MAD_CYC)
+PEAK_ISSUE_ALL = 1024 * 64 * MAX_CLOCK_GHZ / (MODMUL_MADS * MAD_CYC + MODMUL_OTHER * VALU_CYC)
 
 
 def cpu_baseline_msm(lib, cm, key, d_scalars, n, window_bits):
@@ -356,11 +372,15 @@ def extras(lib, cm, with_cpu):
         dt = sorted(walls)[reps // 2]
         acc = {a: sorted(b)[len(b) // 2] for a, b in acc.items()}
         lib.check(lib.c.mira_set_timing(0))
-        kern = acc.get("ntt_pass1", 0) + acc.get("ntt_pass2", 0)
+        passes = sorted(a for a in acc if a.startswith("ntt_pass") or a == "ntt_single")
+        kern = sum(acc[a] for a in passes)                         # EVERY butterfly pass of the transform (2^24: three)
         ex["ntt_2p24"] = {"ms": round(dt * 1e3, 3), "M_elements_per_s": round(n / dt / 1e6, 2), "stages_ms": {a: round(b, 4) for a, b in acc.items()},
-                          "roofline": {"bound": "hbm", "achieved": round(NTT_BYTES_PER_ELEM * n / (kern * 1e-3) / 1e9, 2) if kern else None,
+                          "roofline": {"bound": "hbm", "kernel": "k_ntt_wave", "passes": len(passes), "kernel_ms_all_passes": round(kern, 4),
+                                       "achieved": round(NTT_BYTES_PER_ELEM * n / (kern * 1e-3) / 1e9, 2) if kern else None,
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                       "frac": round(NTT_BYTES_PER_ELEM * n / (kern * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if kern else None}}
+                                       "frac": round(NTT_BYTES_PER_ELEM * n / (kern * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if kern else None,
+                                       "algorithmic_bytes": NTT_BYTES_PER_ELEM * n, "traffic": load_traffic_key("ntt_2p24"),
+                                       "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes on the builder's box, all passes of one transform), not this run"}}
         if with_cpu:
             from oracle import cref as C
             ks = 20

@@ -78,8 +78,10 @@ template <class F> HD void xyzz29_add_affine(Xyzz29<F> &acc, const Aff29<F> &q) 
     Fe29<F> qq = f29_mul(acc.x, pp);                            // 18
     Fe29<F> x3 = f29_sub_b_2c<7>(f29_sqr(r), ppp, qq);                     // 64 ; PPP + 2Q < 6 -> X3 < 9
     // R (Q - X3) - Y1 PPP in one reduction: 8 * 12 + 7 * 2 = 110 -> Y3 < 2.  -Y1 without a carry pass
-    // (Y1 is a multiplier result or an unpacked value: limbs 0..7 <= 2^29 - 1): its limbs stay below
-    // 2^30, and the shared columns hold 9 * 2^58 (R, Q - X3 carried) + 9 * 2^59 + the reduction's 9 * 2^58 < 2^64
+    // (Y1 is a multiplier result, an unpacked value or -- a bucket sum the fix-up wrote, k_accumulate<F, true> --
+    // a carried one: limbs 0..7 < 2^29 + 8, which f29_sub_nc's bias covers, static_assert there): its limbs stay
+    // below 2^30 + 8, and the shared columns hold 9 * 2^58 (R, Q - X3 carried) + 9 * (2^30 + 8) (2^29 + 8) + the
+    // reduction's 9 * 2^58 < 2^64 (the test build checks the columns of every call)
     Fe29<F> y3 = f29_mul2_add(r, f29_sub<10>(qq, x3), f29_sub_nc<7>(f29_zero<F>(), acc.y), ppp);
     acc.x = x3; acc.y = y3;
     acc.zz = f29_mul(acc.zz, pp);

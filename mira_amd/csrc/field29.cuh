@@ -157,27 +157,33 @@ template <class F> HD Fe29<F> f29_add_nc(const Fe29<F> &a, const Fe29<F> &b) {
     F29_ASSERT(F29_GET(r) <= 40.0);
     return r;
 }
-// K * P with limbs 0..7 raised by 2^29 (borrowed as 1 from the next limb): dominates, limb by limb,
-// any subtrahend < K P whose limbs 0..7 are below 2^29 -- a multiplier result or an unpacked value.
-template <class F, int K> struct F29BiasTight {
+// K * P with limbs 0..7 raised by RAISE * 2^29 (borrowed as RAISE from the next limb): dominates, limb by
+// limb, any subtrahend < K P whose limbs 0..7 are below RAISE * 2^29 + 8 -- RAISE = 1: a multiplier result, an
+// unpacked value or a carried one (limbs < 2^29 + 8); RAISE = 2: the uncarried sum of two of those.  `ok` states
+// what that needs of the modulus: every limb of K P at least 8 (so that the borrow never wraps and a carried
+// subtrahend's excess of up to 7 is covered); checked where the bias is used.
+template <class F, int K, int RAISE = 1> struct F29BiasTight {
     uint32_t l[9];
-    constexpr F29BiasTight() : l{} {
+    bool ok;
+    constexpr F29BiasTight() : l{}, ok(true) {
         uint64_t carry = 0;
         for (int i = 0; i < 9; i++) {
             uint64_t v = (uint64_t)K * F::P[i] + carry;
             l[i] = (i < 8) ? (uint32_t)(v & M29) : (uint32_t)v;
             carry = v >> 29;
+            if (l[i] < 8u) ok = false;
         }
         for (int i = 0; i < 8; i++) {
-            l[i] += 0x20000000u;
-            l[i + 1] -= 1;
+            l[i] += (uint32_t)RAISE * 0x20000000u;
+            l[i + 1] -= (uint32_t)RAISE;
         }
     }
 };
-// a - b + K P without a carry pass.  Requires b < (K - 1) P with limbs 0..7 <= 2^29 - 1 (straight
-// from f29_mul or f29_unpack); limbs of the result < limbs of a + 2^30.
-template <int K, class F> HD Fe29<F> f29_sub_nc(const Fe29<F> &a, const Fe29<F> &b) {
-    constexpr F29BiasTight<F, K> bias{};
+// a - b + K P without a carry pass.  Requires b < (K - 1) P with limbs 0..7 < RAISE * 2^29 + 8 (RAISE = 1:
+// straight from f29_mul or f29_unpack, or carried); limbs of the result < limbs of a + (RAISE + 1) 2^29.
+template <int K, class F, int RAISE = 1> HD Fe29<F> f29_sub_nc(const Fe29<F> &a, const Fe29<F> &b) {
+    constexpr F29BiasTight<F, K, RAISE> bias{};
+    static_assert(bias.ok, "a limb of K * P is too small for this bias");
     Fe29<F> r;
 #pragma unroll
     for (int i = 0; i < 9; i++) {

@@ -244,7 +244,8 @@ HD uint32_t nttw_pos(uint32_t lane, uint32_t r, uint32_t t) {
     const uint32_t sh = 2 * t;
     return ((lane >> sh) << (sh + 2)) | (r << sh) | (lane & ((1u << sh) - 1u));
 }
-// one DIT butterfly: (u, v) -> (u + w v, u - w v); bound(u), bound(v) <= b on entry, <= b + 3 on exit.
+// one DIT butterfly: (u, v) -> (u + w v, u - w v); bound(u), bound(v) <= b on entry, <= b + 3 on exit
+// (round 0 ends one higher: nttw_bfly_one2).
 // No carry pass (field29.cuh, f29_add_nc / f29_sub_nc): the limbs of u grow by < 2^30 per layer.  A
 // round is two layers on values that enter carried (limbs < 2^29 + 8: from f29_unpack or f29_carry), so
 // the second layer multiplies limbs < 1.5 * 2^30 and leaves limbs < 2.5 * 2^30 + 8 -- inside the 32-bit
@@ -262,6 +263,14 @@ template <class F> DEV void nttw_bfly(Fe29<F> &u, Fe29<F> &v, const uint32_t *tw
 template <class F> DEV void nttw_bfly_one(Fe29<F> &u, Fe29<F> &v) {    // w = 1 (layer 0 of every line: v is an unpacked value < 2 P)
     const Fe29<F> t = v;
     v = f29_sub_nc<3>(u, t);
+    u = f29_add_nc(u, t);
+}
+// w = 1 again: the butterflies of layer 1 whose position has p mod 2 = 0 (omega^0).  v = the uncarried sum of
+// two unpacked values out of layer 0 (bound 4, limbs < 2^30): the bias is raised by 2^30 per limb.  Bounds on
+// exit: u <= 8, v <= 9 (with the product: 6 and 7); limbs < 2^31, inside what f29_carry and the multiplier take.
+template <class F> DEV void nttw_bfly_one2(Fe29<F> &u, Fe29<F> &v) {
+    const Fe29<F> t = v;
+    v = f29_sub_nc<5, F, 2>(u, t);
     u = f29_add_nc(u, t);
 }
 
@@ -375,7 +384,10 @@ KERNEL void __launch_bounds__(64 * NTTW_WAVES) __attribute__((amdgpu_waves_per_e
     };
     // (a register prefetch of the next group's elements was measured: no gain -- the other waves of
     // the SIMD already cover the strided loads; nor did a fourth wave per SIMD, eight-wave workgroups at 128 VGPRs)
-    U4 *tile = reinterpret_cast<U4 *>(lds);                        // 32 KiB, aliases the exchange planes
+    // ALIASING INVARIANT: `tile` (32 KiB) lies over the exchange planes X of all four waves.  Every transition
+    // between a tile phase (fill / take, give / drain) and an exchange phase (put / get of ANY wave) is therefore
+    // separated by a workgroup barrier, including the one from the last round of group g to the fill of group g + 1.
+    U4 *tile = reinterpret_cast<U4 *>(lds);
     const uint32_t row0 = wv << log_lpw;                           // this wave's first row of the tile
     for (uint32_t idx = blockIdx.x; idx < nbg; idx += gridDim.x) {
         const uint32_t line0 = first_line(idx), line_blk0 = line0 - row0;
@@ -395,7 +407,7 @@ KERNEL void __launch_bounds__(64 * NTTW_WAVES) __attribute__((amdgpu_waves_per_e
                 nttw_put(X, f29_carry(x0), nttw_slot(nttw_pos(lane, 0, t - 1))); nttw_put(X, f29_carry(x1), nttw_slot(nttw_pos(lane, 1, t - 1)));
                 nttw_put(X, f29_carry(x2), nttw_slot(nttw_pos(lane, 2, t - 1))); nttw_put(X, f29_carry(x3), nttw_slot(nttw_pos(lane, 3, t - 1)));
                 WAVE_SYNC();
-                const double bound = 2.0 + 6.0 * t;
+                const double bound = 3.0 + 6.0 * t;                // + 3 per layer, + 1 for the product-free butterfly of layer 1
                 nttw_get(X, x0, nttw_slot(nttw_pos(lane, 0, t)), bound); nttw_get(X, x1, nttw_slot(nttw_pos(lane, 1, t)), bound);
                 nttw_get(X, x2, nttw_slot(nttw_pos(lane, 2, t)), bound); nttw_get(X, x3, nttw_slot(nttw_pos(lane, 3, t)), bound);
                 WAVE_SYNC();
@@ -410,7 +422,8 @@ KERNEL void __launch_bounds__(64 * NTTW_WAVES) __attribute__((amdgpu_waves_per_e
                 nttw_bfly(x2, x3, tw);
             }
             if (s + 1 < m) {                                       // layer s + 1: p mod 2^(s+1) = j + (r & 1) 2^s
-                nttw_bfly(x0, x2, TW + (size_t)(j << (m - 2 - s)) * 9);
+                if (s == 0) nttw_bfly_one2(x0, x2);                // j = 0 in every lane: omega^0, no product
+                else nttw_bfly(x0, x2, TW + (size_t)(j << (m - 2 - s)) * 9);
                 nttw_bfly(x1, x3, TW + (size_t)((j + (1u << s)) << (m - 2 - s)) * 9);
             }
         }
@@ -425,6 +438,9 @@ KERNEL void __launch_bounds__(64 * NTTW_WAVES) __attribute__((amdgpu_waves_per_e
         } else {
             io.store(line0, nttw_pos(lane, 0, tl), x0); io.store(line0, nttw_pos(lane, 1, tl), x1);
             io.store(line0, nttw_pos(lane, 2, tl), x2); io.store(line0, nttw_pos(lane, 3, tl), x3);
+            // `tile` aliases the exchange planes of ALL four waves: the next group's tile_fill must not start
+            // while a slower wave is still between nttw_put and nttw_get (control flow is block-uniform)
+            if (COOP & 1) __syncthreads();
         }
     }
 }

@@ -1,5 +1,6 @@
 #!/bin/bash
-# Development: PMC passes over the 2^24 NTT, wave-level kernel (k_ntt_wave) or, with a second
+# Development: PMC passes over the 2^24 NTT (FETCH_SIZE and WRITE_SIZE: tools/gpu_profile_all.sh, in passes of their own --
+# together they exceed the TCC counter slots and rocprofv3 aborts the process, error 38), wave-level kernel (k_ntt_wave) or, with a second
 # argument 0, the workgroup-level one.  usage: tools/gpu_pmc_ntt2.sh <tag> [wave]
 tag=${1:-x}
 export TMPDIR=/tmp
@@ -9,7 +10,6 @@ i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS GRBM_GUI_ACTIVE" \
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
-           "FETCH_SIZE WRITE_SIZE" \
            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
            "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" \
            "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do

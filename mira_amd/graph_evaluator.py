@@ -40,69 +40,8 @@ def to_montgomery(values, field):
     return out
 
 
-# ---------------------------------------------------------------- Expression (expression.rs:112-120)
-class Expression:
-    def to_tuple(self):
-        """Neutral nested-tuple form (what the test oracle evaluates)."""
-        raise NotImplementedError
-
-
-class Constant(Expression):
-    def __init__(self, value):
-        self.value = int(value)
-
-    def to_tuple(self):
-        return ("const", self.value)
-
-
-class Polynomial(Expression):
-    """A column query: `index` into selectors | fixed | advice, `rotation` relative to the row."""
-
-    def __init__(self, index, rotation=0):
-        self.index, self.rotation = int(index), int(rotation)
-
-    def to_tuple(self):
-        return ("poly", self.index, self.rotation)
-
-
-class Challenge(Expression):
-    def __init__(self, index):
-        self.index = int(index)
-
-    def to_tuple(self):
-        return ("chal", self.index)
-
-
-class Negated(Expression):
-    def __init__(self, a):
-        self.a = a
-
-    def to_tuple(self):
-        return ("neg", self.a.to_tuple())
-
-
-class Sum(Expression):
-    def __init__(self, a, b):
-        self.a, self.b = a, b
-
-    def to_tuple(self):
-        return ("sum", self.a.to_tuple(), self.b.to_tuple())
-
-
-class Product(Expression):
-    def __init__(self, a, b):
-        self.a, self.b = a, b
-
-    def to_tuple(self):
-        return ("prod", self.a.to_tuple(), self.b.to_tuple())
-
-
-class Scaled(Expression):
-    def __init__(self, a, factor):
-        self.a, self.factor = a, int(factor)
-
-    def to_tuple(self):
-        return ("scaled", self.a.to_tuple(), self.factor)
+# Expression, Query and their transformations live in expression.py (re-exported here: the graph is built from them)
+from .expression import Challenge, Constant, Expression, Negated, Polynomial, Product, Scaled, Sum   # noqa: E402,F401
 
 
 # ---------------------------------------------------------------- GraphEvaluator

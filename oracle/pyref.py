@@ -19,6 +19,9 @@ What is restated, with the reference lines each function follows
 * concatenate_with_padding    src/util.rs:189-193
 * cross-term evaluation       src/polynomial/expression.rs:112-120 evaluated directly (eval_expression),
                               src/plonk/eval.rs:152-206 (plonk_advice_location)
+* cross-term expressions      src/plonk/util.rs:97-117 (compress_expression), src/polynomial/expression.rs:233-260,
+                              356-430 (fold_transform, homogeneous), src/polynomial/grouped_poly.rs:88-285 (GroupedPoly),
+                              src/main_gate.rs:543-589 (the MainGate<T> gate) -- PINNED by the reference's Display tests
 * ProtoGalaxy polynomials     src/nifs/protogalaxy/poly/mod.rs:66-179, 218-303, 339-382,
                               folded_trace.rs, src/polynomial/lagrange.rs (pg_*)
 
@@ -238,6 +241,220 @@ def eval_expression(expr, getter, row, num_rows, mod):
     if kind == "scaled":
         return eval_expression(expr[1], getter, row, num_rows, mod) * expr[2] % mod
     raise ValueError(kind)
+
+
+# ---------------------------------------------------------------- from the gates to the cross-term expressions
+# The symbolic pipeline behind commit_cross_terms' graphs (src/nifs/vanilla/mod.rs:100-104:
+# S.custom_gates_lookup_compressed.grouped().iter_from_first()), restated on the nested tuples above -- an
+# implementation independent of the product-side mirror (mira_amd/expression.py, grouped_poly.py, main_gate.py),
+# which the tests compare with it node for node.  Pinned by the reference's own `Display` tests
+# (src/polynomial/expression.rs:528-606, src/polynomial/grouped_poly.rs:287-461; tests/golden/ref_kats.json).
+# ctx = dict(num_selectors, num_fixed, num_advice, num_challenges, num_lookups)   (QueryIndexContext, expression.rs:38-67)
+def _e_sum(a, b): return ("sum", a, b)
+def _e_prod(a, b): return ("prod", a, b)
+def _e_neg(a): return ("neg", a)
+
+
+def expr_to_string(e):
+    """`impl Display for Expression` = visualize, src/polynomial/expression.rs:262-301; constants through
+    trim_leading_zeros (src/util.rs:160-164: zero prints as `0x`)."""
+    hx = lambda v: "0x" + format(v, "x").lstrip("0")
+    k = e[0]
+    if k == "const":
+        return hx(e[1])
+    if k == "poly":
+        return f"Z_{e[1]}" + ("" if e[2] == 0 else f"[{e[2]}]" if e[2] < 0 else f"[+{e[2]}]")
+    if k == "chal":
+        return f"r_{e[1]}"
+    if k == "neg":
+        return "-" + expr_to_string(e[1])
+    if k == "sum":
+        return expr_to_string(e[1]) + (" - " + expr_to_string(e[2][1]) if e[2][0] == "neg" else " + " + expr_to_string(e[2]))
+    if k == "prod":
+        side = lambda x: "(" + expr_to_string(x) + ")" if x[0] == "sum" else expr_to_string(x)
+        return side(e[1]) + " * " + side(e[2])
+    if k == "scaled":
+        return '"' + hx(e[2]) + '" * ' + expr_to_string(e[1])
+    raise ValueError(k)
+
+
+def expr_challenges(e):
+    """the distinct challenge indices of an expression (num_challenges = their count, expression.rs:160-184)"""
+    if e[0] == "chal":
+        return {e[1]}
+    if e[0] in ("const", "poly"):
+        return set()
+    return set().union(*[expr_challenges(x) for x in e[1:] if isinstance(x, tuple)])
+
+
+def query_is_folded(index, ctx):
+    """Query::subtype is Advice or Lookup (expression.rs:83-100): the variables that carry degree and get folded"""
+    lo = ctx["num_selectors"] + ctx["num_fixed"]
+    assert index < lo + ctx["num_advice"] + 5 * ctx["num_lookups"], "unknown index"
+    return index >= lo
+
+
+def challenge_in_degree(index, degree):
+    """expression.rs:501-513"""
+    r = ("chal", index)
+    for _ in range(2, degree + 1):
+        r = _e_prod(r, ("chal", index))
+    return r
+
+
+def expr_homogeneous(e, ctx):
+    """Expression::homogeneous, expression.rs:356-430 -> (expression, degree)"""
+    u = ctx["num_challenges"]
+    k = e[0]
+    if k == "const":
+        return e, 0
+    if k == "poly":
+        return e, 1 if query_is_folded(e[1], ctx) else 0
+    if k == "chal":
+        return e, 1
+    if k == "neg":
+        x, d = expr_homogeneous(e[1], ctx)
+        return _e_neg(x), d
+    if k == "sum":
+        (l, ld), (r, rd) = expr_homogeneous(e[1], ctx), expr_homogeneous(e[2], ctx)
+        if ld > rd:
+            return _e_sum(l, _e_prod(r, challenge_in_degree(u, ld - rd))), ld
+        if ld < rd:
+            return _e_sum(_e_prod(l, challenge_in_degree(u, rd - ld)), r), rd
+        return _e_sum(l, r), ld
+    if k == "prod":
+        (l, ld), (r, rd) = expr_homogeneous(e[1], ctx), expr_homogeneous(e[2], ctx)
+        return _e_prod(l, r), ld + rd
+    if k == "scaled":
+        x, d = expr_homogeneous(e[1], ctx)
+        return ("scaled", x, e[2]), d
+    raise ValueError(k)
+
+
+def expr_fold_transform(e, mm, nn):
+    """Expression::fold_transform, expression.rs:233-260: x_i -> x_i + r y_i for the columns from mm on and for
+    every challenge, r = Challenge(2 * num_challenges)"""
+    nc = len(expr_challenges(e))
+    r = ("chal", 2 * nc)
+
+    def go(x):
+        k = x[0]
+        if k == "const":
+            return x
+        if k == "poly":
+            return x if x[1] < mm else _e_sum(x, _e_prod(r, ("poly", x[1] + nn, x[2])))
+        if k == "chal":
+            return _e_sum(x, _e_prod(r, ("chal", x[1] + nc)))
+        if k == "neg":
+            return _e_neg(go(x[1]))
+        if k == "sum":
+            return _e_sum(go(x[1]), go(x[2]))
+        if k == "prod":
+            return _e_prod(go(x[1]), go(x[2]))
+        return ("scaled", go(x[1]), x[2])
+    return go(e)
+
+
+# GroupedPoly (src/polynomial/grouped_poly.rs): a list, entry k = coefficient of X^k or None
+def grouped_from(pairs):
+    """`impl From<(degree, expr) pairs>`, grouped_poly.rs:46-62"""
+    t = []
+    for d, x in (pairs.items() if isinstance(pairs, dict) else pairs):
+        t.extend([None] * (d + 1 - len(t)))
+        t[d] = x
+    return t
+
+
+def _grouped_zip(a, b, f):                       # impl_poly_ops!, grouped_poly.rs:171-201
+    out = []
+    for i in range(max(len(a), len(b))):
+        l, r = (a[i] if i < len(a) else None), (b[i] if i < len(b) else None)
+        out.append(_e_sum(l, f(r)) if l is not None and r is not None else f(r) if r is not None else l)
+    return out
+
+
+def grouped_add(a, b): return _grouped_zip(a, b, lambda x: x)
+def grouped_sub(a, b): return _grouped_zip(a, b, _e_neg)
+def grouped_neg(a): return [None if x is None else _e_neg(x) for x in a]                        # :272-285
+def grouped_scale(a, k): return [None if x is None else _e_prod(("const", k), x) for x in a]    # Mul<&F>, :203-219
+
+
+def grouped_mul(a, b):
+    """grouped_poly.rs:221-270: the longer operand (the right one on a tie) outside, both from the top degree down"""
+    lhs, rhs = (b, a) if len(a) <= len(b) else (a, b)
+    res = []
+    for ld in range(len(lhs) - 1, -1, -1):
+        if lhs[ld] is None:
+            continue
+        for rd in range(len(rhs) - 1, -1, -1):
+            if rhs[rd] is None:
+                continue
+            d, x = ld + rd, _e_prod(lhs[ld], rhs[rd])
+            res.extend([None] * (d + 1 - len(res)))
+            res[d] = x if res[d] is None else _e_sum(res[d], x)
+    return res
+
+
+def grouped_new(e, ctx):
+    """GroupedPoly::new, grouped_poly.rs:88-140"""
+    k = e[0]
+    if k == "const":
+        return [e]
+    if k == "poly":
+        shift = ctx["num_advice"] + 5 * ctx["num_lookups"]               # num_fold_vars: shift_advice_index == shift_lookup_index
+        return [e, ("poly", e[1] + shift, e[2])] if query_is_folded(e[1], ctx) else [e]
+    if k == "chal":
+        return [e, ("chal", e[1] + ctx["num_challenges"])]
+    if k == "neg":
+        return grouped_neg(grouped_new(e[1], ctx))
+    if k == "sum":
+        return grouped_add(grouped_new(e[1], ctx), grouped_new(e[2], ctx))
+    if k == "prod":
+        return grouped_mul(grouped_new(e[1], ctx), grouped_new(e[2], ctx))
+    if k == "scaled":
+        return grouped_scale(grouped_new(e[1], ctx), e[2])
+    raise ValueError(k)
+
+
+def compress_expression(exprs, challenge_index):
+    """src/plonk/util.rs:97-117"""
+    if len(exprs) > 1:
+        acc = ("const", 0)
+        for x in exprs:
+            acc = _e_sum(x, _e_prod(acc, ("chal", challenge_index)))
+        return acc
+    return exprs[0] if exprs else ("const", 0)
+
+
+def compressed_gates(exprs, ctx):
+    """CompressedGates::new, src/plonk/mod.rs:92-122 -> dict(compressed, homogeneous, degree, grouped, ctx);
+    ctx is a copy updated as the reference updates it"""
+    ctx = dict(ctx)
+    compressed = compress_expression(exprs, ctx["num_challenges"])
+    ctx["num_challenges"] = len(expr_challenges(compressed))
+    homogeneous, degree = expr_homogeneous(compressed, ctx)
+    ctx["num_challenges"] = len(expr_challenges(homogeneous))
+    return dict(compressed=compressed, homogeneous=homogeneous, degree=degree, grouped=grouped_new(homogeneous, ctx), ctx=ctx)
+
+
+def main_gate_polynomial(T, num_selectors, num_fixed, first_fixed, first_advice):
+    """The gate MainGate::<F, T>::configure creates (src/main_gate.rs:543-589) after Expression::from_halo2_expr
+    (src/polynomial/expression.rs:303-341): columns in allocation order -- advice state[T], input, out; fixed
+    q_1[T], q_5[T], q_m[2], q_i, q_o, rc.
+        init = q_m[0] s0 s1 + q_i input + rc + q_o out;  T >= 4: init = q_m[1] s2 s3 + init
+        fold(init, + (q_1[i] s_i + q_5[i] (s_i^2 s_i^2) s_i))"""
+    fx = lambda c: ("poly", num_selectors + first_fixed + c, 0)
+    ad = lambda c: ("poly", num_selectors + num_fixed + first_advice + c, 0)
+    st = [ad(i) for i in range(T)]
+    q_1, q_5 = [fx(i) for i in range(T)], [fx(T + i) for i in range(T)]
+    q_m, q_i, q_o, rc = [fx(2 * T), fx(2 * T + 1)], fx(2 * T + 2), fx(2 * T + 3), fx(2 * T + 4)
+    acc = _e_sum(_e_sum(_e_sum(_e_prod(_e_prod(q_m[0], st[0]), st[1]), _e_prod(q_i, ad(T))), rc), _e_prod(q_o, ad(T + 1)))
+    if T >= 4:
+        acc = _e_sum(_e_prod(_e_prod(q_m[1], st[2]), st[3]), acc)
+    for i in range(T):
+        v2 = _e_prod(st[i], st[i])
+        acc = _e_sum(acc, _e_sum(_e_prod(q_1[i], st[i]), _e_prod(q_5[i], _e_prod(_e_prod(v2, v2), st[i]))))
+    return acc
 
 
 # ----------------------------------------------------------------------------- NTT

@@ -620,119 +620,105 @@ def extras(lib, cm, with_cpu):
         ex["fold_step_k17"] = {"error": repr(e)}
 
     # ---- cross-term evaluation at k = 17 --------------------------------
-    # a synthetic degree-5 gate (eight shared x^5 S-boxes mixed by an 8 x 8 matrix, selector-gated,
-    # one rotated query per output, challenge-combined): 5 cross-term-sized graphs over 2^17 rows,
-    # the step that feeds the cross-term commits above
+    # The reference's own graphs: S.custom_gates_lookup_compressed.grouped().iter_from_first()
+    # (src/nifs/vanilla/mod.rs:100-104) for the circuits of an IVC step -- the MainGate<5> gate
+    # (src/main_gate.rs:543-589), homogenised and grouped by the power of the folding variable
+    # (mira_amd/main_gate.py, expression.py, grouped_poly.py; pinned by the reference's Display tests).
+    # Primary circuit (BN256 scalars): two gates compressed with a challenge, degree 6, 6 cross terms over
+    # 30 fixed + 2 x 14 advice columns.  Secondary (Grumpkin scalars): one gate, degree 5, 5 cross terms
+    # over 15 fixed + 2 x 7 advice columns.  2^17 rows each; outputs stay in HBM for the commits.
     try:
         from mira_amd import graph_evaluator as G
-        k, nadv = 17, 8
+        from mira_amd import main_gate as MG
+        k = 17
         n = 1 << k
-        d_cols = cm.synth_scalars_device(cm.CURVE_BN256, (nadv + 2) * n, seed=0x3000)
-        sel = np.ones(n, dtype=np.uint8); sel[::7] = 0
-        d_sel = lib.alloc(n); lib.upload(d_sel, sel)
-        cols = [(d_sel, G.COL_BOOL)] + [(d_cols + j * n * 32, G.COL_FIELD) for j in range(nadv + 2)]
-        chal = [0x1234567 + 977 * j for j in range(2)]
-
-        def gate(shift):
-            sbox = []
-            for i in range(nadv):
-                x = G.Sum(G.Polynomial(3 + i), G.Constant(1000 + i + shift))
-                x2 = G.Product(x, x)
-                sbox.append(G.Product(G.Product(x2, x2), x))
-            e = None
-            for j in range(nadv):
-                acc = None
-                for i in range(nadv):
-                    t = G.Scaled(sbox[i], 17 * j + 3 * i + 2 + shift)
-                    acc = t if acc is None else G.Sum(acc, t)
-                row = G.Product(G.Polynomial(0), G.Sum(acc, G.Negated(G.Polynomial(3 + j, 1))))
-                e = row if e is None else G.Sum(G.Product(e, G.Challenge(j % 2)), row)
-            return G.Sum(e, G.Product(G.Polynomial(1), G.Polynomial(2, -1)))
-        evs = [G.GraphEvaluator.new(gate(s), G.FIELD_FR) for s in range(5)]
-        d_out = lib.alloc(5 * n * 32)
-        run = lambda: G.GraphEvaluator.evaluate_batch_device(evs, cols, chal, n, [d_out + i * n * 32 for i in range(5)])     # one mira_graph_eval_batch
-        walls = []
-        for _ in range(7):                       # median: see the NTT leg
-            t0 = time.perf_counter(); run(); walls.append((time.perf_counter() - t0) * 1e3)
-        wall = sorted(walls)[3]
-        lib.check(lib.c.mira_set_timing(1))
-        kerns = []
-        for _ in range(5):
-            evs[0].evaluate_device(cols, chal, n, d_out=d_out)
-            kerns.append(dict(lib.timings())["graph_eval"])
-        kern = sorted(kerns)[2]
-        lib.check(lib.c.mira_set_timing(0))
-        ncalc = sum(ev.num_intermediates for ev in evs)
-        ex["cross_term_eval_k17"] = {"graphs": 5, "rows": n, "calculations": ncalc, "ms": round(wall, 3), "kernel_ms_one_graph": round(kern, 4),
-                                     "G_calculations_per_s": round(ncalc * n / wall / 1e6, 2),
-                                     "note": "synthetic degree-5 gate; outputs stay in HBM for the batched commit"}
-        if with_cpu:
-            from oracle import cref as C
-            host_cols = [sel] + [lib.download(d_cols + j * n * 32, (n, 4)) for j in range(nadv + 2)]
-            chal_m = G.to_montgomery(chal, G.FIELD_FR)
-            t0 = time.perf_counter()
-            want = []
+        res = {}
+        for name, c, gates, field in (("primary_bn256", cm.CURVE_BN256, 2, G.FIELD_FR), ("secondary_grumpkin", cm.CURVE_GRUMPKIN, 1, G.FIELD_FQ)):
+            cg, ctx = MG.compressed_circuit(5, gates)
+            evs = [G.GraphEvaluator.new(t, field) for t in cg.grouped.iter_from_first()]
+            d_fix = cm.synth_scalars_device(c, ctx.num_fixed * n, seed=0x3000 + c)
+            d_w1 = cm.synth_scalars_device(c, ctx.num_advice * n, seed=0x3100 + c)
+            d_w2 = cm.synth_scalars_device(c, ctx.num_advice * n, seed=0x3200 + c, kind=1)
+            chal = [(0x1234567 + 977 * j) ** 7 % G.MODULUS[field] for j in range(2 * ctx.num_challenges)]
+            dom = G.PlonkEvalDomain(ctx.num_advice, 0, chal, [], [d_fix + j * n * 32 for j in range(ctx.num_fixed)],
+                                    [(d_w1, ctx.num_advice * n)], [(d_w2, ctx.num_advice * n)], n)
+            cols = dom.columns()
+            d_out = lib.alloc(len(evs) * n * 32)
+            run = lambda: G.GraphEvaluator.evaluate_batch_device(evs, cols, chal, n, [d_out + i * n * 32 for i in range(len(evs))])     # one mira_graph_eval_batch
+            run()
+            walls = []
+            for _ in range(7):                       # median: see the NTT leg
+                t0 = time.perf_counter(); run(); walls.append((time.perf_counter() - t0) * 1e3)
+            wall = sorted(walls)[3]
+            lib.check(lib.c.mira_set_timing(1))
+            kerns = []
             for ev in evs:
-                code, consts, rots = ev.flatten()
-                want.append(C.graph_eval(1, code, ev.num_intermediates, consts, rots, host_cols, chal_m, n))
-            dtc = (time.perf_counter() - t0) * 1e3
-            got = lib.download(d_out, (5, n, 4))
-            ex["cross_term_eval_k17"].update({"cpu_ms": round(dtc, 1), "cpu_cores": C.num_threads(), "cpu_kind": "port",
-                                              "bit_exact_all_rows": bool(all((got[i] == want[i]).all() for i in range(5)))})
-        for p in (d_cols, d_sel, d_out):
-            lib.free(p)
+                ev.evaluate_device(cols, chal, n, d_out=d_out)
+                ev.evaluate_device(cols, chal, n, d_out=d_out)
+                kerns.append(round(dict(lib.timings())["graph_eval"], 4))
+            lib.check(lib.c.mira_set_timing(0))
+            run()
+            ncalc = [ev.num_intermediates for ev in evs]
+            res[name] = {"gates": gates, "degree": cg.degree, "graphs": len(evs), "rows": n, "fixed_columns": ctx.num_fixed, "advice_columns": ctx.num_advice,
+                         "calculations_per_graph": ncalc, "ms": round(wall, 3), "kernel_ms_per_graph_alone": kerns,
+                         "G_calculations_per_s": round(sum(ncalc) * n / wall / 1e6, 2)}
+            if with_cpu:
+                from oracle import cref as C
+                host_cols = list(lib.download(d_fix, (ctx.num_fixed, n, 4))) + list(lib.download(d_w1, (ctx.num_advice, n, 4))) + list(lib.download(d_w2, (ctx.num_advice, n, 4)))
+                chal_m = G.to_montgomery(chal, field)
+                fo = C.FIELD_FR if field == G.FIELD_FR else C.FIELD_FQ
+                t0 = time.perf_counter()
+                want = []
+                for ev in evs:
+                    code, consts, rots = ev.flatten()
+                    want.append(C.graph_eval(fo, code, ev.num_intermediates, consts, rots, host_cols, chal_m, n))
+                dtc = (time.perf_counter() - t0) * 1e3
+                got = lib.download(d_out, (len(evs), n, 4))
+                res[name].update({"cpu_ms": round(dtc, 1), "cpu_cores": C.num_threads(), "cpu_kind": "port",
+                                  "bit_exact_all_rows": bool(all((got[i] == want[i]).all() for i in range(len(evs))))})
+            for p in (d_fix, d_w1, d_w2, d_out):
+                lib.free(p)
+        res["ms"] = round(res["primary_bn256"]["ms"] + res["secondary_grumpkin"]["ms"], 3)
+        res["note"] = ("the reference's cross-term graphs of the MainGate<5> circuits (grouped terms 1..d of the homogenised, challenge-compressed gate), "
+                       "one batched submission per circuit; outputs stay in HBM for the batched commit")
+        ex["cross_term_eval_k17"] = res
     except Exception as e:
-        ex["cross_term_eval_k17"] = {"error": repr(e)}
+        import traceback
+        ex["cross_term_eval_k17"] = {"error": repr(e), "trace": traceback.format_exc()[-600:]}
 
     # ---- one NIFS fold step at k = 17, the whole device-resident chain (BASELINE configs[3]) -------
     # per curve, in the reference's order: generate_plonk_trace's witness commit
-    # (src/plonk/mod.rs:680-688) -> commit_cross_terms = row-wise evaluation of the d - 1 cross-term
+    # (src/plonk/mod.rs:680-688) -> commit_cross_terms = row-wise evaluation of the d cross-term
     # graphs + their commits (src/nifs/vanilla/mod.rs:100-127) -> RelaxedPlonkWitness::fold (W and E,
     # src/plonk/mod.rs:1097-1134) -> the commitment side of RelaxedPlonkInstance::fold (:986-999,
-    # 1049-1053).  Primary: BN256, 14 advice columns, 6 cross terms; secondary: Grumpkin, 7 and 5.
-    # The Rust driver cannot be built here: the gate is the synthetic degree-5 one of the leg above,
-    # witnesses are witness-like scalars, the challenge r is synthetic.  CPU: the oracle's
+    # 1049-1053).  Primary: BN256, two MainGate<5> (14 advice, 30 fixed columns), 6 cross terms;
+    # secondary: Grumpkin, one MainGate<5> (7 advice, 15 fixed), 5 cross terms -- the graphs of the leg above.
+    # The Rust driver cannot be built here: witnesses are witness-like scalars (not a satisfying trace: the
+    # arithmetic does not care), fixed columns uniform, the challenges synthetic.  CPU: the oracle's
     # restatements of the same calls on the effective host cores, same inputs, every output compared.
     try:
         from mira_amd import graph_evaluator as G
+        from mira_amd import main_gate as MG
         from mira_amd import fold as FD
-        k, nadv = 17, 8
+        k = 17
         n = 1 << k
-        shape = {cm.CURVE_BN256: (14, 6, G.FIELD_FR), cm.CURVE_GRUMPKIN: (7, 5, G.FIELD_FQ)}
-
-        def gate(shift, field):
-            sbox = []
-            for i in range(nadv):
-                x = G.Sum(G.Polynomial(3 + i), G.Constant(1000 + i + shift))
-                x2 = G.Product(x, x)
-                sbox.append(G.Product(G.Product(x2, x2), x))
-            e = None
-            for j in range(nadv):
-                acc = None
-                for i in range(nadv):
-                    t = G.Scaled(sbox[i], 17 * j + 3 * i + 2 + shift)
-                    acc = t if acc is None else G.Sum(acc, t)
-                row = G.Product(G.Polynomial(0), G.Sum(acc, G.Negated(G.Polynomial(3 + j, 1))))
-                e = row if e is None else G.Sum(G.Product(e, G.Challenge(j % 2)), row)
-            return G.Sum(e, G.Product(G.Polynomial(1), G.Polynomial(2, -1)))
+        shape = {cm.CURVE_BN256: (2, G.FIELD_FR), cm.CURVE_GRUMPKIN: (1, G.FIELD_FQ)}
         st = {}
-        for c, (ncol, cnt, field) in shape.items():
+        for c, (gates, field) in shape.items():
+            cg, ctx = MG.compressed_circuit(5, gates)
+            ncol, cnt = ctx.num_advice, cg.degree
             nw = ncol * n
             d_w1 = cm.synth_scalars_device(c, nw, seed=0x5100 + c, kind=1)       # accumulator witness
             d_w2 = cm.synth_scalars_device(c, nw, seed=0x5200 + c, kind=1)       # the step's new witness
-            d_fix = cm.synth_scalars_device(c, 2 * n, seed=0x5300 + c)
+            d_fix = cm.synth_scalars_device(c, ctx.num_fixed * n, seed=0x5300 + c)
             d_e = cm.synth_scalars_device(c, n, seed=0x5400 + c)
-            sel = np.ones(n, dtype=np.uint8); sel[::7] = 0
-            d_sel = lib.alloc(n); lib.upload(d_sel, sel)
-            # column table: selector, 2 fixed, then advice columns of W2 (the gate reads columns 3 .. 3 + nadv)
-            cols = [(d_sel, G.COL_BOOL), (d_fix, G.COL_FIELD), (d_fix + n * 32, G.COL_FIELD)] + [(d_w2 + j * n * 32, G.COL_FIELD) for j in range(min(ncol, nadv))]
-            cols += [(d_w1 + j * n * 32, G.COL_FIELD) for j in range(nadv - min(ncol, nadv))]
-            st[c] = dict(key=cm.CommitmentKey.synthetic(c, nw, seed=0x5500 + c), d_w1=d_w1, d_w2=d_w2, d_fix=d_fix, d_e=d_e, d_sel=d_sel, sel=sel, cols=cols, nw=nw,
-                         cnt=cnt, field=field, evs=[G.GraphEvaluator.new(gate(s, field), field) for s in range(cnt)], d_terms=lib.alloc(cnt * n * 32),
+            chal = [(0x1234567 + 977 * j) ** 7 % G.MODULUS[field] for j in range(2 * ctx.num_challenges)]   # [c1.., u1, c2.., u2]
+            dom = G.PlonkEvalDomain(ncol, 0, chal, [], [d_fix + j * n * 32 for j in range(ctx.num_fixed)], [(d_w1, nw)], [(d_w2, nw)], n)
+            st[c] = dict(key=cm.CommitmentKey.synthetic(c, nw, seed=0x5500 + c), d_w1=d_w1, d_w2=d_w2, d_fix=d_fix, d_e=d_e, cols=dom.columns(), chal=chal, nw=nw,
+                         cnt=cnt, field=field, ctx=ctx, evs=[G.GraphEvaluator.new(t, field) for t in cg.grouped.iter_from_first()], d_terms=lib.alloc(cnt * n * 32),
                          d_wout=lib.alloc(nw * 32), d_enew=lib.alloc(n * 32), r_int=(0x5EED0000 + 7919 * c) ** 5 % G.MODULUS[field],
                          acc_w=cm.CommitmentKey.default_value(), acc_e=cm.CommitmentKey.default_value())
             st[c]["r"] = G.to_montgomery([st[c]["r_int"]], field)[0]
-        chal = [0x1234567 + 977 * j for j in range(2)]
 
         def fold_step():
             spans = {"witness_commit": 0.0, "evaluation": 0.0, "commit": 0.0, "fold": 0.0}
@@ -741,7 +727,7 @@ def extras(lib, cm, with_cpu):
                 t0 = time.perf_counter()
                 w_commit = s_["key"].commit_device(s_["d_w2"], s_["nw"])
                 t1 = time.perf_counter()
-                G.GraphEvaluator.evaluate_batch_device(s_["evs"], s_["cols"], chal, n, [s_["d_terms"] + i * n * 32 for i in range(s_["cnt"])])
+                G.GraphEvaluator.evaluate_batch_device(s_["evs"], s_["cols"], s_["chal"], n, [s_["d_terms"] + i * n * 32 for i in range(s_["cnt"])])
                 t2 = time.perf_counter()
                 t_commits = s_["key"].commit_batch_device(s_["d_terms"], n, s_["cnt"])
                 t3 = time.perf_counter()
@@ -762,9 +748,10 @@ def extras(lib, cm, with_cpu):
             t0 = time.perf_counter(); spans, last = fold_step(); walls.append(((time.perf_counter() - t0) * 1e3, spans))
         wall, spans = sorted(walls, key=lambda x: x[0])[2]
         ex["nifs_fold_step_k17"] = {"ms": round(wall, 3), "spans_ms": {a: round(b * 1e3, 3) for a, b in spans.items()},
-                                    "rows": n, "advice_columns": [14, 7], "cross_terms": [6, 5],
-                                    "note": "both curves, device-resident vectors: witness commit, cross-term evaluation, batched cross-term commits, W / E folding "
-                                            "and instance folding (host g1_mul_add); span names follow the reference's tracing spans"}
+                                    "rows": n, "advice_columns": [st[c]["ctx"].num_advice for c in st], "fixed_columns": [st[c]["ctx"].num_fixed for c in st],
+                                    "cross_terms": [st[c]["cnt"] for c in st], "calculations_per_graph": [[ev.num_intermediates for ev in st[c]["evs"]] for c in st],
+                                    "note": "both curves, device-resident vectors: witness commit, evaluation of the reference's MainGate<5> cross-term graphs, batched "
+                                            "cross-term commits, W / E folding and instance folding (host g1_mul_add); span names follow the reference's tracing spans"}
         # opt-in: the same chain over 16-bit fixed-base tables (mira_msm_precompute_ex(handle, 16)) -- a
         # commitment key is fixed for the whole IVC run, its tables are built once
         for s_ in st.values():
@@ -784,11 +771,11 @@ def extras(lib, cm, with_cpu):
             ok = True
             for c, s_ in st.items():
                 fo = C.FIELD_FR if s_["field"] == G.FIELD_FR else C.FIELD_FQ
+                ncol, nfix = s_["ctx"].num_advice, s_["ctx"].num_fixed
                 bases = s_["key"].download()
                 w1, w2 = lib.download(s_["d_w1"], (s_["nw"], 4)), lib.download(s_["d_w2"], (s_["nw"], 4))
-                host_cols = [s_["sel"], lib.download(s_["d_fix"], (n, 4)), lib.download(s_["d_fix"] + n * 32, (n, 4))]
-                host_cols += [w2[j * n:(j + 1) * n] for j in range(min(shape[c][0], nadv))] + [w1[j * n:(j + 1) * n] for j in range(nadv - min(shape[c][0], nadv))]
-                chal_m = G.to_montgomery(chal, s_["field"])
+                host_cols = list(lib.download(s_["d_fix"], (nfix, n, 4))) + [w1[j * n:(j + 1) * n] for j in range(ncol)] + [w2[j * n:(j + 1) * n] for j in range(ncol)]
+                chal_m = G.to_montgomery(s_["chal"], s_["field"])
                 want_w = C.msm_pippenger(c, w2, bases)
                 terms = []
                 for ev in s_["evs"]:
@@ -804,7 +791,7 @@ def extras(lib, cm, with_cpu):
             ex["nifs_fold_step_k17"].update({"cpu_ms": round(cpu_ms, 1), "cpu_cores": C.num_threads(), "cpu_kind": "port (commits, evaluation and folds of the oracle, incl. downloads)",
                                              "bit_exact_commits_terms_folds": ok})
         for c, s_ in st.items():
-            for p in (s_["d_w1"], s_["d_w2"], s_["d_fix"], s_["d_e"], s_["d_sel"], s_["d_terms"], s_["d_wout"], s_["d_enew"]):
+            for p in (s_["d_w1"], s_["d_w2"], s_["d_fix"], s_["d_e"], s_["d_terms"], s_["d_wout"], s_["d_enew"]):
                 lib.free(p)
             s_["key"].close()
     except Exception as e:

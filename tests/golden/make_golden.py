@@ -48,7 +48,12 @@ def main():
             "y": ["8495653923123431417604973247489272438418190587263600148770280649306958101930",
                   "4082367875863433681332203403145435568316851327593401208105741076214120093531"]},
     }
-    json.dump(ref, open(os.path.join(HERE, "ref_kats.json"), "w"), indent=1)
+    # ref_kats.json also holds reference vectors entered by hand as data (basic_lagrange_test; the `Display` strings of
+    # src/polynomial/expression.rs:528-606 and src/polynomial/grouped_poly.rs:287-461): keep them
+    path = os.path.join(HERE, "ref_kats.json")
+    kats = json.load(open(path)) if os.path.exists(path) else {}
+    kats.update(ref)
+    json.dump(kats, open(path, "w"), indent=1)
 
     # ---- field vectors ------------------------------------------------------------------------
     fields = {}

@@ -41,6 +41,7 @@ extern "C" {
 #define MIRA_E_ALLOC (-4)         /* device allocation failed */
 #define MIRA_E_UNSUPPORTED (-5)   /* size not supported by this build */
 #define MIRA_E_INVALID_POINT (-6) /* a base is not on the curve */
+#define MIRA_E_IO (-7)            /* key file missing, unreadable or shorter than 2^k points */
 
 /* Largest number of windows any MSM configuration uses; sizes mira_msm_partial buffers. */
 #define MIRA_MAX_WINDOWS 64
@@ -80,6 +81,15 @@ int mira_msm_precompute_ex(uint64_t handle, int32_t window_bits);
 /* Validate every registered base against the curve equation on the GPU, as
  * load_or_setup_cache does with is_on_curve (src/commitment.rs:145-154). */
 int mira_msm_check_bases(uint64_t handle);
+/* The commitment-key cache file straight into HBM: CommitmentKey::load_from_file (src/commitment.rs:110-127)
+ * and, with validate != 0, the is_on_curve pass of load_or_setup_cache (:145-154) -- the raw in-memory
+ * `[C]` dump save_to_file writes (:96-101), 2^k points of 64 bytes.  The file is read in 64 MiB chunks
+ * by several threads into two pinned buffers; chunk i + 1 is read and copied while chunk i is converted to
+ * the resident layout and checked on the GPU.  A file shorter than 2^k points -> MIRA_E_IO ("failed to fill
+ * whole buffer", read_exact); a point off the curve -> MIRA_E_INVALID_POINT ("Wrong file in cache, some
+ * ptr out of curve"), no handle.  mira_msm_save_bases_file writes that file from a registered key. */
+int mira_msm_register_bases_file(int curve, const char *path, uint32_t k, int validate, uint64_t *handle_out);
+int mira_msm_save_bases_file(uint64_t handle, const char *path);
 
 /* out_affine = sum_i scalars[i] * bases[i], i < n <= registered length (the key's PREFIX is
  * used, src/commitment.rs:80).  n > registered length -> MIRA_E_TOO_LONG (src/commitment.rs:21-24,
@@ -107,8 +117,16 @@ int mira_msm_partial_device(uint64_t handle, size_t first, const void *d_scalars
                             uint64_t out_partial[MIRA_PARTIAL_U64], int32_t *window_bits, int32_t *num_windows);
 int mira_msm_combine(int curve, const uint64_t *partials /* nparts * MIRA_PARTIAL_U64 */, size_t nparts,
                      int32_t window_bits, int32_t num_windows, uint64_t out_affine[8]);
-/* Force the window width c (4..16) for every later MSM; 0 = choose from n.  All ranks of a
- * sharded MSM must use the same c. */
+/* Same, with the partial left in DEVICE memory (d_out_partial: MIRA_PARTIAL_U64 * 8 bytes, e.g. a tensor an
+ * RCCL all-gather reads): nothing crosses PCIe before the exchange.  Words beyond the partial's windows are zero. */
+int mira_msm_partial_to_device(uint64_t handle, size_t first, const void *d_scalars, size_t n,
+                               void *d_out_partial, int32_t *window_bits, int32_t *num_windows);
+/* Window width c (4..16) of every later commit over THIS key; 0 = let the planner choose from n and the
+ * scalar statistics.  Per handle, so two caller threads working on two keys never see each other's choice. */
+int mira_msm_set_handle_window_bits(uint64_t handle, int32_t c);
+/* Process-wide default width for keys without one of their own (tests, benchmarks; 0 = planner).  A process
+ * whose threads want different widths uses the per-handle call above.  All ranks of a sharded MSM must use the
+ * same c. */
 int mira_msm_set_window_bits(int32_t c);
 /* Diagnostics: the window width and count the planner used for the most recent commit of this
  * process (0 / the number of partial sums in fixed-base table mode). */
@@ -130,6 +148,9 @@ int mira_msm_last_plan(int32_t *window_bits, int32_t *num_windows);
 #define MIRA_TUNE_NTT_WAVE 4
 #define MIRA_TUNE_HOST_CHUNK_MIN_N 5
 #define MIRA_TUNE_NTT_SINGLE_TW_LOG 6
+/* largest transform (log2) whose first post-twiddle is served from a table of n entries (48 n bytes per cached
+ * table set); default 24, 0 = never */
+#define MIRA_TUNE_NTT_FULL_TW_MAX_LOG 7
 int mira_set_tuning(int knob, int64_t value);
 
 /* Read a range of the registered key back in the reference layout (cache file writing,
@@ -265,6 +286,16 @@ int mira_get_omega_or_inv(uint32_t k, int is_inverse, uint64_t out[4]);
  * index0 = global index of the first element (lets ranks generate their own chunk).          */
 int mira_synth_scalars_device(int curve, size_t n, uint64_t index0, uint64_t seed, int kind, void *d_out);
 int mira_synth_bases_device(int curve, size_t n, uint64_t index0, uint64_t seed, void *d_out);
+
+/* ---- library-held device memory ------------------------------------------------------------
+ * Workspaces (digit, sort and bucket buffers; NTT temporaries and the four cached twiddle-table sets,
+ * up to 805 MB each at 2^24 points) grow on demand and are reused by later calls: after one commit of
+ * 2^26 pairs the library holds about 6 GiB.  mira_trim releases the largest of them until at most
+ * keep_bytes remain (0 = everything; registered keys, their window tables and compiled graphs are never
+ * touched) and reports the bytes released; the next call re-allocates what it needs.
+ * mira_dev_mem_info: hipMemGetInfo of the bound device. */
+int mira_trim(size_t keep_bytes, size_t *released_out /* may be NULL */);
+int mira_dev_mem_info(size_t *free_bytes, size_t *total_bytes);
 
 /* ---- device memory helpers (thin hipMalloc/hipMemcpy wrappers for non-torch callers) ---- */
 int mira_dev_alloc(size_t bytes, void **d_out);

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmira_gpu.so")
 
 MIRA_OK = 0
-MIRA_E_NO_DEVICE, MIRA_E_BAD_ARG, MIRA_E_TOO_LONG, MIRA_E_ALLOC, MIRA_E_UNSUPPORTED, MIRA_E_INVALID_POINT = -1, -2, -3, -4, -5, -6
+MIRA_E_NO_DEVICE, MIRA_E_BAD_ARG, MIRA_E_TOO_LONG, MIRA_E_ALLOC, MIRA_E_UNSUPPORTED, MIRA_E_INVALID_POINT, MIRA_E_IO = -1, -2, -3, -4, -5, -6, -7
 MIRA_MAX_WINDOWS = 64
 MIRA_PARTIAL_U64 = MIRA_MAX_WINDOWS * 16
 
@@ -27,8 +27,10 @@ SYMBOLS = [
     "mira_get_omega_or_inv", "mira_synth_scalars_device", "mira_synth_bases_device",
     "mira_dev_alloc", "mira_dev_free", "mira_dev_upload", "mira_dev_download", "mira_dev_sync",
     "mira_set_timing", "mira_get_timings", "mira_set_tuning",
+    "mira_msm_register_bases_file", "mira_msm_save_bases_file", "mira_msm_partial_to_device", "mira_msm_set_handle_window_bits",
+    "mira_trim", "mira_dev_mem_info",
 ]
-TUNE_STAGED_MIN_N, TUNE_TABLE_MIN_N, TUNE_PLAN_HIST_MIN_N, TUNE_NTT_MAX_LOG_LINE, TUNE_NTT_WAVE, TUNE_HOST_CHUNK_MIN_N, TUNE_NTT_SINGLE_TW_LOG = 0, 1, 2, 3, 4, 5, 6
+TUNE_STAGED_MIN_N, TUNE_TABLE_MIN_N, TUNE_PLAN_HIST_MIN_N, TUNE_NTT_MAX_LOG_LINE, TUNE_NTT_WAVE, TUNE_HOST_CHUNK_MIN_N, TUNE_NTT_SINGLE_TW_LOG, TUNE_NTT_FULL_TW_MAX_LOG = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 def _preload_hip_runtime():
@@ -107,6 +109,9 @@ class MiraLib:
             "mira_dev_alloc": [sz, vp], "mira_dev_free": [vp], "mira_dev_upload": [vp, vp, sz], "mira_dev_download": [vp, vp, sz],
             "mira_dev_sync": [], "mira_set_timing": [ctypes.c_int], "mira_get_timings": [vp, vp, ctypes.c_int],
             "mira_set_tuning": [ctypes.c_int, ctypes.c_int64],
+            "mira_msm_register_bases_file": [ctypes.c_int, ctypes.c_char_p, u32, ctypes.c_int, vp], "mira_msm_save_bases_file": [u64, ctypes.c_char_p],
+            "mira_msm_partial_to_device": [u64, sz, vp, sz, vp, vp, vp], "mira_msm_set_handle_window_bits": [u64, i32],
+            "mira_trim": [sz, vp], "mira_dev_mem_info": [vp, vp],
         }
         for name, args in sig.items():
             fn = getattr(c, name)
@@ -139,6 +144,18 @@ class MiraLib:
     def tune(self, knob, value):
         """mira_set_tuning; value < 0 restores the default."""
         self.check(self.c.mira_set_tuning(knob, value))
+
+    def trim(self, keep_bytes=0):
+        """mira_trim: release the library's grow-only workspaces down to keep_bytes; returns the bytes released."""
+        rel = ctypes.c_size_t()
+        self.check(self.c.mira_trim(keep_bytes, ctypes.byref(rel)))
+        return rel.value
+
+    def mem_info(self):
+        """(free, total) bytes of the bound device"""
+        f, t = ctypes.c_size_t(), ctypes.c_size_t()
+        self.check(self.c.mira_dev_mem_info(ctypes.byref(f), ctypes.byref(t)))
+        return f.value, t.value
 
     def timings(self):
         names = (ctypes.c_char_p * 32)()

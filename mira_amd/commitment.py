@@ -85,28 +85,28 @@ class CommitmentKey:
         self.lib.check(self.lib.c.mira_msm_download_bases(self.handle, first, n, out.ctypes.data_as(ctypes.c_void_p)))
         return out
 
-    def save_to_file(self, file_path, chunk=1 << 20):
-        """`save_to_file` (src/commitment.rs:96-101): the slice as raw bytes."""
-        with open(file_path, "wb") as f:
-            for first in range(0, self._len, chunk):
-                f.write(self.download(first, min(chunk, self._len - first)).tobytes())
+    def save_to_file(self, file_path):
+        """`save_to_file` (src/commitment.rs:96-101): the slice as raw bytes (mira_msm_save_bases_file)."""
+        self.lib.check(self.lib.c.mira_msm_save_bases_file(self.handle, str(file_path).encode()))
 
     @classmethod
-    def load_from_file(cls, curve, file_path, k, lib=None, chunk=1 << 20):
-        """`load_from_file` (src/commitment.rs:110-127): 2^k points straight from the file into
-        HBM in chunks (memory-mapped, never a second host copy of the whole key)."""
-        lib = lib or _lib.load()
-        n = 1 << k
-        mm = np.memmap(file_path, dtype=np.uint64, mode="r")
-        if mm.size < n * 8:
-            raise IOError(f"failed to fill whole buffer: {file_path} holds {mm.size // 8} points, need {n}")   # read_exact
-        ptr = lib.alloc(max(n, 1) * 64)
-        for first in range(0, n, chunk):
-            cnt = min(chunk, n - first)
-            lib.upload(ptr + first * 64, np.ascontiguousarray(mm[first * 8:(first + cnt) * 8]))
-        key = cls(curve, device_ptr=ptr, length=n, lib=lib)
-        lib.free(ptr)                                   # register keeps its own resident copy
-        return key
+    def load_from_file(cls, curve, file_path, k, lib=None, validate=False):
+        """`load_from_file` (src/commitment.rs:110-127): 2^k points straight from the file into HBM
+        (mira_msm_register_bases_file: chunked pread into pinned buffers beside the conversion of the previous
+        chunk); validate = the is_on_curve pass of load_or_setup_cache folded into the same sweep.
+        A short file raises IOError("failed to fill whole buffer") like read_exact."""
+        self = cls.__new__(cls)
+        self.lib = lib or _lib.load()
+        self.curve, self._len = curve, 1 << k
+        h = ctypes.c_uint64()
+        rc = self.lib.c.mira_msm_register_bases_file(curve, str(file_path).encode(), k, 1 if validate else 0, ctypes.byref(h))
+        if rc == _lib.MIRA_E_IO:
+            raise IOError((self.lib.c.mira_last_error() or b"").decode())
+        if rc == _lib.MIRA_E_INVALID_POINT:
+            raise IOError("Wrong file in cache, some ptr out of curve")
+        self.lib.check(rc)
+        self.handle = h.value
+        return self
 
     @classmethod
     def load_or_setup_cache(cls, curve, cache_folder, label, k, lib=None):
@@ -117,14 +117,7 @@ class CommitmentKey:
         import os
         path = os.path.join(cache_folder, label, f"{k}.bin")
         if os.path.exists(path):
-            key = cls.load_from_file(curve, path, k, lib=lib)
-            try:
-                key.check_on_curve()
-            except _lib.MiraError as e:
-                if e.code == _lib.MIRA_E_INVALID_POINT:
-                    raise IOError("Wrong file in cache, some ptr out of curve") from e
-                raise
-            return key
+            return cls.load_from_file(curve, path, k, lib=lib, validate=True)
         key = cls.synthetic(curve, 1 << k, lib=lib)
         os.makedirs(os.path.dirname(path), exist_ok=True)
         key.save_to_file(path)
@@ -195,6 +188,20 @@ class CommitmentKey:
         self.lib.check(self.lib.c.mira_msm_partial_device(self.handle, first, ctypes.c_void_p(d_scalars), n,
                                                           part.ctypes.data_as(ctypes.c_void_p), ctypes.byref(c), ctypes.byref(w)))
         return part, c.value, w.value
+
+    def commit_partial_to_device(self, first, d_scalars, n, d_out, window_bits=0):
+        """The same with the MIRA_PARTIAL_U64 words left in device memory at `d_out` (the buffer an RCCL all-gather
+        reads); returns (window_bits, num_windows)."""
+        if first + n > self._len:
+            raise TooLongInput(first + n, self._len)
+        c, w = ctypes.c_int32(window_bits), ctypes.c_int32()
+        self.lib.check(self.lib.c.mira_msm_partial_to_device(self.handle, first, ctypes.c_void_p(d_scalars), n, ctypes.c_void_p(d_out),
+                                                             ctypes.byref(c), ctypes.byref(w)))
+        return c.value, w.value
+
+    def set_window_bits(self, c):
+        """Window width of every later commit over THIS key (4..16; 0 = planner): mira_msm_set_handle_window_bits."""
+        self.lib.check(self.lib.c.mira_msm_set_handle_window_bits(self.handle, c))
 
     def close(self):
         if getattr(self, "handle", None):

@@ -4,7 +4,11 @@
 // (src/fft.rs:51-196).  Kernels live in the per-curve units and ntt.hip.
 #include "ctx.h"
 #include "host_field.hpp"
+#include <cerrno>
+#include <fcntl.h>
+#include <sys/stat.h>
 #include <thread>
+#include <unistd.h>
 
 #ifdef MIRA_CPU_EMU
 thread_local dim3 threadIdx, blockIdx;
@@ -282,17 +286,19 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
     // 20-bit tables pay from 2^18 pairs (2^19 buckets to reduce whatever n is); 16-bit tables share the
     // bucket count of ONE window of the per-window path, so they win from a few thousand pairs
     const size_t table_min_n = tuned(MIRA_TUNE_TABLE_MIN_N, bs.table_c == 16 ? TABLE16_MIN_N : TABLE_MIN_N);
-    const bool table_mode = bs.tables && (sharded || n >= table_min_n) && g.forced_c == 0 && requested_c == 0;
+    // window width: the call's own (sharded partials), else this key's (mira_msm_set_handle_window_bits), else the process default
+    const int32_t forced_c = bs.forced_c ? bs.forced_c : g.forced_c;
+    const bool table_mode = bs.tables && (sharded || n >= table_min_n) && forced_c == 0 && requested_c == 0;
     // Data-dependent planning for single (unsharded) commits (ranks of a sharded MSM must agree on
     // the window width, so they keep the dense estimate).  The statistics are those of the previous
     // commit of the same length over this key -- successive fold steps commit witnesses of one
     // shape -- so no call waits for a pre-pass: this call's histogram is enqueued ahead of its MSM
     // kernels and read after the synchronisation that ends it.
     const size_t hist_min_n = tuned(MIRA_TUNE_PLAN_HIST_MIN_N, PLAN_HIST_MIN_N);
-    const bool use_hist = !table_mode && !sharded && g.forced_c == 0 && n >= hist_min_n && d_scalars;
+    const bool use_hist = !table_mode && !sharded && forced_c == 0 && n >= hist_min_n && d_scalars;
     // a rank of a sharded MSM that was not given a width takes 16, whatever its chunk length: partials
     // of different widths cannot be combined, and chunk lengths differ between ranks
-    const int32_t width = requested_c ? requested_c : (sharded && g.forced_c == 0) ? 16 : g.forced_c;
+    const int32_t width = requested_c ? requested_c : (sharded && forced_c == 0) ? 16 : forced_c;
     MsmPlan p = make_plan(n, width, 1, 0, (use_hist && bs.stat_n == n) ? bs.stat_hist : nullptr);
     if (n >= (1ull << 31) || (uint64_t)n * p.W >= (1ull << 32)) { set_error("n too large for 32-bit entry offsets"); return MIRA_E_UNSUPPORTED; }
     if (p.W > MIRA_MAX_WINDOWS) { set_error("window configuration exceeds MIRA_MAX_WINDOWS"); return MIRA_E_UNSUPPORTED; }
@@ -354,7 +360,8 @@ static int msm_batch_device_locked(uint64_t handle, const void *d_scalars, size_
     // 16-bit fixed-base tables: every commitment of the batch gets ONE bucket set for its 16 windows
     // (16 additions per pair instead of ceil(256 / c), 2^15 buckets per commitment instead of W 2^(c-1)),
     // and its 16 partial sums come back to be added -- no chain of doublings
-    if (bs.tables && bs.table_c == 16 && g.forced_c == 0 && n >= tuned(MIRA_TUNE_TABLE_MIN_N, TABLE16_MIN_N)) {
+    const int32_t forced_c = bs.forced_c ? bs.forced_c : g.forced_c;
+    if (bs.tables && bs.table_c == 16 && forced_c == 0 && n >= tuned(MIRA_TUNE_TABLE_MIN_N, TABLE16_MIN_N)) {
         const size_t per = std::max<size_t>(1, std::min<size_t>(64, (size_t)(((1ull << 32) - 1) / ((uint64_t)n * 16))));
         std::vector<uint64_t> sums;
         for (size_t done = 0; done < count; done += per) {
@@ -372,14 +379,14 @@ static int msm_batch_device_locked(uint64_t handle, const void *d_scalars, size_
         }
         return MIRA_OK;
     }
-    MsmPlan p1 = make_plan(n, g.forced_c);
+    MsmPlan p1 = make_plan(n, forced_c);
     // per launch: W_total * B counters <= 2^21 (three-launch scan) and n * W_total entries < 2^32
     size_t per = std::max<size_t>(1, std::min<size_t>((size_t)((1ull << 21) / ((uint64_t)p1.W * p1.B)),
                                                       (size_t)(((1ull << 32) - 1) / ((uint64_t)n * p1.W))));
     std::vector<uint64_t> win;
     for (size_t done = 0; done < count; done += per) {
         const size_t cnt = std::min(per, count - done);
-        MsmPlan p = make_plan(n, g.forced_c, (uint32_t)cnt, stride);
+        MsmPlan p = make_plan(n, forced_c, (uint32_t)cnt, stride);
         g.last_c = (int32_t)p.c; g.last_w = (int32_t)p.W;
         win.assign((size_t)p.Wt * 16, 0);
         const unsigned char *sc = reinterpret_cast<const unsigned char *>(d_scalars) + done * stride * 32;
@@ -660,7 +667,7 @@ int mira_msm_combine(int curve, const uint64_t *partials, size_t nparts, int32_t
 }
 int mira_set_tuning(int knob, int64_t value) {
     std::lock_guard<std::mutex> lk(g_lock);
-    if (knob < 0 || knob > MIRA_TUNE_NTT_SINGLE_TW_LOG) { set_error("unknown tuning knob"); return MIRA_E_BAD_ARG; }
+    if (knob < 0 || knob > MIRA_TUNE_NTT_FULL_TW_MAX_LOG) { set_error("unknown tuning knob"); return MIRA_E_BAD_ARG; }
     g.tune[knob] = value;
     return MIRA_OK;
 }
@@ -674,6 +681,120 @@ int mira_msm_set_window_bits(int32_t c) {
     std::lock_guard<std::mutex> lk(g_lock);
     if (c != 0 && (c < 4 || c > 16)) { set_error("window bits must be 0 or in [4,16]"); return MIRA_E_BAD_ARG; }
     g.forced_c = c;
+    return MIRA_OK;
+}
+
+int mira_msm_set_handle_window_bits(uint64_t handle, int32_t c) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    if (c != 0 && (c < 4 || c > 16)) { set_error("window bits must be 0 or in [4,16]"); return MIRA_E_BAD_ARG; }
+    auto it = g_bases.find(handle);
+    if (it == g_bases.end()) { set_error("unknown bases handle"); return MIRA_E_BAD_ARG; }
+    it->second.forced_c = c;
+    return MIRA_OK;
+}
+int mira_msm_partial_to_device(uint64_t handle, size_t first, const void *d_scalars, size_t n, void *d_out_partial,
+                               int32_t *window_bits, int32_t *num_windows) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    if (!d_out_partial || !window_bits || !num_windows) { set_error("null output"); return MIRA_E_BAD_ARG; }
+    if (*window_bits != 0 && (*window_bits < 4 || *window_bits > 16)) { set_error("window_bits must be 0 or 4..16"); return MIRA_E_BAD_ARG; }
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    RT_CHECK(rt_memset(d_out_partial, 0, MIRA_PARTIAL_U64 * 8, g.stream));     // words beyond the partial's windows (and an empty chunk) read as the identity
+    RT_CHECK(rt_sync(g.stream));
+    uint64_t unused[MIRA_PARTIAL_U64];
+    uint32_t c, W;
+    g.windows_dst = d_out_partial;
+    rc = msm_partial_locked(handle, first, d_scalars, n, unused, &c, &W, true, *window_bits);
+    g.windows_dst = nullptr;
+    if (rc) return rc;
+    *window_bits = (int32_t)c; *num_windows = (int32_t)W;
+    return MIRA_OK;
+}
+
+// CommitmentKey::load_from_file + the is_on_curve pass of load_or_setup_cache (src/commitment.rs:110-127, 145-154)
+int mira_msm_register_bases_file(int curve, const char *path, uint32_t k, int validate, uint64_t *handle_out) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    if ((curve != MIRA_CURVE_BN256 && curve != MIRA_CURVE_GRUMPKIN) || !path || !handle_out || k > 31) { set_error("bad register arguments"); return MIRA_E_BAD_ARG; }
+    const size_t n = (size_t)1 << k;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) { set_error(std::string(path) + ": " + strerror(errno)); return MIRA_E_IO; }
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || (size_t)sb.st_size < n * 64) {                  // read_exact of vec_len * size_of::<C>() bytes
+        set_error("failed to fill whole buffer");
+        close(fd);
+        return MIRA_E_IO;
+    }
+    Bases b; b.curve = curve; b.n = n; b.owned = true;
+    if (rt_malloc(&b.d, n * 64) != hipSuccess || !b.d) { close(fd); set_error("device allocation for bases failed"); return MIRA_E_ALLOC; }
+    uint32_t *bad = nullptr;
+    if ((rc = g.heavy.ensure(64)) == MIRA_OK) {
+        bad = reinterpret_cast<uint32_t *>(g.heavy.p);
+        rc = curve == MIRA_CURVE_BN256 ? load_bases_file_bn256(b, fd, validate != 0, bad) : load_bases_file_grumpkin(b, fd, validate != 0, bad);
+    }
+    close(fd);
+    if (rc == MIRA_OK && validate) {
+        uint32_t h = 0;
+        if (rt_d2h(&h, bad, 4, g.stream) != hipSuccess || rt_sync(g.stream) != hipSuccess) { set_error("device to host copy failed"); rc = MIRA_E_NO_DEVICE; }
+        else if (h) { set_error("Wrong file in cache, some ptr out of curve"); rc = MIRA_E_INVALID_POINT; }
+    }
+    if (rc != MIRA_OK) { (void)rt_free(b.d); return rc; }
+    *handle_out = g.next_handle++;
+    g_bases[*handle_out] = b;
+    return MIRA_OK;
+}
+// save_to_file (src/commitment.rs:96-101): the key as the raw slice of reference-layout points
+int mira_msm_save_bases_file(uint64_t handle, const char *path) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    auto it = g_bases.find(handle);
+    if (it == g_bases.end() || !path) { set_error("unknown bases handle"); return MIRA_E_BAD_ARG; }
+    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) { set_error(std::string(path) + ": " + strerror(errno)); return MIRA_E_IO; }
+    rc = it->second.curve == MIRA_CURVE_BN256 ? save_bases_file_bn256(it->second, fd) : save_bases_file_grumpkin(it->second, fd);
+    if (close(fd) != 0 && rc == MIRA_OK) { set_error(std::string("close failed: ") + strerror(errno)); rc = MIRA_E_IO; }
+    return rc;
+}
+
+// Release grow-only workspaces, largest first, until at most keep_bytes remain.
+int mira_trim(size_t keep_bytes, size_t *released_out) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    if (released_out) *released_out = 0;
+    if (!g.ready) return MIRA_OK;
+    RT_CHECK(rt_sync(g.stream));
+    if (g.copy_stream) RT_CHECK(rt_sync(g.copy_stream));
+    // `consts`, `ntt_consts` and `fold_consts` hold uploaded constants (a few hundred bytes): never released
+    std::vector<DevBuf *> bufs = {&g.digits, &g.counts, &g.offsets, &g.cursor, &g.block_sums, &g.sorted_idx, &g.bucket_sums, &g.part, &g.coarse_offsets,
+                                  &g.fine_counts, &g.fine_cursor, &g.head_part, &g.tail_part, &g.tail_key, &g.heavy, &g.heavy_out, &g.chunks, &g.window_sums,
+                                  &g.scalars_stage, &g.ntt_tmp, &g.ntt_stage, &g.graph_ws, &g.tree_a, &g.tree_b, &g.hist_dev};
+    for (int i = 0; i < Ctx::NTT_SETS; i++) bufs.push_back(&g.ntt_set[i]);
+    size_t total = 0;
+    for (DevBuf *b : bufs) total += b->cap;
+    std::sort(bufs.begin(), bufs.end(), [](const DevBuf *a, const DevBuf *b) { return a->cap > b->cap; });
+    size_t released = 0;
+    for (DevBuf *b : bufs) {
+        if (total - released <= keep_bytes || b->cap == 0) break;
+        for (int i = 0; i < Ctx::NTT_SETS; i++)
+            if (b == &g.ntt_set[i]) { g.ntt_set_key[i].clear(); g.ntt_set_stamp[i] = 0; }
+        if (b == &g.hist_dev) g.hist_sel = 0;
+        released += b->cap;
+        b->release();
+    }
+    if (released_out) *released_out = released;
+    return MIRA_OK;
+}
+int mira_dev_mem_info(size_t *free_bytes, size_t *total_bytes) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    size_t f = 0, t = 0;
+#ifndef MIRA_CPU_EMU
+    RT_CHECK(hipMemGetInfo(&f, &t));
+#endif
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
     return MIRA_OK;
 }
 

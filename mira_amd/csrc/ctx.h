@@ -33,6 +33,7 @@ static inline hipError_t rt_sync(hipStream_t s) { return hipStreamSynchronize(s)
 static inline hipError_t rt_last() { return hipGetLastError(); }
 static inline hipError_t rt_host_alloc(void **p, size_t n) { return hipHostMalloc(p, n, hipHostMallocDefault); }
 static inline hipError_t rt_host_free(void *p) { return hipHostFree(p); }
+static inline hipError_t rt_event_sync(hipEvent_t e) { return hipEventSynchronize(e); }
 // `waiter` does not start work enqueued after this call before everything enqueued on `done` so far has finished
 static inline hipError_t rt_stream_wait(hipStream_t waiter, hipStream_t done, hipEvent_t ev) {
     hipError_t e = hipEventRecord(ev, done);
@@ -41,6 +42,7 @@ static inline hipError_t rt_stream_wait(hipStream_t waiter, hipStream_t done, hi
 #else
 typedef int hipEvent_t;
 static inline int rt_stream_wait(hipStream_t, hipStream_t, hipEvent_t) { return 0; }
+static inline int rt_event_sync(hipEvent_t) { return 0; }
 #define RT_CHECK(expr) do { (void)(expr); } while (0)
 static inline int rt_malloc(void **p, size_t n) { *p = aligned_alloc(64, (n + 63) / 64 * 64); return *p ? 0 : 1; }
 static inline int rt_free(void *p) { free(p); return 0; }
@@ -57,6 +59,7 @@ static inline int rt_host_free(void *p) { free(p); return 0; }
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    void release() { if (p) (void)rt_free(p); p = nullptr; cap = 0; }
     int ensure(size_t bytes) {
         if (bytes <= cap) return MIRA_OK;
         if (p) (void)rt_free(p);
@@ -89,7 +92,7 @@ struct Ctx {
     hipStream_t copy_stream = nullptr;   // host scalars travel here, chunk by chunk, beside the kernels of earlier chunks
     std::vector<hipEvent_t> copy_events;
     int32_t forced_c = 0;
-    int64_t tune[7] = {-1, -1, -1, -1, -1, -1, -1};   // mira_set_tuning overrides, < 0 = default
+    int64_t tune[8] = {-1, -1, -1, -1, -1, -1, -1, -1};   // mira_set_tuning overrides, < 0 = default
     Timing tm;
     // MSM workspace (grow-only, shared by all handles: calls are serialised by the ABI lock)
     DevBuf digits, counts, offsets, cursor, block_sums, sorted_idx, bucket_sums, part, coarse_offsets, fine_counts, fine_cursor;
@@ -109,6 +112,7 @@ struct Ctx {
     int32_t last_c = 0, last_w = 0;  // mira_msm_last_plan
     uint32_t hist_sel = 0;           // which of the two device histograms the next commit adds into
     unsigned char *out_host = nullptr; size_t out_host_cap = 0;   // pinned staging of window sums + statistics   // cross-term evaluator: staged program, intermediates[slot][lane]
+    void *windows_dst = nullptr;     // mira_msm_partial_to_device: device destination of the window sums of the call in flight
     uint64_t next_handle = 1;
 };
 extern Ctx g;
@@ -118,6 +122,7 @@ struct Bases {
     size_t n;
     void *d = nullptr;
     bool owned = false;
+    int32_t forced_c = 0;     // mira_msm_set_handle_window_bits: this key's window width, 0 = planner / process default
     void *tables = nullptr;   // fixed-base window tables 2^(table_c w) P_i, w < table_w (table_kernels.cuh), or null
     uint32_t table_c = 0, table_w = 0;
     // bit-length histogram of the scalars of the previous commit of stat_n elements over this key
@@ -165,6 +170,11 @@ int synth_bases_bn256(size_t n, uint64_t index0, uint64_t seed, void *d_out);
 int synth_bases_grumpkin(size_t n, uint64_t index0, uint64_t seed, void *d_out);
 int check_bases_bn256(const Bases &bs, uint32_t *d_bad);
 int check_bases_grumpkin(const Bases &bs, uint32_t *d_bad);
+// key cache file <-> HBM (msm_host.cuh): read 2^k points in chunks beside their conversion / validation; write
+int load_bases_file_bn256(Bases &b, int fd, bool validate, uint32_t *d_bad);
+int load_bases_file_grumpkin(Bases &b, int fd, bool validate, uint32_t *d_bad);
+int save_bases_file_bn256(const Bases &b, int fd);
+int save_bases_file_grumpkin(const Bases &b, int fd);
 
 // fold.hip
 int fold_witness_device(int field, void *d_out, const void *d_w1, const void *d_w2, const uint64_t r[4], size_t n);

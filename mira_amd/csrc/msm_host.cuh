@@ -5,6 +5,9 @@
 #include "msm_kernels.cuh"
 #include "table_kernels.cuh"
 #include "sort_kernels.cuh"
+#include <cerrno>
+#include <thread>
+#include <unistd.h>
 
 #ifdef MIRA_CPU_EMU
 static constexpr uint32_t FIXUP_HEAVY_GRID = 4;     // emulated lanes are OS threads: keep the idle grid small
@@ -37,8 +40,31 @@ static inline std::vector<size_t> host_chunks(size_t n, size_t min_n) {
 }
 
 template <class F, class FS>
+static int msm_launch_body(const Bases &bs, size_t first, const void *d_scalars, const void *h_scalars, size_t n, const MsmPlan &p,
+                           uint64_t *host_windows /* count * W * 16 u64 */);
+// A failure inside the launch sequence (an allocation, a runtime error) must not leave work behind that the next
+// call would trip over: the copy stream may still be reading the caller's host buffer, the work stream may still
+// be using the workspaces, and the planning histogram this commit was to fill is half written.
+template <class F, class FS>
 static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, const void *h_scalars, size_t n, const MsmPlan &p,
-                      uint64_t *host_windows /* count * W * 16 u64 */) {
+                      uint64_t *host_windows) {
+    const uint32_t hist_sel_before = g.hist_sel;
+    const int rc = msm_launch_body<F, FS>(bs, first, d_scalars, h_scalars, n, p, host_windows);
+    if (rc != MIRA_OK) {
+        if (g.copy_stream) (void)rt_sync(g.copy_stream);
+        (void)rt_sync(g.stream);
+        (void)rt_last();
+        if (p.stats && g.hist_dev.p) {                       // both histograms back to zero, selector as before
+            (void)rt_memset(g.hist_dev.p, 0, 2048, g.stream);
+            (void)rt_sync(g.stream);
+            g.hist_sel = hist_sel_before;
+        }
+    }
+    return rc;
+}
+template <class F, class FS>
+static int msm_launch_body(const Bases &bs, size_t first, const void *d_scalars, const void *h_scalars, size_t n, const MsmPlan &p,
+                           uint64_t *host_windows /* count * W * 16 u64 */) {
     int rc;
     // chunks: [0, ends[0]), [ends[0], ends[1]), ...  (one chunk unless the scalars are in host memory)
     const std::vector<size_t> ends = (h_scalars && p.count == 1) ? host_chunks(n, tuned(MIRA_TUNE_HOST_CHUNK_MIN_N, (size_t)1 << 19)) : std::vector<size_t>{n};
@@ -200,7 +226,10 @@ static int msm_launch(const Bases &bs, size_t first, const void *d_scalars, cons
     }
     tm_mark("window_sum");
     RT_CHECK(rt_last());
-    if (p.stats) {                                           // sums and statistics in one copy, through pinned memory
+    if (g.windows_dst) {                                     // mira_msm_partial_to_device: the sums stay in device memory
+        RT_CHECK(rt_d2d(g.windows_dst, g.window_sums.p, (size_t)nsum * 128, st));
+        RT_CHECK(rt_sync(st));
+    } else if (p.stats) {                                    // sums and statistics in one copy, through pinned memory
         const size_t bytes = (size_t)nsum * 128 + 1024;
         if (g.out_host_cap < bytes) {
             if (g.out_host) (void)rt_host_free(g.out_host);
@@ -384,9 +413,101 @@ static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars
                    reinterpret_cast<const unsigned char *>(g.chunks.p), nchunks / TABLE_SUMS, reinterpret_cast<unsigned char *>(g.window_sums.p), (const uint32_t *)nullptr);
     tm_mark("window_sum");
     RT_CHECK(rt_last());
-    RT_CHECK(rt_d2h(host_sums, g.window_sums.p, (size_t)TABLE_SUMS * 128, st));
+    if (g.windows_dst) RT_CHECK(rt_d2d(g.windows_dst, g.window_sums.p, (size_t)TABLE_SUMS * 128, st));
+    else RT_CHECK(rt_d2h(host_sums, g.window_sums.p, (size_t)TABLE_SUMS * 128, st));
     RT_CHECK(rt_sync(st));
     tm_end();
     return MIRA_OK;
+}
+
+// ---- commitment-key cache file <-> HBM ----------------------------------------------------
+// The file is the raw `[C]` slice save_to_file writes (src/commitment.rs:96-101): 64 bytes per point, reference
+// layout.  load_from_file (:110-127) reads it whole into host memory and load_or_setup_cache (:145-154) then walks
+// it with is_on_curve; here it goes straight to HBM in chunks: chunk i + 1 is read from the file (several threads,
+// pread) into the other of two pinned buffers and copied while chunk i is converted to the resident layout and
+// checked against the curve equation on the work stream.
+static constexpr size_t KEYFILE_CHUNK_POINTS = (size_t)1 << 20;     // 64 MiB
+static inline int read_exact_parallel(int fd, unsigned char *dst, size_t bytes, size_t file_off) {
+    const size_t nthreads = std::max<size_t>(1, std::min<size_t>(8, std::thread::hardware_concurrency()));
+    const size_t slice = (bytes + nthreads - 1) / nthreads;
+    std::vector<int> fail(nthreads, 0);
+    std::vector<std::thread> th;
+    auto work = [&](size_t t) {
+        size_t lo = std::min(bytes, t * slice), hi = std::min(bytes, lo + slice);
+        while (lo < hi) {
+            const ssize_t r = pread(fd, dst + lo, hi - lo, (off_t)(file_off + lo));
+            if (r <= 0) { fail[t] = 1; return; }                  // error or end of file: read_exact's "failed to fill whole buffer"
+            lo += (size_t)r;
+        }
+    };
+    for (size_t t = 1; t < nthreads; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    for (int f : fail) if (f) return 1;
+    return 0;
+}
+template <class F> static int load_bases_file(Bases &b, int fd, bool validate, const unsigned char *d_curve_b, uint32_t *d_bad) {
+    unsigned char *pinned[2] = {nullptr, nullptr};
+    const size_t chunk_bytes = std::min(b.n, KEYFILE_CHUNK_POINTS) * 64;
+    auto body = [&]() -> int {
+        for (int k = 0; k < 2; k++) RT_CHECK(rt_host_alloc(reinterpret_cast<void **>(&pinned[k]), chunk_bytes));
+#ifndef MIRA_CPU_EMU
+        if (!g.copy_stream) RT_CHECK(hipStreamCreateWithFlags(&g.copy_stream, hipStreamNonBlocking));
+        while (g.copy_events.size() < 2) {
+            hipEvent_t e;
+            RT_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            g.copy_events.push_back(e);
+        }
+#endif
+        hipStream_t st = g.stream, cs = g.copy_stream ? g.copy_stream : st;
+        if (validate) RT_CHECK(rt_memset(d_bad, 0, 4, st));
+        unsigned char *dst = reinterpret_cast<unsigned char *>(b.d);
+        size_t i = 0;
+        for (size_t off = 0; off < b.n; off += KEYFILE_CHUNK_POINTS, i++) {
+            const size_t cnt = std::min(KEYFILE_CHUNK_POINTS, b.n - off);
+            unsigned char *buf = pinned[i & 1];
+#ifndef MIRA_CPU_EMU
+            if (i >= 2) RT_CHECK(rt_event_sync(g.copy_events[i & 1]));     // the copy out of this buffer two chunks ago is done
+#endif
+            if (read_exact_parallel(fd, buf, cnt * 64, off * 64)) { set_error("failed to fill whole buffer"); return MIRA_E_IO; }
+            RT_CHECK(rt_h2d(dst + off * 64, buf, cnt * 64, cs));
+#ifndef MIRA_CPU_EMU
+            if (cs != st) RT_CHECK(rt_stream_wait(st, cs, g.copy_events[i & 1]));
+            else RT_CHECK(hipEventRecord(g.copy_events[i & 1], cs));
+#endif
+            LAUNCH(k_convert_bases<F>, ceil_div(cnt, 256), 256, 0, st, (const unsigned char *)(dst + off * 64), dst + off * 64, (uint64_t)cnt);
+            if (validate) LAUNCH(k_check_on_curve<F>, ceil_div(cnt, 256), 256, 0, st, (const unsigned char *)(dst + off * 64), (uint64_t)cnt, d_curve_b, d_bad);
+        }
+        RT_CHECK(rt_last());
+        RT_CHECK(rt_sync(cs));
+        RT_CHECK(rt_sync(st));
+        return MIRA_OK;
+    };
+    const int rc = body();
+    if (rc != MIRA_OK) { if (g.copy_stream) (void)rt_sync(g.copy_stream); (void)rt_sync(g.stream); }
+    for (int k = 0; k < 2; k++) if (pinned[k]) (void)rt_host_free(pinned[k]);
+    return rc;
+}
+template <class F> static int save_bases_file(const Bases &b, int fd) {
+    int rc;
+    const size_t chunk = std::min(b.n, KEYFILE_CHUNK_POINTS);
+    if (!chunk) return MIRA_OK;
+    if ((rc = g.scalars_stage.ensure(chunk * 64))) return rc;
+    unsigned char *pinned = nullptr;
+    RT_CHECK(rt_host_alloc(reinterpret_cast<void **>(&pinned), chunk * 64));
+    rc = MIRA_OK;
+    for (size_t off = 0; off < b.n && rc == MIRA_OK; off += chunk) {
+        const size_t cnt = std::min(chunk, b.n - off);
+        LAUNCH(k_export_bases<F>, ceil_div(cnt, 256), 256, 0, g.stream, reinterpret_cast<const unsigned char *>(b.d) + off * 64,
+               reinterpret_cast<unsigned char *>(g.scalars_stage.p), (uint64_t)cnt);
+        if (rt_d2h(pinned, g.scalars_stage.p, cnt * 64, g.stream) != hipSuccess || rt_sync(g.stream) != hipSuccess) { set_error("device to host copy failed"); rc = MIRA_E_NO_DEVICE; break; }
+        for (size_t done = 0; done < cnt * 64;) {
+            const ssize_t w = write(fd, pinned + done, cnt * 64 - done);
+            if (w <= 0) { set_error(std::string("write failed: ") + strerror(errno)); rc = MIRA_E_IO; break; }
+            done += (size_t)w;
+        }
+    }
+    (void)rt_host_free(pinned);
+    return rc;
 }
 

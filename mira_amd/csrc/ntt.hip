@@ -58,7 +58,7 @@ static uint32_t ntt_max_log_line(uint32_t log_n) {
     const int v = (int)g.tune[MIRA_TUNE_NTT_MAX_LOG_LINE];
     return (uint32_t)std::min(std::max(v, 1), NTT_MAX_LOG_LINE);
 }
-static int ntt_prepare_tables(uint32_t log_n, const uint64_t omega[4], NttTables &t) {
+static int ntt_prepare_tables(uint32_t log_n, const uint64_t omega[4], NttTables &t, bool want_full = true) {
     const uint32_t max_line = ntt_max_log_line(log_n);
     t.passes = log_n <= max_line ? 1 : log_n <= 2 * max_line ? 2 : 3;
     uint32_t rest = log_n;
@@ -76,7 +76,7 @@ static int ntt_prepare_tables(uint32_t log_n, const uint64_t omega[4], NttTables
         t.off_tw[p] = off; off += n_tw[p] * TW_BYTES;
     }
     const uint32_t single_log = (uint32_t)tuned(MIRA_TUNE_NTT_SINGLE_TW_LOG, NTT_SINGLE_TW_LOG);
-    const bool full0 = t.passes > 1 && range[0] > single_log && log_n <= NTT_FULL_TW_MAX_LOG;
+    const bool full0 = want_full && t.passes > 1 && range[0] > single_log && log_n <= (uint32_t)tuned(MIRA_TUNE_NTT_FULL_TW_MAX_LOG, NTT_FULL_TW_MAX_LOG);
     for (uint32_t q = 0; q + 1 < t.passes; q++) {
         t.single[q] = range[q] <= single_log;                                      // small ranges: one table, no product per element
         t.h[q] = t.single[q] ? range[q] : (range[q] + 1) / 2;
@@ -87,7 +87,7 @@ static int ntt_prepare_tables(uint32_t log_n, const uint64_t omega[4], NttTables
     t.off_full = off;
     if (full0) off += ((size_t)TW_BYTES) << log_n;
     std::string key((const char *)omega, 32);
-    key += std::to_string(log_n) + "/" + std::to_string(max_line) + "/" + std::to_string(single_log);
+    key += std::to_string(log_n) + "/" + std::to_string(max_line) + "/" + std::to_string(single_log) + (full0 ? "/full" : "");
     // four cached sets, least recently used replaced: fft and ifft of two sizes alternate without rebuilding
     int slot = -1, lru = 0;
     for (int i = 0; i < Ctx::NTT_SETS; i++) {
@@ -102,7 +102,13 @@ static int ntt_prepare_tables(uint32_t log_n, const uint64_t omega[4], NttTables
     if (hit) return MIRA_OK;
     int rc;
     g.ntt_set_key[slot].clear();
-    if ((rc = g.ntt_set[slot].ensure(off))) return rc;
+    // an evicted set that is far larger than the new one goes back to the allocator (a 2^24 set is 0.8 GB)
+    if (g.ntt_set[slot].cap > 4 * off + ((size_t)1 << 20)) g.ntt_set[slot].release();
+    if ((rc = g.ntt_set[slot].ensure(off))) {
+        // the n-entry table is an optimisation: without the memory for it the two-table product still works
+        if (full0) return ntt_prepare_tables(log_n, omega, t, false);
+        return rc;
+    }
     if ((rc = g.ntt_consts.ensure(256))) return rc;
     RT_CHECK(rt_h2d(g.ntt_consts.p, omega, 32, g.stream));
     unsigned char *tab = reinterpret_cast<unsigned char *>(g.ntt_set[slot].p);

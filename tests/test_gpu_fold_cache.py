@@ -53,3 +53,79 @@ def test_key_cache_roundtrip(gpu_lib, tmp_path):
     (folder / f"{k}.bin").write_bytes(bytes(raw))
     with pytest.raises(IOError, match="Wrong file in cache, some ptr out of curve"):
         cm.CommitmentKey.load_or_setup_cache(cid, str(tmp_path / "cache"), "grumpkin", k)
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_key_file_into_hbm_in_chunks(gpu_lib, tmp_path, cid):
+    """mira_msm_register_bases_file: a key of several 64 MiB chunks (2^21 + ragged tail is not a power of two, so
+    k = 21 reads the first 2^21 points of a longer file) through the two-buffer pipeline; the loaded key commits to
+    the oracle's point and exports the file's bytes; validation is folded into the same sweep."""
+    k = 21
+    n = (1 << k) + 12345                                        # the file is LONGER than 2^k points: load_from_file reads exactly 2^k
+    key = cm.CommitmentKey.synthetic(cid, n, seed=91 + cid)
+    path = tmp_path / "key.bin"
+    key.save_to_file(path)
+    assert path.stat().st_size == n * 64
+    loaded = cm.CommitmentKey.load_from_file(cid, path, k, validate=True)
+    assert len(loaded) == 1 << k
+    rng = np.random.default_rng(5)
+    for first in (0, 1 << 20, (1 << 21) - 4096, int(rng.integers(0, (1 << 21) - 4096))):      # chunk boundaries and a random spot
+        assert (loaded.download(first, 4096) == key.download(first, 4096)).all()
+    m = 1 << 16
+    sc = C.synth_scalars(cid, m, seed=93)
+    assert (loaded.commit(sc) == C.msm_pippenger(cid, sc, key.download(0, m))).all()
+    with pytest.raises(IOError, match="failed to fill whole buffer"):
+        cm.CommitmentKey.load_from_file(cid, path, k + 1)
+    # one flipped bit in the LAST chunk: only the validating load refuses it
+    raw = np.memmap(path, dtype=np.uint8, mode="r+")
+    raw[((1 << k) - 7) * 64 + 9] ^= 0x10
+    raw.flush(); del raw
+    cm.CommitmentKey.load_from_file(cid, path, k).close()
+    with pytest.raises(IOError, match="Wrong file in cache, some ptr out of curve"):
+        cm.CommitmentKey.load_from_file(cid, path, k, validate=True)
+    key.close(); loaded.close()
+
+
+def test_trim_returns_device_memory(gpu_lib):
+    """mira_trim(0) after a large commit and transforms: the device's free memory is back where it was before the
+    library grew its workspaces."""
+    lib = gpu_lib
+    lib.trim(0)
+    n = 1 << 24
+    key = cm.CommitmentKey.synthetic(0, n, seed=7)
+    d = cm.synth_scalars_device(0, n, seed=8)
+    lib.check(lib.c.mira_dev_sync())
+    free0, total = lib.mem_info()
+    from mira_amd import fft as F
+    p1 = key.commit_device(d, n)
+    F.fft_device(d, 24); F.ifft_device(d, 24)                   # two cached table sets of 0.8 GB each + the temporary
+    free1, _ = lib.mem_info()
+    grown = free0 - free1
+    assert grown > (2 * 16 + 4 * 16) * n                        # at least the digit and sorted-entry buffers of that commit
+    released = lib.trim(0)
+    free2, _ = lib.mem_info()
+    assert released >= grown * 0.95 and free0 - free2 < 64 << 20, (free0, free1, free2, released)
+    p2 = key.commit_device(d, n)                                 # everything comes back on demand (d now holds ifft(fft(x)) = x)
+    assert (p1 == p2).all()
+    keep = 1 << 30
+    lib.trim(keep)
+    free3, _ = lib.mem_info()
+    assert free0 - free3 <= keep + (64 << 20)
+    lib.free(d); key.close(); lib.trim(0)
+
+
+def test_window_width_per_handle_gpu(gpu_lib):
+    import ctypes
+    lib = gpu_lib
+    n = 1 << 15
+    keys = [cm.CommitmentKey.synthetic(cid, n, seed=50 + cid) for cid in (0, 1)]
+    ds = [cm.synth_scalars_device(cid, n, seed=60 + cid) for cid in (0, 1)]
+    want = [keys[i].commit_device(ds[i], n) for i in (0, 1)]
+    keys[0].set_window_bits(8); keys[1].set_window_bits(14)
+    for i, c in ((0, 8), (1, 14), (0, 8)):
+        assert (keys[i].commit_device(ds[i], n) == want[i]).all()
+        cc, ww = ctypes.c_int32(), ctypes.c_int32()
+        lib.check(lib.c.mira_msm_last_plan(ctypes.byref(cc), ctypes.byref(ww)))
+        assert cc.value == c
+    for i in (0, 1):
+        lib.free(ds[i]); keys[i].close()

@@ -2,6 +2,7 @@
 import numpy as np
 import pytest
 
+from mira_amd import _lib as _lib_mod
 from mira_amd import commitment as cm
 from mira_amd import fft as F
 from oracle import cref as C
@@ -115,3 +116,93 @@ def _two_thread_abi(lib, n, log_n, rounds):
 
 def test_abi_from_two_threads(emu_lib):
     _two_thread_abi(emu_lib, n=40, log_n=5, rounds=3)
+
+
+def test_window_width_is_per_handle(emu_lib):
+    """mira_msm_set_handle_window_bits: two keys, two widths, neither sees the other's (the process-wide
+    mira_msm_set_window_bits stays the default for keys without one); the point never depends on the width."""
+    import ctypes
+    lib = emu_lib
+    n = 300
+    keys = {cid: cm.CommitmentKey(cid, C.synth_bases(cid, n, seed=31 + cid), lib=lib) for cid in (0, 1)}
+    d = {cid: cm.synth_scalars_device(cid, n, seed=41 + cid, lib=lib) for cid in (0, 1)}
+    want = {cid: keys[cid].commit_device(d[cid], n) for cid in (0, 1)}
+
+    def last_plan():
+        c, w = ctypes.c_int32(), ctypes.c_int32()
+        lib.check(lib.c.mira_msm_last_plan(ctypes.byref(c), ctypes.byref(w)))
+        return c.value, w.value
+    keys[0].set_window_bits(7)
+    keys[1].set_window_bits(11)
+    for cid, c in ((0, 7), (1, 11), (0, 7)):
+        assert (keys[cid].commit_device(d[cid], n) == want[cid]).all()
+        assert last_plan() == (c, (256 + c - 1) // c)
+    lib.check(lib.c.mira_msm_set_window_bits(9))               # process default: only for keys without a width of their own
+    try:
+        assert (keys[0].commit_device(d[0], n) == want[0]).all() and last_plan()[0] == 7
+        keys[0].set_window_bits(0)
+        assert (keys[0].commit_device(d[0], n) == want[0]).all() and last_plan()[0] == 9
+        assert (keys[0].commit_batch_device(d[0], n, 1)[0] == want[0]).all() and last_plan()[0] == 9
+    finally:
+        lib.check(lib.c.mira_msm_set_window_bits(0))
+    with pytest.raises(_lib_mod.MiraError):
+        keys[0].set_window_bits(3)
+    assert lib.c.mira_msm_set_handle_window_bits(424242, 8) == _lib_mod.MIRA_E_BAD_ARG
+    for cid in (0, 1):
+        lib.free(d[cid]); keys[cid].close()
+
+
+def test_trim_releases_workspaces_and_calls_recover(emu_lib):
+    """mira_trim: grow-only workspaces and cached NTT table sets go back; the next calls re-allocate"""
+    lib = emu_lib
+    n = 2000
+    key = cm.CommitmentKey(0, C.synth_bases(0, n, seed=51), lib=lib)
+    sc = C.synth_scalars(0, n, seed=52)
+    want = key.commit(sc)
+    a = C.synth_scalars(0, 1 << 9, seed=53)
+    want_fft = F.fft(a, 9, lib=lib)
+    released = lib.trim(0)
+    assert released > n * 16 * 2                                # at least the digit buffer of that commit
+    assert lib.trim(0) == 0                                     # nothing left to release
+    assert (key.commit(sc) == want).all()
+    assert (F.fft(a, 9, lib=lib) == want_fft).all()
+    assert (F.ifft(F.fft(a, 9, lib=lib), 9, lib=lib) == a).all()
+    big = lib.trim(1 << 40)                                     # keep more than there is: nothing happens
+    assert big == 0 and (key.commit(sc) == want).all()
+    key.close()
+
+
+def test_partial_to_device_equals_host_partial(emu_lib):
+    lib = emu_lib
+    n = 700
+    key = cm.CommitmentKey(1, C.synth_bases(1, n, seed=61), lib=lib)
+    d = cm.synth_scalars_device(1, n, seed=62, lib=lib)
+    d_out = lib.alloc(_lib_mod.MIRA_PARTIAL_U64 * 8)
+    for first, cnt, c in ((0, n, 0), (100, 333, 13), (n, 0, 16)):
+        part, c1, w1 = key.commit_partial_device(first, d + 0, cnt, window_bits=c)
+        c2, w2 = key.commit_partial_to_device(first, d + 0, cnt, d_out, window_bits=c)
+        assert (c1, w1) == (c2, w2)
+        got = lib.download(d_out, (_lib_mod.MIRA_PARTIAL_U64,))
+        assert not got[w2 * 16:].any()                           # words beyond the partial's windows are zero
+        # (the projective representation of a window sum depends on the order the sort's atomics left the
+        # entries in; the point does not)
+        assert (cm.combine_partials(1, got, c2, w2, lib=lib) == cm.combine_partials(1, part, c1, w1, lib=lib)).all()
+    with pytest.raises(cm.TooLongInput):
+        key.commit_partial_to_device(1, d, n, d_out)
+    lib.free(d); lib.free(d_out); key.close()
+
+
+def test_key_file_errors(emu_lib, tmp_path):
+    import ctypes
+    h = ctypes.c_uint64()
+    assert emu_lib.c.mira_msm_register_bases_file(0, str(tmp_path / "missing.bin").encode(), 4, 1, ctypes.byref(h)) == _lib_mod.MIRA_E_IO
+    assert b"missing.bin" in emu_lib.c.mira_last_error()
+    (tmp_path / "short.bin").write_bytes(b"\0" * (15 * 64))
+    assert emu_lib.c.mira_msm_register_bases_file(0, str(tmp_path / "short.bin").encode(), 4, 0, ctypes.byref(h)) == _lib_mod.MIRA_E_IO
+    assert emu_lib.c.mira_last_error() == b"failed to fill whole buffer"
+    assert emu_lib.c.mira_msm_register_bases_file(5, str(tmp_path / "short.bin").encode(), 2, 0, ctypes.byref(h)) == _lib_mod.MIRA_E_BAD_ARG
+    # the all-zero file is 16 identity points: loads, validates (the identity passes is_on_curve), commits to the identity
+    (tmp_path / "zeros.bin").write_bytes(b"\0" * (16 * 64))
+    key = cm.CommitmentKey.load_from_file(0, tmp_path / "zeros.bin", 4, lib=emu_lib, validate=True)
+    assert not key.commit(C.synth_scalars(0, 16, seed=3)).any()
+    key.close()

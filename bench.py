@@ -197,7 +197,10 @@ def main():
     stages = {k: v / args.steps for k, v in stage_acc.items()}
     t_acc = stages.get("accumulate", 0.0)
     achieved = (MSM_BYTES_PER_PAIR * n / (t_acc * 1e-3) / 1e9) if t_acc > 0 else None
-    adds_per_pair = (256 + args.window_bits - 1) // args.window_bits
+    used_c, used_w = ctypes.c_int32(), ctypes.c_int32()
+    lib.check(lib.c.mira_msm_last_plan(ctypes.byref(used_c), ctypes.byref(used_w)))
+    window_bits = args.window_bits or used_c.value or 16       # --window-bits 0: whatever the planner (or the sharded key) chose
+    adds_per_pair = (256 + window_bits - 1) // window_bits
 
     out = {
         "metric": "bn256_g1_msm_throughput", "value": round(value, 3), "unit": "M scalar-point pairs/s",
@@ -207,8 +210,8 @@ def main():
         "data": ("synthetic -- CPU EMULATION REHEARSAL of the launch path, not a measurement" if args.emulate else
                  "synthetic -- REHEARSAL: every rank on GPU 0, gloo exchange; not a measurement" if args.rehearse_one_gpu else "synthetic"),
         "config": {"workload": (f"BN256 G1 MSM 2^{total_log_n} pairs point-sharded over {n_gpus} GPU(s)" if strong else f"BN256 G1 MSM 2^{log_n} pairs per GPU")
-                               + f" via CommitmentKey::commit, {args.window_bits}-bit signed windows",
-                   "pairs_per_gpu": n, "total_pairs": total, "window_bits": args.window_bits,
+                               + f" via CommitmentKey::commit, {window_bits}-bit signed windows",
+                   "pairs_per_gpu": n, "total_pairs": total, "window_bits": window_bits,
                    "parallelism": f"point-chunk x{n_gpus}" if n_gpus > 1 else "single GPU",
                    "inputs": "uniform Fr scalars, bases k_i*G, resident in HBM"},
         "roofline": {"bound": "hbm", "kernel": "k_accumulate", "achieved": None if achieved is None else round(achieved, 2),
@@ -227,12 +230,15 @@ def main():
                                  "(profiles/r01_b_microbench_f29.txt)"},
                      "note": "integer-ALU bound (about 160 modular multiplications per pair); see DESIGN.md section 4"},
         "stages_ms": {k: round(v, 4) for k, v in stages.items()},
+        # the commitment of the last timed step, x || y as 8 little-endian u64 limbs (Montgomery form): lets a test
+        # compare a multi-rank run with the oracle's point for the same synthetic inputs
+        "result_affine_u64": [hex(int(v)) for v in np.asarray(result, dtype=np.uint64).reshape(-1)],
     }
 
     if strong and n_gpus > 1 and dist is not None and not args.emulate and not args.no_extras:
         out["extras"] = multi_gpu_extras(lib, cm, dist, rank, n_gpus, total_log_n, args)
     if rank == 0 and n_gpus == 1 and not args.no_cpu:
-        out["cpu_baseline"], parity = cpu_baseline_msm(lib, cm, key, d_scalars, n, args.window_bits)
+        out["cpu_baseline"], parity = cpu_baseline_msm(lib, cm, key, d_scalars, n, window_bits)
         out["parity"] = parity
     if rank == 0 and n_gpus == 1 and not args.no_extras:
         out["extras"] = extras(lib, cm, not args.no_cpu)

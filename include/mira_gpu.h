@@ -128,6 +128,9 @@ int mira_msm_set_handle_window_bits(uint64_t handle, int32_t c);
  * whose threads want different widths uses the per-handle call above.  All ranks of a sharded MSM must use the
  * same c. */
 int mira_msm_set_window_bits(int32_t c);
+/* The width the planner picks for a commit of n uniform scalars when it has no statistics of the data (a pure
+ * function of n: every rank of a sharded MSM derives the same width from the same global length). */
+int mira_msm_plan_window_bits(size_t n, int32_t *window_bits);
 /* Diagnostics: the window width and count the planner used for the most recent commit of this
  * process (0 / the number of partial sums in fixed-base table mode). */
 int mira_msm_last_plan(int32_t *window_bits, int32_t *num_windows);

@@ -671,6 +671,11 @@ int mira_set_tuning(int knob, int64_t value) {
     g.tune[knob] = value;
     return MIRA_OK;
 }
+int mira_msm_plan_window_bits(size_t n, int32_t *window_bits) {
+    if (!window_bits) { set_error("null output"); return MIRA_E_BAD_ARG; }
+    *window_bits = (int32_t)make_plan(std::max<size_t>(n, 1), 0).c;
+    return MIRA_OK;
+}
 int mira_msm_last_plan(int32_t *window_bits, int32_t *num_windows) {
     std::lock_guard<std::mutex> lk(g_lock);
     if (!window_bits || !num_windows) { set_error("null output"); return MIRA_E_BAD_ARG; }

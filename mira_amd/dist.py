@@ -7,6 +7,8 @@ W * 128 bytes per rank (elliptic-curve addition is not an RCCL reduction operato
 all-gather + local add is the "reduce"); every rank then holds the same affine commitment.
 Message size is <= 8 KiB per rank: latency-bound, xGMI bandwidth is irrelevant.
 """
+import ctypes
+
 import numpy as np
 
 from . import _lib
@@ -54,34 +56,48 @@ class ShardedCommitmentKey:
         """How many of the first n_global pairs live on this rank."""
         return max(0, min(self.hi, n_global) - self.lo)
 
-    def _all_gather(self, part_words):
-        import torch
-        backend = self.dist.get_backend(self.group)
-        dev = "cuda" if backend == "nccl" else "cpu"
-        mine = torch.from_numpy(part_words.view(np.int64)).to(dev)
-        out = torch.empty(self.world * mine.numel(), dtype=torch.int64, device=dev)
-        self.dist.all_gather_into_tensor(out, mine, group=self.group)
-        return out.cpu().numpy().view(np.uint64).reshape(self.world, -1)
-
     def _agreed_window_bits(self, n_global):
         """Every rank must cut its scalars into the same windows, but the ranks' chunk lengths differ
         (a prefix of the key ends inside one rank's chunk), so the width cannot be left to each
-        rank's planner: it is derived from the global length, which all ranks know."""
+        rank's planner with its own length and statistics: it is the planner's choice for the LARGEST chunk
+        of the global length (mira_msm_plan_window_bits), which all ranks compute alike."""
         if self.window_bits:
             return self.window_bits
-        per_rank = -(-n_global // self.world)
-        return 13 if per_rank < (1 << 18) else 15 if per_rank < (1 << 21) else 16
+        c = ctypes.c_int32()
+        self.lib.check(self.lib.c.mira_msm_plan_window_bits(-(-n_global // self.world), ctypes.byref(c)))
+        return c.value
 
     def commit_device(self, d_scalars_local, n_global):
         """src/commitment.rs:78-87 over the sharded key; every rank returns the same point.
-        Fixed-base tables (`precompute()`) must be built on all ranks or on none."""
+        Fixed-base tables (`precompute()`) must be built on all ranks or on none.
+
+        The partial stays in device memory: mira_msm_partial_to_device writes the window sums into the tensor the
+        all-gather reads (RCCL over xGMI), and ONE device-to-host copy of world * W * 128 bytes follows the gather;
+        the G - 1 additions per window, Horner and to_affine run on the host (mira_msm_combine)."""
+        import torch
         if n_global > self.total_len:
             raise TooLongInput(n_global, self.total_len)
         n_local = self.local_prefix(n_global)
         # table partials have one layout whatever the length; otherwise every rank names the same width
         tables = getattr(self.key, "precomputed", False)
-        part, c, w = self.key.commit_partial_device(0, d_scalars_local, n_local, window_bits=0 if tables else self._agreed_window_bits(n_global))
-        gathered = self._all_gather(np.ascontiguousarray(part[: w * 16]))
-        parts = np.zeros((self.world, _lib.MIRA_PARTIAL_U64), dtype=np.uint64)
+        width = 0 if tables else self._agreed_window_bits(n_global)
+        words = _lib.MIRA_PARTIAL_U64
+        if self.dist.get_backend(self.group) == "nccl":
+            mine = torch.empty(words, dtype=torch.int64, device="cuda")
+            c, w = self.key.commit_partial_to_device(0, d_scalars_local, n_local, mine.data_ptr(), window_bits=width)   # synchronises the library's stream
+            out = torch.empty(self.world * w * 16, dtype=torch.int64, device="cuda")
+            self.dist.all_gather_into_tensor(out, mine[: w * 16], group=self.group)
+            gathered = out.cpu().numpy().view(np.uint64).reshape(self.world, w * 16)
+        else:                                                  # gloo (CPU tests, one-GPU rehearsal): the same partial, through host memory
+            d_part = self.lib.alloc(words * 8)
+            try:
+                c, w = self.key.commit_partial_to_device(0, d_scalars_local, n_local, d_part, window_bits=width)
+                mine = torch.from_numpy(self.lib.download(d_part, (words,))[: w * 16].view(np.int64).copy())
+            finally:
+                self.lib.free(d_part)
+            out = torch.empty(self.world * w * 16, dtype=torch.int64)
+            self.dist.all_gather_into_tensor(out, mine, group=self.group)
+            gathered = out.numpy().view(np.uint64).reshape(self.world, w * 16)
+        parts = np.zeros((self.world, words), dtype=np.uint64)
         parts[:, : w * 16] = gathered
         return combine_partials(self.curve, parts, c, w, lib=self.lib)

@@ -10,9 +10,9 @@
 #include <unistd.h>
 
 #ifdef MIRA_CPU_EMU
-static constexpr uint32_t FIXUP_HEAVY_GRID = 4;     // emulated lanes are OS threads: keep the idle grid small
+static constexpr uint32_t FIXUP_HEAVY_GRID = 4;     // emulated lanes are OS threads: keep the idle grid small (stage A: a quarter of it)
 #else
-static constexpr uint32_t FIXUP_HEAVY_GRID = 4096;   // waves of stage A (a quarter as many 256-lane workgroups in stage B); idle ones leave at once
+static constexpr uint32_t FIXUP_HEAVY_GRID = 1024;   // waves of either heavy stage = 256 workgroups of 256 lanes, one per CU (the sub-jobs of stage A are sized to just fill them; dispatching 1024 mostly idle workgroups alone took 15 us)
 #endif
 
 // quads for the bucket reduction while its work items number less than ~1.5 waves per SIMD (the
@@ -198,10 +198,10 @@ static int msm_launch_body(const Bases &bs, size_t first, const void *d_scalars,
         LAUNCH(k_fixup<F>, ceil_div((uint64_t)(fix_by_bucket ? fix_by_bucket : p.T) * 4, 128), 128, 0, st, (const uint32_t *)plan, reinterpret_cast<const uint32_t *>(g.offsets.p),
                reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
                reinterpret_cast<const uint32_t *>(g.tail_key.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p), heavy_count, heavy_runs, heavy_subs, fix_by_bucket);
-        LAUNCH_BARRIER(k_fixup_heavy_a<F>, FIXUP_HEAVY_GRID, HEAVY_BLOCK_A, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_subs, (const U4 *)heavy_runs,
+        LAUNCH_BARRIER(k_fixup_heavy_a<F>, (FIXUP_HEAVY_GRID + 3) / 4, HEAVY_BLOCK_A, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_subs, (const U4 *)heavy_runs,
                        reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
                        reinterpret_cast<unsigned char *>(g.heavy_out.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p));
-        LAUNCH_BARRIER(k_fixup_heavy_b<F>, FIXUP_HEAVY_GRID / 4, HEAVY_BLOCK_B, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_runs,
+        LAUNCH_BARRIER(k_fixup_heavy_b<F>, (FIXUP_HEAVY_GRID + 3) / 4, HEAVY_BLOCK_B, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_runs,
                        reinterpret_cast<const unsigned char *>(g.heavy_out.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
                        reinterpret_cast<unsigned char *>(g.bucket_sums.p));
         tm_mark("fixup");
@@ -399,10 +399,10 @@ static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars
     LAUNCH(k_fixup<F>, ceil_div((uint64_t)T * 4, 128), 128, 0, st, (const uint32_t *)plan, reinterpret_cast<const uint32_t *>(g.offsets.p),
            reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
            reinterpret_cast<const uint32_t *>(g.tail_key.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p), heavy_count, heavy_runs, heavy_subs, 0u);
-    LAUNCH_BARRIER(k_fixup_heavy_a<F>, FIXUP_HEAVY_GRID, HEAVY_BLOCK_A, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_subs, (const U4 *)heavy_runs,
+    LAUNCH_BARRIER(k_fixup_heavy_a<F>, (FIXUP_HEAVY_GRID + 3) / 4, HEAVY_BLOCK_A, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_subs, (const U4 *)heavy_runs,
                    reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
                    reinterpret_cast<unsigned char *>(g.heavy_out.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p));
-    LAUNCH_BARRIER(k_fixup_heavy_b<F>, FIXUP_HEAVY_GRID / 4, HEAVY_BLOCK_B, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_runs,
+    LAUNCH_BARRIER(k_fixup_heavy_b<F>, (FIXUP_HEAVY_GRID + 3) / 4, HEAVY_BLOCK_B, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_runs,
                    reinterpret_cast<const unsigned char *>(g.heavy_out.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
                    reinterpret_cast<unsigned char *>(g.bucket_sums.p));
     tm_mark("fixup");

@@ -24,7 +24,10 @@
 #include "quad29.cuh"
 
 static constexpr uint32_t KEY_NONE = 0xFFFFFFFFu;
-static constexpr int HEAVY_SPAN = 6;        // chains longer than this go to k_fixup_heavy (a lane adds ~6.6 us per link)
+// Chains longer than this go to k_fixup_heavy (a quad adds a link in ~2.2 us plus the load of the partial).  Raising it
+// to 16 was measured: commits whose longest chains are 7 .. 16 links gain, but wherever the heavy stages run anyway the
+// medium chains then sit in k_fixup for 100 us (2^13 pairs under 5-bit windows: 57 -> 158 us) -- the threshold stays.
+static constexpr int HEAVY_SPAN = 6;
 static constexpr int WSUM_BLOCK = 512;       // k_window_sum: 128 quads
 
 // ------------------------------------------------------------------------------------------
@@ -203,7 +206,7 @@ KERNEL void k_scan_c(const uint32_t *__restrict__ counts, uint32_t NB, const uin
                     if (L < min_L) L = min_L;
                     plan[0] = L;
                     plan[1] = (uint32_t)(((uint64_t)run + L - 1) / L);
-                    heavy_ctr[0] = 0; heavy_ctr[1] = 0;
+                    heavy_ctr[0] = 0; heavy_ctr[1] = 0; heavy_ctr[4] = 0;
                 }
             }
         }
@@ -422,6 +425,7 @@ KERNEL void __launch_bounds__(128) k_fixup(const uint32_t *__restrict__ plan, co
         const uint32_t nsub = (span + HEAVY_SUB - 1) / HEAVY_SUB;
         const uint32_t h = atomicAdd(&heavy_ctr[0], 1u);
         const uint32_t base = atomicAdd(&heavy_ctr[1], nsub);
+        if (nsub > 1) atomicAdd(&heavy_ctr[4], 1u);
         runs[h] = U4{t, span, key, base};
         for (uint32_t s = 0; s < nsub; s++) {
             const uint32_t first = t + 1 + s * HEAVY_SUB;
@@ -451,31 +455,63 @@ template <class F> DEV void block_tree_sum_quad(Xyzz29<F> &acc, unsigned char *r
         __syncthreads();
     }
 }
-// stage A: one wave of 16 quads per sub-job (grid-stride): sub_out[s] = sum of its <= 64 head
-// partials (each quad first adds up to 4 of them, then a 4-level LDS tree).  Most heavy runs are a
-// few dozen partials (dense vectors under narrow windows make EVERY bucket one): wave-sized jobs keep
-// all of them in flight at once; a 256-lane workgroup per job took 25 ns per run, 0.2 - 0.6 ms at 2^17.
-static constexpr uint32_t HEAVY_BLOCK_A = 64, HEAVY_BLOCK_B = 256;
+// LDS tree inside groups of `gq` consecutive quads (gq a power of two <= blockDim.x / 4): the sum of the values of the
+// first `cnt` quads of a group ends in the group's quad 0.  cnt may differ between groups; the loop bounds do not.
+template <class F> DEV void group_tree_sum_quad(Xyzz29<F> &acc, unsigned char *red, uint32_t gq, uint32_t cnt) {
+    const uint32_t qi = threadIdx.x >> 2, ql = qi & (gq - 1u);
+    if (quad_lane() == 0) xyzz29_store(red + qi * XYZZ29_BYTES, acc);
+    __syncthreads();
+    for (uint32_t st = gq >> 1; st > 0; st >>= 1) {
+        if (ql < st && ql + st < cnt) {
+            xyzz29_add_quad(acc, xyzz29_load<F>(red + (qi + st) * XYZZ29_BYTES));
+            if (quad_lane() == 0) xyzz29_store(red + qi * XYZZ29_BYTES, acc);
+        }
+        __syncthreads();
+    }
+}
+// stage A: sub_out[s] = sum of the <= 64 head partials of sub-job s.  One wave = 16 quads works on 16 / gq sub-jobs at
+// a time, gq quads each: every quad first adds its share of the partials, then an LDS tree over the gq quads.  A
+// quad addition costs ~4 100 issue cycles whatever the number of busy quads, so the kernel is bound by
+// max(chain of one wave, waves per SIMD x chain): with few sub-jobs a whole wave per sub-job (gq = 16: chain 4 + 4)
+// is fastest; when EVERY bucket is a heavy run (dense vectors under narrow windows: 4 096 sub-jobs at 2^17 pairs,
+// c = 8) that puts four waves on every SIMD, half of whose additions are idle tree levels -- 89 us.  gq is
+// therefore chosen so that the waves just cover the 1 024 SIMDs: 16 384 / sub-jobs, between 2 and 16.
+// Workgroups of 256 lanes (64 quads, four waves on the four SIMDs of a CU): 64-lane workgroups were seen packed onto a
+// fraction of the CUs, several chains sharing a SIMD while others idle.  heavy_ctr[4] counts the runs that stage B
+// still has to finish (more than one sub-job).
+static constexpr uint32_t HEAVY_BLOCK_A = 256, HEAVY_BLOCK_B = 256;
 // A run that is one sub-job (<= HEAVY_SUB partials: the usual case) is finished here -- tail partial
 // added, bucket written -- and stage B skips it.
 template <class F>
-KERNEL void __launch_bounds__(64) k_fixup_heavy_a(const uint32_t *__restrict__ heavy_ctr, const U4 *__restrict__ subs, const U4 *__restrict__ runs,
+KERNEL void __launch_bounds__(256) k_fixup_heavy_a(const uint32_t *__restrict__ heavy_ctr, const U4 *__restrict__ subs, const U4 *__restrict__ runs,
                           const unsigned char *__restrict__ head_part, const unsigned char *__restrict__ tail_part,
                           unsigned char *__restrict__ sub_out, unsigned char *__restrict__ bucket_sums) {
     __shared__ __attribute__((aligned(16))) unsigned char red[(HEAVY_BLOCK_A / 4) * XYZZ29_BYTES];
-    const uint32_t nsubs = heavy_ctr[1], qi = threadIdx.x >> 2, nq = blockDim.x >> 2;
-    for (uint32_t s = blockIdx.x; s < nsubs; s += gridDim.x) {
-        const U4 d = subs[s];
+    const uint32_t nsubs = heavy_ctr[1], qi = threadIdx.x >> 2;
+    const uint32_t lg = nsubs > 4096 ? 1u : nsubs > 2048 ? 2u : nsubs > 1024 ? 3u : 4u;        // quads per sub-job = 2^lg
+    const uint32_t gq = 1u << lg, spb = (HEAVY_BLOCK_A / 4) >> lg, ql = qi & (gq - 1u);       // sub-jobs per workgroup
+    for (uint32_t s0 = blockIdx.x * spb; s0 < nsubs; s0 += gridDim.x * spb) {
+        const uint32_t s = s0 + (qi >> lg);
+        const bool active = s < nsubs;
+        const U4 d = active ? subs[s] : U4{0, 0, 0, 0};
         Xyzz29<F> acc = xyzz29_identity<F>();
-        for (uint32_t q = qi; q < d.y; q += nq)
-            xyzz29_add_quad(acc, xyzz29_load<F>(head_part + (size_t)(d.x + q) * XYZZ29_BYTES));
-        block_tree_sum_quad(acc, red, d.y < nq ? d.y : nq);
-        if (qi == 0) {
+        if (ql < d.y) {
+            // the next partial is fetched before the current one is added (its index clamped: the last fetch is unused)
+            Xyzz29<F> nxt = xyzz29_load<F>(head_part + (size_t)(d.x + ql) * XYZZ29_BYTES);
+            for (uint32_t q = ql; q < d.y; q += gq) {
+                const Xyzz29<F> cur = nxt;
+                const uint32_t qn = q + gq < d.y ? q + gq : q;
+                nxt = xyzz29_load<F>(head_part + (size_t)(d.x + qn) * XYZZ29_BYTES);
+                xyzz29_add_quad(acc, cur);
+            }
+        }
+        group_tree_sum_quad(acc, red, gq, d.y < gq ? d.y : gq);
+        if (active && ql == 0) {
             const U4 r = runs[d.z];                                // {lane, span, bucket, first sub-job}
             if (r.y <= HEAVY_SUB) {
                 xyzz29_add_quad(acc, xyzz29_load<F>(tail_part + (size_t)r.x * XYZZ29_BYTES));
-                if (threadIdx.x == 0) xyzz29_store(bucket_sums + (size_t)r.z * XYZZ29_BYTES, acc);
-            } else if (threadIdx.x == 0) {
+                if (quad_lane() == 0) xyzz29_store(bucket_sums + (size_t)r.z * XYZZ29_BYTES, acc);
+            } else if (quad_lane() == 0) {
                 xyzz29_store(sub_out + (size_t)s * XYZZ29_BYTES, acc);
             }
         }
@@ -488,6 +524,7 @@ KERNEL void __launch_bounds__(256) k_fixup_heavy_b(const uint32_t *__restrict__ 
                           const unsigned char *__restrict__ sub_out, const unsigned char *__restrict__ tail_part,
                           unsigned char *__restrict__ bucket_sums) {
     __shared__ __attribute__((aligned(16))) unsigned char red[(HEAVY_BLOCK_B / 4) * XYZZ29_BYTES];
+    if (heavy_ctr[4] == 0) return;                                 // every heavy run was one sub-job: stage A finished them all
     const uint32_t nruns = heavy_ctr[0], qi = threadIdx.x >> 2, nq = blockDim.x >> 2;
     for (uint32_t h = blockIdx.x; h < nruns; h += gridDim.x) {
         const U4 r = runs[h];                                      // {lane, span, bucket, first sub-job}

@@ -333,3 +333,16 @@ def test_emu_host_scalars_in_chunks(emu_lib, tune):
             assert (key.commit(sc[:33]) == C.commit(cid, bs[:33], sc[:33])).all()      # below the threshold: one chunk
         finally:
             emu_lib.check(emu_lib.c.mira_msm_set_window_bits(0))
+
+
+@pytest.mark.parametrize("n,c", [(20000, 4), (36000, 4)])
+def test_emu_heavy_subjob_grouping(emu_lib, n, c):
+    """k_fixup_heavy_a gives a sub-job 16, 8, 4 or 2 quads by the number of sub-jobs: 4-bit windows over a few 10^4
+    dense scalars make every bucket a heavy run of several sub-jobs -- 1 536 sub-jobs (8 quads each) and 2 560 (4 quads)."""
+    cid = 1
+    key = cm.CommitmentKey.synthetic(cid, n, seed=17, lib=emu_lib)
+    key.set_window_bits(c)
+    d = cm.synth_scalars_device(cid, n, seed=18, lib=emu_lib)
+    sc = emu_lib.download(d, (n, 4))
+    assert (key.commit_device(d, n) == C.msm_pippenger(cid, sc, key.download())).all()
+    emu_lib.free(d); key.close()

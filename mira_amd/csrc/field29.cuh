@@ -284,6 +284,31 @@ template <class F> HD Fe29<F> f29_mul2_add(const Fe29<F> &a, const Fe29<F> &b, c
     F29_SET(r, (F29_GET(a) * F29_GET(b) + F29_GET(c2) * F29_GET(d)) / 168.9 + 1.0);
     return r;
 }
+// Montgomery reduction alone: a * 2^-261 mod P -- half a multiplication (81 reduction products, no a * b).  Limbs of a
+// up to 2^32 (a column holds one limb, nine reduction products < 2^58 and a carry); result loose, < a / (2^261 P) + 1.
+// The NTT's last pass ends with it: the pass before has multiplied every element by 2^261 (and the ifft scale) inside
+// its post-twiddle, so the value that leaves is exact and < 2 P.
+template <class F> HD Fe29<F> f29_redc(const Fe29<F> &a) {
+    uint64_t c[18];
+#pragma unroll
+    for (int k = 0; k < 9; k++) { c[k] = a.l[k]; c[k + 9] = 0; }
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        uint32_t m = ((uint32_t)c[k] * F::N0) & M29;
+#pragma unroll
+        for (int j = 0; j < 9; j++) c[k + j] += (uint64_t)m * F::P[j];
+        c[k + 1] += c[k] >> 29;
+    }
+    Fe29<F> r;
+#pragma unroll
+    for (int i = 9; i < 17; i++) {
+        r.l[i - 9] = (uint32_t)c[i] & M29;
+        c[i + 1] += c[i] >> 29;
+    }
+    r.l[8] = (uint32_t)c[17];
+    F29_SET(r, F29_GET(a) / 168.9 + 1.0);
+    return r;
+}
 template <class F> HD Fe29<F> f29_sqr(const Fe29<F> &a) {
     F29_ASSERT(F29_GET(a) * F29_GET(a) <= F29_RP_OVER_P);
     uint64_t c[18];

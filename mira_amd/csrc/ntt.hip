@@ -58,7 +58,9 @@ static uint32_t ntt_max_log_line(uint32_t log_n) {
     const int v = (int)g.tune[MIRA_TUNE_NTT_MAX_LOG_LINE];
     return (uint32_t)std::min(std::max(v, 1), NTT_MAX_LOG_LINE);
 }
-static int ntt_prepare_tables(uint32_t log_n, const uint64_t omega[4], NttTables &t, bool want_full = true) {
+// scale261 (reference Montgomery form): what the post-twiddle feeding the LAST pass is multiplied by -- 2^261 times the
+// transform's final scale -- so that the last pass ends with a Montgomery reduction instead of a multiplication.
+static int ntt_prepare_tables(uint32_t log_n, const uint64_t omega[4], const HFr &scale261, NttTables &t, bool want_full = true) {
     const uint32_t max_line = ntt_max_log_line(log_n);
     t.passes = log_n <= max_line ? 1 : log_n <= 2 * max_line ? 2 : 3;
     uint32_t rest = log_n;
@@ -87,6 +89,7 @@ static int ntt_prepare_tables(uint32_t log_n, const uint64_t omega[4], NttTables
     t.off_full = off;
     if (full0) off += ((size_t)TW_BYTES) << log_n;
     std::string key((const char *)omega, 32);
+    key.append((const char *)scale261.l, 32);
     key += std::to_string(log_n) + "/" + std::to_string(max_line) + "/" + std::to_string(single_log) + (full0 ? "/full" : "");
     // four cached sets, least recently used replaced: fft and ifft of two sizes alternate without rebuilding
     int slot = -1, lru = 0;
@@ -106,21 +109,24 @@ static int ntt_prepare_tables(uint32_t log_n, const uint64_t omega[4], NttTables
     if (g.ntt_set[slot].cap > 4 * off + ((size_t)1 << 20)) g.ntt_set[slot].release();
     if ((rc = g.ntt_set[slot].ensure(off))) {
         // the n-entry table is an optimisation: without the memory for it the two-table product still works
-        if (full0) return ntt_prepare_tables(log_n, omega, t, false);
+        if (full0) return ntt_prepare_tables(log_n, omega, scale261, t, false);
         return rc;
     }
     if ((rc = g.ntt_consts.ensure(256))) return rc;
     RT_CHECK(rt_h2d(g.ntt_consts.p, omega, 32, g.stream));
+    RT_CHECK(rt_h2d(reinterpret_cast<unsigned char *>(g.ntt_consts.p) + 32, scale261.l, 32, g.stream));
     unsigned char *tab = reinterpret_cast<unsigned char *>(g.ntt_set[slot].p);
-    const unsigned char *w = reinterpret_cast<const unsigned char *>(g.ntt_consts.p);
+    const unsigned char *w = reinterpret_cast<const unsigned char *>(g.ntt_consts.p), *w_scale = w + 32;
     const unsigned char *none = nullptr;
     const uint64_t n = (uint64_t)1 << log_n;
     for (uint32_t p = 0; p < t.passes; p++)
         LAUNCH(k_pow_table<Fr29>, ceil_div(n_tw[p], 256), 256, 0, g.stream, w, n >> t.m[p], (uint32_t)n_tw[p], none, tab + t.off_tw[p]);
     for (uint32_t q = 0; q + 1 < t.passes; q++) {
         const uint64_t base_stride = q == 0 ? 1 : (uint64_t)1 << t.m[0];   // omega_n, then omega_n^(n1)
-        LAUNCH(k_pow_table<Fr29>, ceil_div(n_lo[q], 256), 256, 0, g.stream, w, base_stride, (uint32_t)n_lo[q], none, tab + t.off_lo[q]);
-        LAUNCH(k_pow_table<Fr29>, ceil_div(n_hi[q], 256), 256, 0, g.stream, w, base_stride << t.h[q], (uint32_t)n_hi[q], none, tab + t.off_hi[q]);
+        // the boundary in front of the last pass carries the final scale: on its only table, or on the high one of two
+        const bool last = q + 2 == t.passes, lo_only = t.single[q] == 1;
+        LAUNCH(k_pow_table<Fr29>, ceil_div(n_lo[q], 256), 256, 0, g.stream, w, base_stride, (uint32_t)n_lo[q], last && lo_only ? w_scale : none, tab + t.off_lo[q]);
+        LAUNCH(k_pow_table<Fr29>, ceil_div(n_hi[q], 256), 256, 0, g.stream, w, base_stride << t.h[q], (uint32_t)n_hi[q], last && !lo_only ? w_scale : none, tab + t.off_hi[q]);
     }
     if (full0)
         LAUNCH(k_tw_full<Fr29>, ceil_div(n, 256), 256, 0, g.stream, (const unsigned char *)(tab + t.off_lo[0]), (const unsigned char *)(tab + t.off_hi[0]), t.h[0], t.m[0], n,
@@ -149,7 +155,12 @@ static int ntt_device_locked(void *d_a, uint32_t log_n, const uint64_t omega[4],
     if (log_n > 3 * ntt_max_log_line(log_n)) { set_error("log_n exceeds three passes of the configured line length"); return MIRA_E_UNSUPPORTED; }
     NttTables t;
     tm_begin();
-    if ((rc = ntt_prepare_tables(log_n, omega, t))) return rc;
+    // the final scale (ifft: TWO_INV^log_n, else one) rides on the post-twiddle in front of the last pass, times 2^261:
+    // mont(s * 2^261) = s_mont * 32 * R^2 / R^2 ... in this library's terms mul(mul(s, 32), R^2)
+    HFr s_final = hostf::one<FrP>();
+    if (scale) memcpy(s_final.l, scale, 32);
+    const HFr scale261 = hostf::mul(hostf::mul(s_final, hostf::from_u64<FrP>(32)), hostf::r2<FrP>());
+    if ((rc = ntt_prepare_tables(log_n, omega, scale261, t))) return rc;
     tm_mark("twiddle_tables");
     const unsigned char *tab = reinterpret_cast<const unsigned char *>(g.ntt_set[g.ntt_set_cur].p);
     unsigned char *scale_d = nullptr;
@@ -186,7 +197,7 @@ static int ntt_device_locked(void *d_a, uint32_t log_n, const uint64_t omega[4],
             // (line l starts at (l >> split) * hi + (l & mask) * lo) and the pass has only whole tiles
             const uint64_t tl = (uint64_t)NTTW_WAVES * lpw;
             auto adjacent = [&](uint64_t hi, uint64_t lo) { return ps.split == 0 ? hi == 1 : (lo == 1 && tl <= ((uint64_t)1 << ps.split)); };
-            if (NTTW_WAVES == 4 && ps.nlines % tl == 0)
+            if (NTTW_WAVES == 4 && ps.nlines % tl == 0 && ps.log_len >= 3)   // (the tile copy loops walk 8 columns per lane: lines of 8 points and more)
                 ps.coop = (adjacent(ps.in_hi, ps.in_lo) ? 1u : 0u) | (adjacent(ps.out_hi, ps.out_lo) ? 2u : 0u);
 #define NTTW_LAUNCH(COOP)                                                                                                                                  \
     LAUNCH_BARRIER((k_ntt_wave<Fr29, COOP>), std::min<uint32_t>(nbg, NTT_PERSISTENT_GRID * 3), 64 * NTTW_WAVES, NTTW_LDS_BYTES, g.stream, src, dst, ps,       \
@@ -216,12 +227,12 @@ static int ntt_device_locked(void *d_a, uint32_t log_n, const uint64_t omega[4],
         unsigned char *tmp = reinterpret_cast<unsigned char *>(g.ntt_tmp.p);
         if (t.passes == 2) {
             run(NttPass{t.m[0], (uint32_t)n2, 0, 0, 1, 0, n2, n1, 0, 1, t.h[0], t.single[0], 0u, 0u}, a, tmp, 0, 0, "ntt_pass1");
-            run(NttPass{t.m[1], (uint32_t)n1, 0, 0, 1, 0, n1, 1, 0, n1, NONE, 0u, 0u, 0u}, tmp, a, 1, -1, "ntt_pass2");
+            run(NttPass{t.m[1], (uint32_t)n1, 0, 0, 1, 0, n1, 1, 0, n1, NONE, 0u, 0u, 1u}, tmp, a, 1, -1, "ntt_pass2");
         } else {
             const uint64_t m = n2 * n3;
             run(NttPass{t.m[0], (uint32_t)m, 0, 0, 1, 0, m, n1, 0, 1, t.h[0], t.single[0], 0u, 0u}, a, tmp, 0, 0, "ntt_pass1");
             run(NttPass{t.m[1], (uint32_t)(n1 * n3), t.m[0], t.m[0], n1, 1, n3 * n1, n1 * n2, 1, n1, t.h[1], t.single[1], 0u, 0u}, tmp, a, 1, 1, "ntt_pass2");
-            run(NttPass{t.m[2], (uint32_t)(n1 * n2), 0, 0, 1, 0, n1 * n2, 1, 0, n1 * n2, NONE, 0u, 0u, 0u}, a, a, 2, -1, "ntt_pass3");
+            run(NttPass{t.m[2], (uint32_t)(n1 * n2), 0, 0, 1, 0, n1 * n2, 1, 0, n1 * n2, NONE, 0u, 0u, 1u}, a, a, 2, -1, "ntt_pass3");
         }
     }
     RT_CHECK(rt_last());

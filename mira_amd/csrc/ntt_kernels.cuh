@@ -79,7 +79,7 @@ struct NttPass {
     uint32_t tw_shift;         // post-twiddle w^e = T_hi[e >> tw_shift] * T_lo[e & mask]; 0xFFFFFFFF = none
     uint32_t tw_single;        // 1: the exponent range fits T_lo alone (w^e = T_lo[e], no product); 2: T_lo holds the twiddle of EVERY element, T_lo[line << log_len | k]
     uint32_t coop;             // k_ntt_wave: bit 0 / bit 1 = the lines of a workgroup are adjacent in the input / output
-    uint32_t reserved;
+    uint32_t prescaled;        // last pass only: the pass before left every element times 2^261 (times the ifft scale): finish with f29_redc, not a product
 };
 
 // One workgroup per line.  blockDim.x = max(64, N/2) capped at 1024.  dynamic LDS = N * 36 B + 16 + 256 * 36 B.
@@ -197,6 +197,8 @@ KERNEL void __launch_bounds__(1024) k_ntt_lines(const unsigned char *__restrict_
                 Fe29<F> tw = ps.tw_single ? tw_load<F>(t_lo + (size_t)e * TW_BYTES)
                                           : f29_mul(tw_load<F>(t_hi + (size_t)(e >> ps.tw_shift) * TW_BYTES), tw_load<F>(t_lo + (size_t)(e & lo_mask) * TW_BYTES));
                 v = f29_mul(v, tw);
+            } else if (ps.prescaled) {
+                v = f29_redc(v);
             } else {
                 v = f29_mul(v, tw_load<F>(scale));
             }
@@ -236,9 +238,28 @@ static constexpr size_t NTTW_LDS_BYTES = (size_t)NTTW_WAVES * 9 * NTTW_PLANE * 4
 // (NttPass::coop), the workgroup moves them as ONE tile: every 8 consecutive lanes read or write 128
 // contiguous bytes, and the tile goes through LDS (aliasing the exchange planes, hence the
 // barriers) to hand each wave its own lines.
-// 16-byte slot of column `pos` of tile row i (second half at + 1); the XOR spreads the columns a
-// half-wave reads (pos = 4 lane + r) over all banks
-HD uint32_t nttw_tslot(uint32_t i, uint32_t pos, uint32_t m) { return ((((i << m) | pos) ^ ((pos >> 3) & 7u)) << 1); }
+// Tile layouts: 2048 slots of 16 bytes, slot(e, h) for half h of element e = row << m | position (10 bits).  The four
+// accesses want different things of the low slot bits (= the bank group: ds_write_b128 serves 8 consecutive lanes per
+// LDS cycle and is conflict-free when their slots differ mod 8, ds_read_b128 serves 16 lanes -- {0-3, 12-15, 20-27},
+// {4-11, 16-19, 28-31} and the same + 32 -- and wants them different mod 16; MI355X_MICROARCH.md, LDS):
+//   fill   8 lanes = both halves of rows i .. i + 3 at one position        -> low 3 bits from (h, row & 3)
+//   take   16 lanes = one half of elements e0 + 4 L + r, L as above        -> low 4 bits from e bits 2 .. 5
+//   give   8 lanes = one half of 8 consecutive elements                    -> low 3 bits from e bits 0 .. 2
+//   drain  16 lanes = both halves of rows (0, 1) or (2, 3) at 4 positions  -> low 4 bits from (h, row & 3, position & 1)
+// One layout cannot serve all four (the first version's, e ^ (pos >> 3 & 7), left fill 4-way and take / drain 2-way
+// conflicted: 34 M conflict cycles of 88 M LDS cycles per pass, profiles/r03_a_ntt2p24_pmc.txt), but fill / take and
+// give / drain never meet in one tile, so each pair gets its own.  Both are bijections for every m (the XOR mixes
+// low bits with a function of high ones only); the conflict-free claims hold for m >= 6, the sizes tiles are used at.
+HD uint32_t nttw_tslot_in(uint32_t e, uint32_t h, uint32_t m) {
+    const uint32_t hb = m > 6u ? m : 6u;
+    const uint32_t a = (((h << 6) | ((e & 3u) << 4) | (e >> 6)) << 4) | ((e >> 2) & 15u);
+    return a ^ ((((e >> hb) & 3u) << 1) | h);
+}
+HD uint32_t nttw_tslot_out(uint32_t e, uint32_t h, uint32_t m) {
+    const uint32_t hb = m > 3u ? m : 3u;
+    const uint32_t b = ((e >> 3) << 4) | (h << 3) | (e & 7u), x = e >> hb;
+    return b ^ (((x & 3u) << 1) | (m <= 6u ? (x >> 2) & 1u : 0u));    // 64-point lines: a drain group spans 8 rows of one position
+}
 HD uint32_t nttw_slot(uint32_t p) { return p ^ (((p >> 5) & 1u) * 0x05u) ^ (((p >> 6) & 1u) * 0x1Au); }
 HD uint32_t nttw_pos(uint32_t lane, uint32_t r, uint32_t t) {
     const uint32_t sh = 2 * t;
@@ -312,6 +333,7 @@ template <class F> struct NttwIo {
                                             : f29_mul(tw_load<F>(t_hi + (size_t)(e >> ps.tw_shift) * TW_BYTES), tw_load<F>(t_lo + (size_t)(e & lo_mask) * TW_BYTES));
             return f29_pack(f29_mul(x, tw));
         }
+        if (ps.prescaled) return f29_canonical(f29_redc(x));
         return f29_canonical(f29_mul(x, tw_load<F>(scale)));
     }
     DEV void store(uint32_t line0, uint32_t p, const Fe29<F> &x) const {
@@ -320,40 +342,52 @@ template <class F> struct NttwIo {
         fe_store(dst + (out_start(line) + (size_t)k * ps.out_elem_stride) * 32, finish(line, k, x));
     }
     // ---- workgroup tiles (NttPass::coop): 1024 elements = TL adjacent lines x N points -------------
-    // global -> LDS tile, column q of every row stored at its DIT position brev(q); 8 x 16 bytes per lane
+    // Both layouts are GF(2)-linear in (e, h): slot(e ^ d) = slot(e) ^ slot(d).  Every access below therefore computes
+    // ONE slot per lane and phase with vector instructions and reaches the others (the other half, the other three
+    // points of the lane, the other seven copy iterations) by an XOR with a wave-uniform constant -- the passes are
+    // VALU-bound, and a slot formula evaluated per access cost more than the bank conflicts it removed.
+    // global -> LDS tile, column q of every row stored at its DIT position brev(q); 8 x 16 bytes per lane.  Copy
+    // iteration `it` handles element index e' = it * 128 + tid / 2: the same row, column q0 + it * 2^(m-3), whose DIT
+    // position is brev(q0) | brev3(it).
     DEV void tile_fill(U4 *tile, uint32_t line_blk0) const {
-        const uint32_t log_tl = 10 - m, tl_mask = (1u << log_tl) - 1u;
-        const unsigned char *base = src + in_start(line_blk0) * 32;
+        const uint32_t log_tl = 10 - m, e0 = threadIdx.x >> 1, q0 = e0 >> log_tl, i = e0 & ((1u << log_tl) - 1u), h = threadIdx.x & 1u;
+        const unsigned char *base = src + (in_start(line_blk0) + (size_t)i + (size_t)q0 * ps.in_elem_stride) * 32 + h * 16;
+        const size_t step = ((size_t)ps.in_elem_stride << (m - 3)) * 32;                   // m >= 3 wherever a pass has tiles (TL <= 128 rows)
+        const uint32_t s0 = nttw_tslot_in((i << m) | (m ? (__brev(q0) >> (32 - m)) : 0u), h, m);
 #pragma unroll
         for (int it = 0; it < 8; it++) {                           // (the compiler hoists the eight loads above the LDS stores)
-            const uint32_t c = it * 256 + threadIdx.x, e = c >> 1, q = e >> log_tl, i = e & tl_mask;
-            const U4 v = *reinterpret_cast<const U4 *>(base + ((size_t)i + (size_t)q * ps.in_elem_stride) * 32 + (c & 1u) * 16);
-            tile[nttw_tslot(i, m ? (__brev(q) >> (32 - m)) : 0, m) + (c & 1u)] = v;
+            constexpr uint32_t B3[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+            const U4 v = *reinterpret_cast<const U4 *>(base + (size_t)it * step);
+            tile[s0 ^ nttw_tslot_in(B3[it], 0u, m)] = v;
         }
     }
-    DEV Fe29<F> tile_take(const U4 *tile, uint32_t row0, uint32_t p) const {
+    // this wave's element (wave << 8 | p), p = 4 lane + r: four points of a lane differ in e bits 0, 1
+    DEV uint32_t take_base(uint32_t wave, uint32_t lane) const { return nttw_tslot_in((wave << 8) | (lane << 2), 0u, m); }
+    DEV Fe29<F> tile_take(const U4 *tile, uint32_t tb, uint32_t r) const {
         using S = typename F::Sat;
-        const uint32_t sl = nttw_tslot(row0 + (p >> m), p & (N - 1), m);
-        const U4 a = tile[sl], b = tile[sl + 1];
+        const uint32_t sl = tb ^ nttw_tslot_in(r, 0u, m);
+        const U4 a = tile[sl], b = tile[sl ^ nttw_tslot_in(0u, 1u, m)];
         Fe<S> s;
         s.l[0] = a.x; s.l[1] = a.y; s.l[2] = a.z; s.l[3] = a.w; s.l[4] = b.x; s.l[5] = b.y; s.l[6] = b.z; s.l[7] = b.w;
         return ntt_unpack<F>(s);
     }
-    DEV void tile_give(U4 *tile, uint32_t line0, uint32_t row0, uint32_t p, const Fe29<F> &x) const {
-        const uint32_t k = p & (N - 1);
-        const Fe<typename F::Sat> s = finish(line0 + (p >> m), k, x);
-        const uint32_t sl = nttw_tslot(row0 + (p >> m), k, m);
+    // results of the last round: p = nttw_pos(lane, r, tl) = nttw_pos(lane, 0, tl) | r << 2 tl
+    DEV uint32_t give_base(uint32_t wave, uint32_t lane, uint32_t tl) const { return nttw_tslot_out((wave << 8) | nttw_pos(lane, 0, tl), 0u, m); }
+    DEV void tile_give(U4 *tile, uint32_t gb, uint32_t line0, uint32_t p, uint32_t r, uint32_t tl, const Fe29<F> &x) const {
+        const Fe<typename F::Sat> s = finish(line0 + (p >> m), p & (N - 1), x);
+        const uint32_t sl = gb ^ nttw_tslot_out(r << (2 * tl), 0u, m);
         tile[sl] = U4{s.l[0], s.l[1], s.l[2], s.l[3]};
-        tile[sl + 1] = U4{s.l[4], s.l[5], s.l[6], s.l[7]};
+        tile[sl ^ nttw_tslot_out(0u, 1u, m)] = U4{s.l[4], s.l[5], s.l[6], s.l[7]};
     }
+    // LDS tile -> global; copy iteration `it` handles output position k0 + it * 2^(m-3) of the same row
     DEV void tile_drain(const U4 *tile, uint32_t line_blk0) const {
-        const uint32_t log_tl = 10 - m, tl_mask = (1u << log_tl) - 1u;
-        unsigned char *base = dst + out_start(line_blk0) * 32;
+        const uint32_t log_tl = 10 - m, e0 = threadIdx.x >> 1, k0 = e0 >> log_tl, i = e0 & ((1u << log_tl) - 1u), h = threadIdx.x & 1u;
+        unsigned char *base = dst + (out_start(line_blk0) + (size_t)i + (size_t)k0 * ps.out_elem_stride) * 32 + h * 16;
+        const size_t step = ((size_t)ps.out_elem_stride << (m - 3)) * 32;
+        const uint32_t s0 = nttw_tslot_out((i << m) | k0, h, m);
 #pragma unroll
-        for (int it = 0; it < 8; it++) {
-            const uint32_t c = it * 256 + threadIdx.x, e = c >> 1, k = e >> log_tl, i = e & tl_mask;
-            *reinterpret_cast<U4 *>(base + ((size_t)i + (size_t)k * ps.out_elem_stride) * 32 + (c & 1u) * 16) = tile[nttw_tslot(i, k, m) + (c & 1u)];
-        }
+        for (int it = 0; it < 8; it++)
+            *reinterpret_cast<U4 *>(base + (size_t)it * step) = tile[s0 ^ nttw_tslot_out((uint32_t)it << (m - 3), 0u, m)];
     }
 };
 
@@ -395,8 +429,8 @@ KERNEL void __launch_bounds__(64 * NTTW_WAVES) __attribute__((amdgpu_waves_per_e
         if (COOP & 1) {
             io.tile_fill(tile, line_blk0);
             __syncthreads();
-            x0 = io.tile_take(tile, row0, nttw_pos(lane, 0, 0)); x1 = io.tile_take(tile, row0, nttw_pos(lane, 1, 0));
-            x2 = io.tile_take(tile, row0, nttw_pos(lane, 2, 0)); x3 = io.tile_take(tile, row0, nttw_pos(lane, 3, 0));
+            const uint32_t tb = io.take_base(wv, lane);
+            x0 = io.tile_take(tile, tb, 0); x1 = io.tile_take(tile, tb, 1); x2 = io.tile_take(tile, tb, 2); x3 = io.tile_take(tile, tb, 3);
             __syncthreads();                                       // the exchange planes overwrite the tile
         } else {
             x0 = ntt_unpack<F>(io.fetch(line0, nttw_pos(lane, 0, 0))); x1 = ntt_unpack<F>(io.fetch(line0, nttw_pos(lane, 1, 0)));
@@ -430,8 +464,9 @@ KERNEL void __launch_bounds__(64 * NTTW_WAVES) __attribute__((amdgpu_waves_per_e
         const uint32_t tl = rounds ? rounds - 1 : 0;
         if (COOP & 2) {
             __syncthreads();                                       // every wave is done with its exchange planes
-            io.tile_give(tile, line0, row0, nttw_pos(lane, 0, tl), x0); io.tile_give(tile, line0, row0, nttw_pos(lane, 1, tl), x1);
-            io.tile_give(tile, line0, row0, nttw_pos(lane, 2, tl), x2); io.tile_give(tile, line0, row0, nttw_pos(lane, 3, tl), x3);
+            const uint32_t gb = io.give_base(wv, lane, tl);
+            io.tile_give(tile, gb, line0, nttw_pos(lane, 0, tl), 0, tl, x0); io.tile_give(tile, gb, line0, nttw_pos(lane, 1, tl), 1, tl, x1);
+            io.tile_give(tile, gb, line0, nttw_pos(lane, 2, tl), 2, tl, x2); io.tile_give(tile, gb, line0, nttw_pos(lane, 3, tl), 3, tl, x3);
             __syncthreads();
             io.tile_drain(tile, line_blk0);
             __syncthreads();                                       // the next group's tile or exchange planes reuse the space

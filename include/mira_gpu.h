@@ -266,6 +266,12 @@ int mira_pow_tree_reduce_device(int field, const void *d_leaves, size_t n_leaves
                                 const uint64_t *weights, uint32_t num_points, uint64_t *out);
 int mira_lincomb_device(int field, void *d_out, const void *const *d_vecs, const uint64_t *coeffs /* num_vecs * 4 limbs, host */,
                         size_t num_vecs, size_t n);
+/* num_outs <= 8 linear combinations of the same num_vecs <= 16 vectors in one sweep: outs[m][i] = sum_k coeffs[m][k] * vecs[k][i]
+ * (coeffs: num_outs x num_vecs elements, row-major, host).  An output must not alias an input.  The interpolation step of the
+ * cross terms: commit_cross_terms' d vectors (src/nifs/vanilla/mod.rs:100-121) are the coefficients of
+ * f(W1 + X W2, c1 + X c2) in X, i.e. fixed linear combinations of d + 1 values of that polynomial per row. */
+int mira_lincomb_multi_device(int field, void *const *d_outs, size_t num_outs, const void *const *d_vecs, size_t num_vecs,
+                              const uint64_t *coeffs, size_t n);
 
 /* ---- NTT over bn256::Fr (src/fft.rs) -----------------------------------------------------
  * In place, natural order in and out.  `a` = 2^log_n elements, log_n <= 28 = Fr::S as in the

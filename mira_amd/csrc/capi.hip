@@ -117,7 +117,7 @@ static int upload_consts() {
 // Estimated time of one submission in microseconds for window width c.
 //
 // Dense vectors: measured.  plan_wall_us[r][c] is the wall time of one commit of 2^plan_log_n[r]
-// uniform scalars under width c on MI355X (tools/plan_calibrate.py, one box, one run; boxes differ
+// uniform scalars under width c on MI355X (tools/plan_calibrate.py, one box, one run, profiles/r03_b_plan_calibrate.txt; boxes differ
 // by 5 - 10 %, the ORDER of the widths within a row is what is used).  Between rows: linear in
 // log2 n; beyond the last row: proportional to n.
 //
@@ -133,16 +133,16 @@ static int upload_consts() {
 static const int plan_log_n[10] = {6, 10, 13, 15, 16, 17, 18, 19, 20, 21};
 static const double plan_wall_us[10][17] = {
     //            c = 4     5     6     7     8     9    10    11    12    13    14    15    16
-    {0, 0, 0, 0,   228,   240,   274,   293,   330,   356,   359,   416,   454,   522,   568,   886,   939},
-    {0, 0, 0, 0,   304,   258,   282,   290,   267,   305,   358,   362,   483,   538,   624,   674,   808},
-    {0, 0, 0, 0,   290,   284,   322,   352,   306,   320,   320,   346,   411,   485,   540,   653,   758},
-    {0, 0, 0, 0,   461,   450,   459,   457,   421,   489,   415,   427,   474,   508,   580,   655,   713},
-    {0, 0, 0, 0,   536,   491,   493,   505,   486,   569,   645,   502,   557,   581,   636,   679,   775},
-    {0, 0, 0, 0,   798,   703,   684,   655,   586,   641,   687,   833,   596,   618,   702,   722,   827},
-    {0, 0, 0, 0,  1335,  1134,  1055,   979,   875,   912,   922,  1043,   811,   798,   868,   863,   941},
-    {0, 0, 0, 0,  2494,  2069,  1859,  1670,  1445,  1574,  1474,  1521,  1238,  1174,  1234,  1172,  1214},
-    {0, 0, 0, 0,  4899,  3997,  3513,  3043,  2714,  2849,  2571,  2501,  2137,  1996,  2014,  1879,  1895},
-    {0, 0, 0, 0,  9830,  8161,  7043,  6200,  5380,  5475,  4802,  4552,  4024,  3650,  3548,  3280,  3231},
+    {0, 0, 0, 0,   221,   233,   263,   285,   340,   372,   378,   424,   420,   516,   557,   921,   893},
+    {0, 0, 0, 0,   299,   245,   286,   289,   260,   310,   351,   352,   436,   518,   604,   685,   813},
+    {0, 0, 0, 0,   294,   276,   310,   354,   321,   327,   330,   347,   375,   493,   547,   656,   757},
+    {0, 0, 0, 0,   396,   402,   401,   390,   393,   489,   423,   434,   453,   530,   592,   656,   720},
+    {0, 0, 0, 0,   516,   483,   499,   512,   401,   490,   529,   461,   474,   601,   657,   659,   781},
+    {0, 0, 0, 0,   783,   694,   686,   697,   551,   597,   634,   723,   571,   633,   718,   735,   839},
+    {0, 0, 0, 0,  1310,  1127,  1056,  1020,   841,   860,   875,   937,   787,   814,   886,   879,   949},
+    {0, 0, 0, 0,  2450,  2076,  1851,  1708,  1413,  1522,  1394,  1376,  1190,  1160,  1207,  1170,  1215},
+    {0, 0, 0, 0,  4803,  3984,  3484,  3133,  2667,  2746,  2436,  2328,  1997,  1957,  1934,  1827,  1854},
+    {0, 0, 0, 0,  9521,  7961,  7017,  6183,  5248,  5336,  4607,  4349,  3792,  3554,  3459,  3208,  3167},
 };
 static double plan_table_us(uint32_t c, double n_eff) {
     const double x = std::log2(std::max(n_eff, 1.0));
@@ -851,6 +851,24 @@ int mira_lincomb_device(int field, void *d_out, const void *const *d_vecs, const
         if (n && !d_vecs[k]) { set_error("null vector"); return MIRA_E_BAD_ARG; }
     if (!n) return MIRA_OK;
     return lincomb_device(field, d_out, d_vecs, coeffs, num_vecs, n);
+}
+int mira_lincomb_multi_device(int field, void *const *d_outs, size_t num_outs, const void *const *d_vecs, size_t num_vecs, const uint64_t *coeffs, size_t n) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    if ((field != MIRA_FIELD_FQ && field != MIRA_FIELD_FR) || num_outs == 0 || num_outs > 8 || num_vecs == 0 || num_vecs > 16 || !d_outs || !d_vecs || !coeffs) {
+        set_error("bad linear-combination arguments");
+        return MIRA_E_BAD_ARG;
+    }
+    for (size_t k = 0; k < num_vecs; k++)
+        if (n && !d_vecs[k]) { set_error("null vector"); return MIRA_E_BAD_ARG; }
+    for (size_t m = 0; m < num_outs; m++) {
+        if (n && !d_outs[m]) { set_error("null output"); return MIRA_E_BAD_ARG; }
+        for (size_t k = 0; k < num_vecs; k++)
+            if (n && d_outs[m] == d_vecs[k]) { set_error("an output aliases an input vector"); return MIRA_E_BAD_ARG; }
+    }
+    if (!n) return MIRA_OK;
+    return lincomb_multi_device(field, d_outs, num_outs, d_vecs, num_vecs, coeffs, n);
 }
 int mira_pow_tree_reduce_device(int field, const void *d_leaves, size_t n_leaves, size_t leaf_point_stride, const uint64_t *weights, uint32_t num_points, uint64_t *out) {
     std::lock_guard<std::mutex> lk(g_lock);

@@ -77,6 +77,31 @@ template <class F, class FP> static int lincomb_t(void *d_out, const void *const
     tm_end();
     return MIRA_OK;
 }
+template <class F, class FP> static int lincomb_multi_t(void *const *d_outs, size_t M, const void *const *d_vecs, size_t J, const uint64_t *coeffs, size_t n) {
+    int rc;
+    if ((rc = g.fold_consts.ensure(48 * (FOLD_MAX_TERMS + 1 + LINCOMB_MAX_OUTS * FOLD_MAX_TERMS)))) return rc;
+    std::vector<uint32_t> cm(12 * M * J);
+    FoldTerms vecs;
+    FoldOuts outs;
+    memset(&vecs, 0, sizeof vecs); memset(&outs, 0, sizeof outs);
+    for (size_t j = 0; j < J; j++) vecs.t[j] = reinterpret_cast<const unsigned char *>(d_vecs[j]);
+    for (size_t m = 0; m < M; m++) {
+        outs.t[m] = reinterpret_cast<unsigned char *>(d_outs[m]);
+        for (size_t j = 0; j < J; j++) to_mult48<FP>(coeffs + 4 * (m * J + j), cm.data() + 12 * (m * J + j));
+    }
+    unsigned char *d_c = reinterpret_cast<unsigned char *>(g.fold_consts.p) + 48 * (FOLD_MAX_TERMS + 1);
+    RT_CHECK(rt_h2d(d_c, cm.data(), 48 * M * J, g.stream));
+    tm_begin();
+    LAUNCH(k_lincomb_multi<F>, fold_grid(n), 256, 0, g.stream, outs, (uint32_t)M, vecs, (uint32_t)J, (const unsigned char *)d_c, (uint64_t)n);
+    tm_mark("lincomb_multi");
+    RT_CHECK(rt_last());
+    RT_CHECK(rt_sync(g.stream));                                 // (the staged coefficients live on this function's stack until here)
+    tm_end();
+    return MIRA_OK;
+}
+int lincomb_multi_device(int field, void *const *d_outs, size_t M, const void *const *d_vecs, size_t J, const uint64_t *coeffs, size_t n) {
+    return field == 1 ? lincomb_multi_t<Fr29, FrP>(d_outs, M, d_vecs, J, coeffs, n) : lincomb_multi_t<Fq29, FqP>(d_outs, M, d_vecs, J, coeffs, n);
+}
 int lincomb_device(int field, void *d_out, const void *const *d_vecs, const uint64_t *coeffs, size_t K, size_t n) {
     return field == 1 ? lincomb_t<Fr29, FrP>(d_out, d_vecs, coeffs, K, n) : lincomb_t<Fq29, FqP>(d_out, d_vecs, coeffs, K, n);
 }

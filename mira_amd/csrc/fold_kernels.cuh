@@ -66,6 +66,32 @@ KERNEL void k_lincomb(unsigned char *__restrict__ out, FoldTerms vecs, uint32_t 
     }
 }
 
+// M linear combinations of the same J vectors in one sweep: out_m[i] = sum_j coeffs[m][j] * vecs[j][i].  Every vector
+// element is read once for all M outputs -- the interpolation step of the cross terms (CrossTermPlan in
+// mira_amd/graph_evaluator.py: d - 1 outputs over d + 1 evaluations of the gate polynomial).
+static constexpr int LINCOMB_MAX_OUTS = 8;
+struct FoldOuts {
+    unsigned char *t[LINCOMB_MAX_OUTS];
+};
+template <class F>
+KERNEL void k_lincomb_multi(FoldOuts outs, uint32_t M, FoldTerms vecs, uint32_t J, const unsigned char *__restrict__ coeffs, uint64_t n) {
+    using S = typename F::Sat;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        Fe<S> acc[LINCOMB_MAX_OUTS];
+#pragma unroll
+        for (int m = 0; m < LINCOMB_MAX_OUTS; m++) acc[m] = fe_zero<S>();
+        for (uint32_t j = 0; j < J; j++) {
+            const Fe29<F> t = f29_unpack_canonical<F>(fe_load<S>(vecs.t[j] + i * 32));
+#pragma unroll
+            for (int m = 0; m < LINCOMB_MAX_OUTS; m++)
+                if ((uint32_t)m < M) acc[m] = fe_add(acc[m], fold_canonical(f29_mul(t, fold_const_load<F>(coeffs + ((size_t)m * J + j) * 48))));
+        }
+#pragma unroll
+        for (int m = 0; m < LINCOMB_MAX_OUTS; m++)
+            if ((uint32_t)m < M) fe_store(outs.t[m] + i * 32, acc[m]);
+    }
+}
+
 // One round of ProtoGalaxy's weighted tree reduction (compute_F / compute_G, reference
 // src/nifs/protogalaxy/poly/mod.rs:131-166, 263-290): node(left, right) at height j is
 // left + right * w[p][j].  A workgroup folds 2^levels consecutive values of point p = blockIdx.y:

@@ -276,9 +276,19 @@ class PlonkEvalDomain:
 def commit_cross_terms(key, evaluators, domain, lib=None):
     """The evaluation and commit spans of commit_cross_terms (src/nifs/vanilla/mod.rs:100-127):
     evaluators[k] is the GraphEvaluator of cross term k, or None for an absent term (a zero vector,
-    :115).  Returns (device pointer of the len(evaluators) x row_size cross terms, commitments
+    :115) -- or `evaluators` is a CrossTermPlan, which produces the same d vectors from d + 1 evaluations of the gate
+    polynomial.  Returns (device pointer of the len(evaluators) x row_size cross terms, commitments
     (len, 8) uint64); the caller frees the pointer (mira_fold_error_device consumes it first)."""
     lib = lib or _lib.load()
+    if isinstance(evaluators, CrossTermPlan):
+        n, count = domain.row_size, evaluators.degree
+        d = lib.alloc(max(1, n * count) * 32)
+        try:
+            evaluators.evaluate_device(domain.columns(), domain.challenges, n, d, lib=lib)
+            return d, key.commit_batch_device(d, n, count)
+        except Exception:
+            lib.free(d)
+            raise
     n, count = domain.row_size, len(evaluators)
     d = lib.alloc(max(1, n * count) * 32)
     try:
@@ -295,3 +305,95 @@ def commit_cross_terms(key, evaluators, domain, lib=None):
         lib.free(d)
         raise
     return d, commits
+
+
+# ---------------------------------------------------------------- cross terms by evaluation + interpolation
+class CrossTermPlan:
+    """All d cross terms of one fold step from d + 1 evaluations of the homogeneous gate polynomial f itself.
+
+    The reference multiplies f(W1 + X W2, c1 + X c2) out symbolically (GroupedPoly::new, src/polynomial/
+    grouped_poly.rs:88-140) and evaluates every coefficient T_k as a graph of its own (src/nifs/vanilla/mod.rs:
+    100-121): for the MainGate<5> circuits 815 (one gate) and 2 448 (two gates) calculations per row, against 81
+    and 162 for f.  The coefficients of a degree-d polynomial in X are also fixed by d + 1 of its values, so here
+        p_0 = f(W1, c1) = T_0,    p_inf = f(W2, c2) = T_d,    p_x = f(W1 + x W2, c1 + x c2),  x = 1, -1, 2, -2, ... (d - 1 points)
+    are evaluated row by row (d + 1 graphs over the same columns, one mira_graph_eval_batch) and
+        T_k = sum_x Ainv[k][x] (p_x - T_0 - x^d T_d),  A[x][k] = x^k,  1 <= k <= d - 1
+    is one linear combination of those d + 1 vectors per cross term (mira_lincomb_device).  Field arithmetic is
+    exact, so every T_k is the reference's value bit for bit (tests compare with the grouped graphs and the oracle);
+    the work is (d + 1) (|f| + one fold per queried column) + d - 1 streamed passes instead of sum_k |T_k|."""
+
+    def __init__(self, homogeneous, degree, ctx, field=FIELD_FR):
+        from .expression import QueryIndexContext                         # noqa: F401  (ctx is one)
+        self.degree, self.field, self.mod = degree, field, MODULUS[field]
+        nsf, shift, nc = ctx.num_selectors + ctx.num_fixed, ctx.num_fold_vars(), ctx.num_challenges
+        d = degree
+
+        def at(x):
+            """f with every folded variable v replaced by v1 + x v2 (x = None: by v2 -- the leading coefficient)"""
+            def poly(p):
+                if p.index < nsf:
+                    return Polynomial(p.index, p.rotation)
+                second = Polynomial(p.index + shift, p.rotation)
+                if x is None:
+                    return second
+                return fold(Polynomial(p.index, p.rotation), second)
+
+            def fold(first, second):                                       # first + x * second in the cheapest calculations
+                if x == 0:
+                    return first
+                mag = second if abs(x) == 1 else Product(Constant(2), second) if abs(x) == 2 else Scaled(second, abs(x))   # (2 * v is a DOUBLE)
+                return Sum(first, mag if x > 0 else Negated(mag))          # a + (-b) is one SUB
+
+            def chal(i):
+                return Challenge(i + nc) if x is None else fold(Challenge(i), Challenge(i + nc))
+            return homogeneous.evaluate(lambda c: Constant(c), poly, chal, lambda a: Negated(a), lambda a, b: Sum(a, b), lambda a, b: Product(a, b),
+                                        lambda a, k: Scaled(a, k))
+        xs = [(j // 2 + 1) * (1 if j % 2 == 0 else -1) for j in range(d - 1)]     # 1, -1, 2, -2, 3, ...: the cheapest folds
+        self.points = [0, None] + xs                                       # vector order: p_0, p_inf, p_x ...
+        self.evaluators = [GraphEvaluator.new(at(x), field) for x in self.points]
+        # Ainv over the field: Gauss-Jordan on the (d - 1) x (d - 1) matrix x^k
+        m, mod = d - 1, self.mod
+        A = [[pow(x, k, mod) for k in range(1, d)] + [1 if j == r else 0 for j in range(m)] for r, x in enumerate(xs)]
+        for col in range(m):
+            piv = next(r for r in range(col, m) if A[r][col])
+            A[col], A[piv] = A[piv], A[col]
+            inv = pow(A[col][col], mod - 2, mod)
+            A[col] = [v * inv % mod for v in A[col]]
+            for r in range(m):
+                if r != col and A[r][col]:
+                    f = A[r][col]
+                    A[r] = [(a - f * b) % mod for a, b in zip(A[r], A[col])]
+        ainv = [row[m:] for row in A]                                      # ainv[k - 1][index of x]
+        # coefficients of T_k (k = 1 .. d - 1) on [p_0, p_inf, p_x ...]
+        self.coeffs = [[(-sum(ainv[k])) % mod, (-sum(ainv[k][r] * pow(x, d, mod) for r, x in enumerate(xs))) % mod] + ainv[k] for k in range(m)]
+
+    @classmethod
+    def from_compressed_gates(cls, cg, ctx, field=FIELD_FR):
+        """cg: expression.CompressedGates (homogeneous form + degree), ctx: the QueryIndexContext after CompressedGates.new"""
+        return cls(cg.homogeneous, cg.degree, ctx, field)
+
+    @property
+    def num_calculations(self):
+        return [ev.num_intermediates for ev in self.evaluators]
+
+    def evaluate_device(self, columns, challenges, num_rows, d_terms, lib=None):
+        """d_terms: device buffer of degree x num_rows elements; term k (1 .. d) lands at d_terms + (k - 1) * num_rows * 32,
+        the layout commit_cross_terms hands to mira_msm_batch_device and mira_fold_error_device."""
+        lib = lib or _lib.load()
+        d, n = self.degree, num_rows
+        if d == 1:                                                         # one cross term: the leading coefficient
+            self.evaluators[1].evaluate_device(columns, challenges, n, d_out=d_terms, lib=lib)
+            return
+        d_p = lib.alloc((d + 1) * max(1, n) * 32)
+        try:
+            outs = [d_p + j * n * 32 for j in range(d + 1)]
+            outs[1] = d_terms + (d - 1) * n * 32                           # p_inf IS T_d
+            GraphEvaluator.evaluate_batch_device(self.evaluators, columns, challenges, n, outs, lib=lib)
+            vecs = (ctypes.c_void_p * (d + 1))(*outs)
+            for k0 in range(0, d - 1, 8):                                  # mira_lincomb_multi_device: up to 8 terms per sweep over the d + 1 vectors
+                ks = range(k0, min(d - 1, k0 + 8))
+                c = to_montgomery([v for k in ks for v in self.coeffs[k]], self.field)
+                dst = (ctypes.c_void_p * len(ks))(*[d_terms + k * n * 32 for k in ks])
+                lib.check(lib.c.mira_lincomb_multi_device(self.field, dst, len(ks), vecs, d + 1, c.ctypes.data_as(ctypes.c_void_p), n))
+        finally:
+            lib.free(d_p)

@@ -200,3 +200,27 @@ def test_cross_term_graphs_on_emulated_kernel(emu_lib, field, count):
         assert mont_to_ints(C.graph_eval(field, code, ev.num_intermediates, consts, rots, arrs, chal_m, rows), mod) == want
     for p in ptrs + [d]:
         emu_lib.free(p)
+
+
+@pytest.mark.parametrize("field,T,count", [(1, 5, 2), (0, 5, 1), (1, 2, 1), (0, 3, 3)])
+def test_cross_term_plan_equals_grouped_terms(emu_lib, field, T, count):
+    """CrossTermPlan: the d cross terms from d + 1 evaluations of f and one linear combination each -- the same field
+    elements as the reference's grouped graphs (direct Python-integer evaluation of every grouped term)."""
+    mod, rows = MODS[field], 19
+    rng = random.Random(900 + 10 * T + count + field)
+    cg, ctx = MG.compressed_circuit(T, count)
+    plan = G.CrossTermPlan.from_compressed_gates(cg, ctx, field)
+    assert plan.degree == cg.degree and len(plan.evaluators) == cg.degree + 1
+    inst = random_instance(rng, vars(ctx), mod, rows)
+    both = dict(selectors=[], fixed=inst["fixed"], advice=inst["W1"] + inst["W2"], challenges=inst["c1"] + inst["c2"])
+    arrs = [ints_to_mont(c, mod) for c in both["fixed"] + both["advice"]]
+    ptrs, cols = [], []
+    for a in arrs:
+        p = emu_lib.alloc(a.nbytes); emu_lib.upload(p, a); ptrs.append(p); cols.append((p, G.COL_FIELD))
+    d = emu_lib.alloc(plan.degree * rows * 32)
+    plan.evaluate_device(cols, both["challenges"], rows, d, lib=emu_lib)
+    got = emu_lib.download(d, (plan.degree, rows, 4))
+    for k, t in enumerate(cg.grouped.iter_from_first()):
+        assert mont_to_ints(got[k], mod) == [P.eval_expression(t.to_tuple(), both, r, rows, mod) for r in range(rows)], k
+    for p in ptrs + [d]:
+        emu_lib.free(p)

@@ -74,6 +74,15 @@ def test_main_gate_cross_terms_k17(gpu_lib, cid, gates):
             want = C.graph_eval(field, code, ev.num_intermediates, consts, rots, cols_host, chal_m, rows)
             assert (got[t] == want).all(), (t, ev.num_intermediates)
             assert (commits[t] == C.msm_pippenger(cid, want, bases)).all(), t
+        # the same d vectors from d + 1 evaluations of f and one linear combination per term (CrossTermPlan)
+        plan = G.CrossTermPlan.from_compressed_gates(cg, ctx, field)
+        d_plan, commits_plan = G.commit_cross_terms(key, plan, dom, lib=lib)
+        try:
+            assert (lib.download(d_plan, (d, rows, 4)) == got).all()
+            assert (commits_plan == commits).all()
+            assert sum(plan.num_calculations) < sum(ev.num_intermediates for ev in evs)
+        finally:
+            lib.free(d_plan)
         # sampled rows with Python integers: the grouped expressions directly, and the folding identity
         both = dict(selectors=[], fixed=[_Lazy(c, mod) for c in fix], advice=[_Lazy(c, mod) for c in list(w1) + list(w2)], challenges=chal)
         f = cg.homogeneous.to_tuple()

@@ -206,3 +206,28 @@ def test_key_file_errors(emu_lib, tmp_path):
     key = cm.CommitmentKey.load_from_file(0, tmp_path / "zeros.bin", 4, lib=emu_lib, validate=True)
     assert not key.commit(C.synth_scalars(0, 16, seed=3)).any()
     key.close()
+
+
+def test_lincomb_multi_matches_single_lincombs(emu_lib):
+    """mira_lincomb_multi_device: M combinations of the same J vectors in one sweep = M mira_lincomb_device calls"""
+    import ctypes
+    lib, n, J, M, field = emu_lib, 37, 5, 3, 1
+    vecs = [C.synth_scalars(0, n, seed=300 + j) for j in range(J)]
+    coeffs = C.synth_scalars(0, M * J, seed=400)
+    d_v = [lib.alloc(n * 32) for _ in range(J)]
+    for p, v in zip(d_v, vecs):
+        lib.upload(p, v)
+    d_multi = [lib.alloc(n * 32) for _ in range(M)]
+    d_one = lib.alloc(n * 32)
+    vp = (ctypes.c_void_p * J)(*d_v)
+    lib.check(lib.c.mira_lincomb_multi_device(field, (ctypes.c_void_p * M)(*d_multi), M, vp, J, coeffs.ctypes.data_as(ctypes.c_void_p), n))
+    for m in range(M):
+        cm_ = np.ascontiguousarray(coeffs[m * J:(m + 1) * J])
+        lib.check(lib.c.mira_lincomb_device(field, ctypes.c_void_p(d_one), vp, cm_.ctypes.data_as(ctypes.c_void_p), J, n))
+        assert (lib.download(d_multi[m], (n, 4)) == lib.download(d_one, (n, 4))).all()
+    # an output that aliases an input, too many outputs, a null vector
+    bad = (ctypes.c_void_p * M)(d_v[0], d_multi[1], d_multi[2])
+    assert lib.c.mira_lincomb_multi_device(field, bad, M, vp, J, coeffs.ctypes.data_as(ctypes.c_void_p), n) == _lib_mod.MIRA_E_BAD_ARG
+    assert lib.c.mira_lincomb_multi_device(field, (ctypes.c_void_p * 9)(*([d_one] * 9)), 9, vp, J, coeffs.ctypes.data_as(ctypes.c_void_p), n) == _lib_mod.MIRA_E_BAD_ARG
+    for p in d_v + d_multi + [d_one]:
+        lib.free(p)

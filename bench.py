@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--window-bits", type=int, default=16)
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-key-load", action="store_true", help="skip the 8 GiB commitment-key file leg of the extras")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="REHEARSAL ONLY: all ranks share GPU 0 and exchange over gloo -- the whole multi-rank path with the product library on a one-GPU box; never a measurement")
     ap.add_argument("--emulate", action="store_true",
@@ -241,7 +242,7 @@ def main():
         out["cpu_baseline"], parity = cpu_baseline_msm(lib, cm, key, d_scalars, n, window_bits)
         out["parity"] = parity
     if rank == 0 and n_gpus == 1 and not args.no_extras:
-        out["extras"] = extras(lib, cm, not args.no_cpu)
+        out["extras"] = extras(lib, cm, not args.no_cpu, args.no_key_load)
 
     if dist is not None:
         dist.barrier()
@@ -357,7 +358,7 @@ def cpu_baseline_msm(lib, cm, key, d_scalars, n, window_bits):
     return base, {"sample_pairs": sample, "bit_exact_vs_oracle": bool((got == want).all())}
 
 
-def extras(lib, cm, with_cpu):
+def extras(lib, cm, with_cpu, skip_key_load=False):
     ex = {}
     lib.check(lib.c.mira_msm_set_window_bits(0))
     # ---- NTT 2^24 over bn256::Fr (BASELINE configs[2]) ---------------------------------------
@@ -821,6 +822,64 @@ def extras(lib, cm, with_cpu):
     except Exception as e:
         import traceback
         ex["nifs_fold_step_k17"] = {"error": repr(e), "trace": traceback.format_exc()[-600:]}
+
+    # ---- commitment-key cache file -> HBM -------------------------------------------
+    # load_or_setup_cache (src/commitment.rs:134-166) = load_from_file + is_on_curve over every point; the only timing the
+    # reference holds for it: 3.47 s for 2^27 bn256 points (the `get_or_create_commitment_key` span of the log fixture in
+    # .scripts/build_profiling.py:213).  mira_msm_register_bases_file reads the 8 GiB file in 64 MiB chunks by several
+    # threads into pinned memory, the copy and the read of chunk i + 1 beside the conversion + curve check of chunk i.
+    # The file is a valid key of 2^22 generated points written 32 times over (the loader cannot tell).
+    if not skip_key_load:
+        try:
+            import shutil
+            import tempfile
+            k = 27
+            tmpdir = tempfile.mkdtemp(prefix="mira_key_")
+            try:
+                while k > 22 and shutil.disk_usage(tmpdir).free < (64 << k) + (2 << 30):
+                    k -= 1                                             # what fits the scratch disk, noted in the result
+                n, nb = 1 << k, 1 << 22
+                base = cm.CommitmentKey.synthetic(cm.CURVE_BN256, nb, seed=0x4B4559)
+                block = base.download().tobytes()
+                path = os.path.join(tmpdir, f"{k}.bin")
+                t0 = time.perf_counter()
+                with open(path, "wb") as f:
+                    for _ in range(n // nb):
+                        f.write(block)
+                    f.flush(); os.fsync(f.fileno())
+                t_write = time.perf_counter() - t0
+                res = {"points": n, "file_bytes": n * 64, "file_write_s": round(t_write, 2), "threads": min(8, os.cpu_count() or 1),
+                       "reference_literal_s": 3.47, "reference_literal_source": ".scripts/build_profiling.py:213 (2^27 bn256 points, load + is_on_curve, unknown hardware)"}
+
+                def load(validate):
+                    t0 = time.perf_counter()
+                    key = cm.CommitmentKey.load_from_file(cm.CURVE_BN256, path, k, validate=validate)
+                    dt = time.perf_counter() - t0
+                    return key, dt
+                try:                                                   # evict the file from the page cache: a cold read from the scratch disk
+                    fd = os.open(path, os.O_RDONLY)
+                    os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+                    os.close(fd)
+                    key, dt = load(True)
+                    res["cold_load_validate_s"] = round(dt, 3)
+                    key.close()
+                except Exception as e:
+                    res["cold_load_validate_s"] = repr(e)
+                key, dt_v = load(True)                                 # page-cache warm from here on
+                sample = bool((key.download(n - 4096, 4096) == base.download(nb - 4096, 4096)).all())
+                key.close()
+                key, dt_n = load(False)
+                key.close()
+                res.update({"load_validate_s": round(dt_v, 3), "load_s": round(dt_n, 3), "GB_per_s_validate": round(n * 64 / dt_v / 1e9, 2),
+                            "GB_per_s": round(n * 64 / dt_n / 1e9, 2), "tail_matches_source": sample,
+                            "note": "page-cache-warm file -> pinned -> HBM, resident-layout conversion and (validate) the curve check of every point included"})
+                base.close()
+                ex[f"key_load_2p{k}"] = res
+            finally:
+                shutil.rmtree(tmpdir, ignore_errors=True)
+        except Exception as e:
+            import traceback
+            ex["key_load_2p27"] = {"error": repr(e), "trace": traceback.format_exc()[-500:]}
 
     # ---- ProtoGalaxy's weighted tree reduction: compute_F's shape at k = 17
     # with 8 gates -- 2^20 gate evaluations folded for 32 challenges

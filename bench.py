@@ -756,7 +756,7 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
                 t3 = time.perf_counter()
                 FD.fold_witness_device(s_["field"], s_["d_wout"], s_["d_w1"], s_["d_w2"], s_["r"], s_["nw"])
                 d_e_new = s_["d_enew"]
-                FD.fold_witness_device(s_["field"], d_e_new, s_["d_e"], s_["d_e"], np.zeros(4, dtype=np.uint64), n)      # E' = E (+ 0 * E), then the terms are folded in
+                lib.copy(d_e_new, s_["d_e"], n * 32)                                # E' starts as the accumulator's E, then the terms are folded in
                 FD.fold_error_device(s_["field"], d_e_new, [s_["d_terms"] + i * n * 32 for i in range(s_["cnt"])], s_["r"], n)
                 folded_w = FD.g1_mul_add(c, s_["acc_w"], s_["r"], w_commit)
                 powers = G.to_montgomery([pow(s_["r_int"], i + 1, G.MODULUS[s_["field"]]) for i in range(s_["cnt"])], s_["field"])

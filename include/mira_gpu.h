@@ -311,6 +311,7 @@ int mira_dev_alloc(size_t bytes, void **d_out);
 int mira_dev_free(void *d);
 int mira_dev_upload(void *d_dst, const void *h_src, size_t bytes);
 int mira_dev_download(void *h_dst, const void *d_src, size_t bytes);
+int mira_dev_copy(void *d_dst, const void *d_src, size_t bytes);   /* device to device */
 int mira_dev_sync(void);
 
 /* ---- measurement ------------------------------------------------------------------------

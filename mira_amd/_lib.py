@@ -28,7 +28,7 @@ SYMBOLS = [
     "mira_dev_alloc", "mira_dev_free", "mira_dev_upload", "mira_dev_download", "mira_dev_sync",
     "mira_set_timing", "mira_get_timings", "mira_set_tuning",
     "mira_msm_register_bases_file", "mira_msm_save_bases_file", "mira_msm_partial_to_device", "mira_msm_set_handle_window_bits",
-    "mira_trim", "mira_dev_mem_info", "mira_msm_plan_window_bits", "mira_lincomb_multi_device",
+    "mira_trim", "mira_dev_mem_info", "mira_msm_plan_window_bits", "mira_lincomb_multi_device", "mira_dev_copy",
 ]
 TUNE_STAGED_MIN_N, TUNE_TABLE_MIN_N, TUNE_PLAN_HIST_MIN_N, TUNE_NTT_MAX_LOG_LINE, TUNE_NTT_WAVE, TUNE_HOST_CHUNK_MIN_N, TUNE_NTT_SINGLE_TW_LOG, TUNE_NTT_FULL_TW_MAX_LOG = 0, 1, 2, 3, 4, 5, 6, 7
 
@@ -112,7 +112,7 @@ class MiraLib:
             "mira_msm_register_bases_file": [ctypes.c_int, ctypes.c_char_p, u32, ctypes.c_int, vp], "mira_msm_save_bases_file": [u64, ctypes.c_char_p],
             "mira_msm_partial_to_device": [u64, sz, vp, sz, vp, vp, vp], "mira_msm_set_handle_window_bits": [u64, i32],
             "mira_trim": [sz, vp], "mira_dev_mem_info": [vp, vp], "mira_msm_plan_window_bits": [sz, vp],
-            "mira_lincomb_multi_device": [ctypes.c_int, vp, sz, vp, sz, u64p, sz],
+            "mira_lincomb_multi_device": [ctypes.c_int, vp, sz, vp, sz, u64p, sz], "mira_dev_copy": [vp, vp, sz],
         }
         for name, args in sig.items():
             fn = getattr(c, name)
@@ -141,6 +141,9 @@ class MiraLib:
         out = np.empty(shape, dtype=dtype)
         self.check(self.c.mira_dev_download(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), out.nbytes))
         return out
+
+    def copy(self, dst, src, nbytes):
+        self.check(self.c.mira_dev_copy(ctypes.c_void_p(dst), ctypes.c_void_p(src), nbytes))
 
     def tune(self, knob, value):
         """mira_set_tuning; value < 0 restores the default."""

@@ -1000,6 +1000,15 @@ int mira_dev_download(void *h_dst, const void *d_src, size_t bytes) {
     RT_CHECK(rt_sync(g.stream));
     return MIRA_OK;
 }
+int mira_dev_copy(void *d_dst, const void *d_src, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    if (bytes && (!d_dst || !d_src)) { set_error("null argument"); return MIRA_E_BAD_ARG; }
+    RT_CHECK(rt_d2d(d_dst, d_src, bytes, g.stream));
+    RT_CHECK(rt_sync(g.stream));
+    return MIRA_OK;
+}
 int mira_dev_sync(void) {
     std::lock_guard<std::mutex> lk(g_lock);
     int rc = ensure_ctx();

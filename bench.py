@@ -227,6 +227,13 @@ def main():
                          "peak_issue_derived": {"G_modmul_per_s_mads_only": round(PEAK_ISSUE_MAD_ONLY, 1), "G_modmul_per_s_all_valu": round(PEAK_ISSUE_ALL, 1),
                                                 "frac_of_all_valu": round(10 * adds_per_pair * n / (t_acc * 1e-3) / 1e9 / PEAK_ISSUE_ALL, 3),
                                                 "how": "1024 SIMDs x 64 lanes x 2.4 GHz / (162 v_mad_u64_u32 x 4.76 cyc [+ 85 other VALU x 2.08 cyc]) per f29_mul"},
+                         # the instruction mix of the shipped mixed addition itself (hipcc -S: 1 467 v_mad_u64_u32, 82 v_mul_lo_u32, 152 v_lshl_add_u64,
+                         # 144 v_lshrrev_b64, ~530 simple VALU on the common path) at the measured issue costs: 9 855 cycles per wave-addition
+                         "mix_issue_bound": {"cycles_per_wave_addition": MADD_ISSUE_CYCLES, "G_additions_per_s_at_max_clock": round(PEAK_MADD, 2),
+                                             "achieved_G_additions_per_s": round(adds_per_pair * n / (t_acc * 1e-3) / 1e9, 2),
+                                             "frac_at_max_clock": round(adds_per_pair * n / (t_acc * 1e-3) / 1e9 / PEAK_MADD, 3),
+                                             "note": "the chip holds ~2.06 GHz under this load (GRBM_GUI_ACTIVE / 8 / duration, profiles/r03_c_msm2p22_pmc_valu.txt): "
+                                                     "0.99 of the bound at the sustained clock (profiles/r03_c_accumulate_variants.txt)"},
                          "note": f"{adds_per_pair} mixed XYZZ additions x 10 field multiplications per pair; peak = f29_mul microbenchmark "
                                  "(profiles/r01_b_microbench_f29.txt)"},
                      "note": "integer-ALU bound (about 160 modular multiplications per pair); see DESIGN.md section 4"},
@@ -331,6 +338,8 @@ def load_traffic(log_n):
 MODMUL_MADS, MODMUL_OTHER, MAD_CYC, VALU_CYC, MAX_CLOCK_GHZ = 162, 85, 4.76, 2.08, 2.4
 PEAK_ISSUE_MAD_ONLY = 1024 * 64 * MAX_CLOCK_GHZ / (MODMUL_MADS * MAD_CYC)
 PEAK_ISSUE_ALL = 1024 * 64 * MAX_CLOCK_GHZ / (MODMUL_MADS * MAD_CYC + MODMUL_OTHER * VALU_CYC)
+MADD_ISSUE_CYCLES = round(1467 * 4.76 + 82 * 5.07 + 152 * 4.36 + 144 * 4.8 + 530 * 2.08)
+PEAK_MADD = 1024 * 64 * MAX_CLOCK_GHZ / MADD_ISSUE_CYCLES
 
 
 def cpu_baseline_msm(lib, cm, key, d_scalars, n, window_bits):

@@ -335,10 +335,11 @@ def test_emu_host_scalars_in_chunks(emu_lib, tune):
             emu_lib.check(emu_lib.c.mira_msm_set_window_bits(0))
 
 
-@pytest.mark.parametrize("n,c", [(20000, 4), (36000, 4)])
+@pytest.mark.parametrize("n,c", [(20000, 4)])
 def test_emu_heavy_subjob_grouping(emu_lib, n, c):
-    """k_fixup_heavy_a gives a sub-job 16, 8, 4 or 2 quads by the number of sub-jobs: 4-bit windows over a few 10^4
-    dense scalars make every bucket a heavy run of several sub-jobs -- 1 536 sub-jobs (8 quads each) and 2 560 (4 quads)."""
+    """k_fixup_heavy_a gives a sub-job 16, 8, 4 or 2 quads by the number of sub-jobs: 4-bit windows over 20 000 dense scalars
+    make every bucket a heavy run of three sub-jobs -- 1 536 sub-jobs, 8 quads each (4 and 2 quads per sub-job: the -m gpu
+    suite, tests/test_gpu_msm.py::test_every_bucket_heavy)."""
     cid = 1
     key = cm.CommitmentKey.synthetic(cid, n, seed=17, lib=emu_lib)
     key.set_window_bits(c)

@@ -299,3 +299,18 @@ def test_shared_bucket_tables_16bit(gpu_lib, cid, log_n):
     else:
         assert all((got_b[b] == key.commit_device(d + b * (n // 8) * 32, n // 8)).all() for b in range(cnt))
     gpu_lib.free(d); gpu_lib.free(dw)
+
+
+@pytest.mark.parametrize("cid,n,c", [(0, 1 << 17, 8), (1, 1 << 15, 9), (0, 1 << 17, 6), (1, 1 << 13, 5), (0, 20000, 4)])
+def test_every_bucket_heavy(gpu_lib, cid, n, c):
+    """Dense scalars under narrow windows cut EVERY bucket into a heavy run; k_fixup_heavy_a then sizes its sub-jobs by their
+    number: 4 096 sub-jobs of 47 partials (4 quads each), 7 424 of 7 (2 quads), 5 504 of ~30 (2 quads), 832 of 31 (16 quads),
+    1 536 (8 quads).  Every point against the oracle; the width is the key's own (mira_msm_set_handle_window_bits)."""
+    key = cm.CommitmentKey.synthetic(cid, n, seed=600 + c)
+    key.set_window_bits(c)
+    d = cm.synth_scalars_device(cid, n, seed=610 + c)
+    sc = gpu_lib.download(d, (n, 4))
+    want = C.msm_pippenger(cid, sc, key.download())
+    assert (key.commit_device(d, n) == want).all()
+    assert (key.commit(sc) == want).all()                        # host scalars, same width
+    gpu_lib.free(d); key.close()

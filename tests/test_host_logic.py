@@ -178,7 +178,7 @@ def test_partial_to_device_equals_host_partial(emu_lib):
     key = cm.CommitmentKey(1, C.synth_bases(1, n, seed=61), lib=lib)
     d = cm.synth_scalars_device(1, n, seed=62, lib=lib)
     d_out = lib.alloc(_lib_mod.MIRA_PARTIAL_U64 * 8)
-    for first, cnt, c in ((0, n, 0), (100, 333, 13), (n, 0, 16)):
+    for first, cnt, c in ((0, n, 9), (100, 333, 11), (n, 0, 0)):       # (width 0 = the 16-bit default of a sharded partial: only on the empty chunk, the emulation is slow at 2^15 buckets)
         part, c1, w1 = key.commit_partial_device(first, d + 0, cnt, window_bits=c)
         c2, w2 = key.commit_partial_to_device(first, d + 0, cnt, d_out, window_bits=c)
         assert (c1, w1) == (c2, w2)

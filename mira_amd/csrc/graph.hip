@@ -61,9 +61,7 @@ struct Program {
     uint32_t ninstr = 0, nslots = 0, num_challenges = 0, num_columns = 0, num_rotations = 0, num_calculations = 0;
     std::vector<uint32_t> used_columns;        // column indices the code reads
     std::vector<std::pair<uint32_t, int>> chal_vars;   // (challenge, form) of every challenge operand: converted per evaluation
-    void *d_static = nullptr;                  // code | constants | rotations (reduced mod rot_rows, see graph_eval_batch)
-    std::vector<int32_t> rot_raw;              // the rotations as the caller gave them
-    uint64_t rot_rows = 0;                     // the row count the device copy of the rotations is reduced for (0: not yet)
+    void *d_static = nullptr;                  // code | constants | rotations
     size_t o_code = 0, o_const = 0, o_rot = 0;
     DevBuf dyn;                                // challenges | column table of the current evaluation
     unsigned char *h_dyn = nullptr;            // pinned staging of the same
@@ -558,7 +556,7 @@ int graph_compile(int field, const mira_graph *gr, uint32_t num_challenges, uint
     for (size_t k = 0; k < pool.size(); k++)
         to_limbs29(field, pool[k].first < 0 ? one_r : gr->constants + (size_t)pool[k].first * 4, pool[k].second,
                    reinterpret_cast<uint32_t *>(stage.data() + pg.o_const) + k * 9);
-    if (gr->num_rotations) pg.rot_raw.assign(gr->rotations, gr->rotations + gr->num_rotations);   // the device copy is written per row count
+    if (gr->num_rotations) memcpy(stage.data() + pg.o_rot, gr->rotations, (size_t)gr->num_rotations * 4);
     if (rt_malloc(&pg.d_static, total) != hipSuccess || !pg.d_static) { set_error("device allocation for the compiled graph failed"); return MIRA_E_ALLOC; }
     RT_CHECK(rt_h2d(pg.d_static, stage.data(), total, g.stream));
     RT_CHECK(rt_sync(g.stream));                             // `stage` is pageable host memory about to go out of scope
@@ -653,20 +651,6 @@ int graph_eval_batch(const uint64_t *handles, uint32_t count, const mira_eval_co
                 continue;
             }
             const unsigned char *st = reinterpret_cast<const unsigned char *>(pg.d_static);
-            // (row + rotation).rem_euclid(num_rows) (graph_evaluator.rs:51-53) costs the kernel a 64-bit division per column read
-            // if it is taken there; rotations are per program and the row count per evaluation, so the device table holds
-            // rotation.rem_euclid(num_rows) in [0, num_rows) and the kernel wraps with one compare (rewritten when the row count changes)
-            if (pg.rot_rows != num_rows && !pg.rot_raw.empty()) {
-                std::vector<int32_t> red(pg.rot_raw.size());
-                for (size_t r = 0; r < red.size(); r++) {
-                    int64_t m = (int64_t)pg.rot_raw[r] % (int64_t)num_rows;
-                    red[r] = (int32_t)(m < 0 ? m + (int64_t)num_rows : m);
-                }
-                RT_CHECK(rt_sync(g.stream));                   // an earlier evaluation with another row count may still be reading the table
-                RT_CHECK(rt_h2d(const_cast<unsigned char *>(st) + pg.o_rot, red.data(), red.size() * 4, g.stream));
-                RT_CHECK(rt_sync(g.stream));                   // `red` is pageable host memory about to go out of scope
-                pg.rot_rows = num_rows;
-            }
             for (size_t v = 0; v < pg.chal_vars.size(); v++)
                 to_limbs29(p0.field, challenges + (size_t)pg.chal_vars[v].first * 4, pg.chal_vars[v].second, reinterpret_cast<uint32_t *>(p0.h_dyn + p0.o_chal) + (chal_at + v) * 9);
             GraphJob job{reinterpret_cast<const uint32_t *>(st + pg.o_code), reinterpret_cast<const uint32_t *>(st + pg.o_const),

@@ -94,9 +94,8 @@ KERNEL void __launch_bounds__(256) k_graph_eval(const GraphJob *__restrict__ job
                 }
             } else {
                 const GraphCol c = cols[payload & 0xFFFFFu];
-                // rem_euclid (graph_evaluator.rs:51-53): the table holds rotation mod nrows in [0, nrows) (graph.hip), rows < 2^31
-                uint32_t rr = (uint32_t)row + (uint32_t)rotations[payload >> 20];
-                if (rr >= (uint32_t)nrows) rr -= (uint32_t)nrows;
+                int64_t rr = ((int64_t)row + rotations[payload >> 20]) % (int64_t)nrows;   // rem_euclid, graph_evaluator.rs:51-53
+                if (rr < 0) rr += (int64_t)nrows;
                 // a column enters as it lies in memory -- x * 2^256, "form 1" of the compiler (graph.hip), no lifting
                 // product -- and a selector as the number one in that form (src/plonk/eval.rs:62)
                 if (c.kind == MIRA_COL_BOOL) {

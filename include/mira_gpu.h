@@ -71,12 +71,17 @@ int mira_msm_unregister(uint64_t handle);
  * partial sums to be added).  MIRA_E_ALLOC if the tables do not fit. */
 int mira_msm_precompute(uint64_t handle);
 /* Same with the window width named: 20 (as above), 22 (12 tables, 2^21 buckets, 12 additions per
- * pair: for commits of 2^24 pairs and more) or 16.  16-bit tables (16 x the key size: 1.9 GB
- * for the 1.8 M-point key of a k = 17 fold step) keep the 16 additions per pair of the per-window
- * path but give all windows ONE set of 2^15 buckets: a commit then pays the fix-up and bucket
- * reduction of one window instead of sixteen and no Horner epilogue -- the latency-bound part of
- * the small commits of a fold step (131 072 pairs: 0.63 -> 0.4 ms).  Used from 2^12 pairs up;
- * mira_msm_partial_device reports window_bits = 0, num_windows = 16.  One width per key. */
+ * pair: for commits of 2^24 pairs and more) -- one of the two per key -- or any of 8 .. 16: a SHARED-BUCKET
+ * set of W = ceil(256 / c) tables 2^(c w) * P_i (W x the key size: 16 bits = 1.9 GB, 12 bits = 2.6 GB for the
+ * 1.8 M-point key of a k = 17 fold step).  All W windows of a commit then share ONE set of 2^(c-1) buckets:
+ * W additions per pair, the fix-up and bucket reduction of one window instead of W, and no Horner
+ * epilogue on the host -- the latency-bound part of the small commits of a fold step.  Several shared
+ * widths may be built beside each other (and beside the wide tables): every commit of >= 2^12 pairs
+ * picks the set that is fastest for its length (narrow for 2^17 pairs, 16 bits for 2^21), commits of
+ * >= 2^18 pairs the wide tables when the key has them.  mira_msm_partial_device reports window_bits = 0,
+ * num_windows = 16 (fewer below 8 buckets per sum); a rank of a sharded MSM takes the wide tables if
+ * present, else the widest shared set, whatever its chunk length.  Results are bit-identical whichever
+ * set serves a commit.  Building a width twice is a no-op. */
 int mira_msm_precompute_ex(uint64_t handle, int32_t window_bits);
 /* Validate every registered base against the curve equation on the GPU, as
  * load_or_setup_cache does with is_on_curve (src/commitment.rs:145-154). */
@@ -134,6 +139,8 @@ int mira_msm_plan_window_bits(size_t n, int32_t *window_bits);
 /* Diagnostics: the window width and count the planner used for the most recent commit of this
  * process (0 / the number of partial sums in fixed-base table mode). */
 int mira_msm_last_plan(int32_t *window_bits, int32_t *num_windows);
+/* ... and the width of the table set that commit went through (8 .. 16 shared buckets, 20 or 22 wide tables), 0 = none. */
+int mira_msm_last_table_bits(int32_t *table_bits);
 
 /* Thresholds of the engine's internal choices, for tests and tuning runs (they never change a
  * result): the smallest MSM that takes the LDS-staged two-level sort, the smallest MSM that uses a
@@ -154,6 +161,8 @@ int mira_msm_last_plan(int32_t *window_bits, int32_t *num_windows);
 /* largest transform (log2) whose first post-twiddle is served from a table of n entries (48 n bytes per cached
  * table set); default 24, 0 = never */
 #define MIRA_TUNE_NTT_FULL_TW_MAX_LOG 7
+/* serve commits from the shared-bucket table set of exactly this width (calibration, tests); 0 / default = choose by length */
+#define MIRA_TUNE_TABLE_WIDTH 8
 int mira_set_tuning(int knob, int64_t value);
 
 /* Read a range of the registered key back in the reference layout (cache file writing,

@@ -28,9 +28,9 @@ SYMBOLS = [
     "mira_dev_alloc", "mira_dev_free", "mira_dev_upload", "mira_dev_download", "mira_dev_sync",
     "mira_set_timing", "mira_get_timings", "mira_set_tuning",
     "mira_msm_register_bases_file", "mira_msm_save_bases_file", "mira_msm_partial_to_device", "mira_msm_set_handle_window_bits",
-    "mira_trim", "mira_dev_mem_info", "mira_msm_plan_window_bits", "mira_lincomb_multi_device", "mira_dev_copy",
+    "mira_trim", "mira_dev_mem_info", "mira_msm_plan_window_bits", "mira_lincomb_multi_device", "mira_dev_copy", "mira_msm_last_table_bits",
 ]
-TUNE_STAGED_MIN_N, TUNE_TABLE_MIN_N, TUNE_PLAN_HIST_MIN_N, TUNE_NTT_MAX_LOG_LINE, TUNE_NTT_WAVE, TUNE_HOST_CHUNK_MIN_N, TUNE_NTT_SINGLE_TW_LOG, TUNE_NTT_FULL_TW_MAX_LOG = 0, 1, 2, 3, 4, 5, 6, 7
+TUNE_STAGED_MIN_N, TUNE_TABLE_MIN_N, TUNE_PLAN_HIST_MIN_N, TUNE_NTT_MAX_LOG_LINE, TUNE_NTT_WAVE, TUNE_HOST_CHUNK_MIN_N, TUNE_NTT_SINGLE_TW_LOG, TUNE_NTT_FULL_TW_MAX_LOG, TUNE_TABLE_WIDTH = 0, 1, 2, 3, 4, 5, 6, 7, 8
 
 
 def _preload_hip_runtime():
@@ -98,7 +98,7 @@ class MiraLib:
             "mira_lincomb_device": [ctypes.c_int, vp, vp, u64p, sz, sz],
             "mira_msm_batch": [u64, vp, sz, sz, u64p], "mira_msm_batch_device": [u64, vp, sz, sz, sz, u64p],
             "mira_msm_partial_device": [u64, sz, vp, sz, u64p, vp, vp],
-            "mira_msm_combine": [ctypes.c_int, u64p, sz, i32, i32, u64p], "mira_msm_set_window_bits": [i32], "mira_msm_last_plan": [vp, vp],
+            "mira_msm_combine": [ctypes.c_int, u64p, sz, i32, i32, u64p], "mira_msm_set_window_bits": [i32], "mira_msm_last_plan": [vp, vp], "mira_msm_last_table_bits": [vp],
             "mira_ntt_bn256_fr": [u64p, u32, u64p], "mira_ntt_bn256_fr_device": [vp, u32, u64p],
             "mira_fft_bn256_fr": [u64p, u32], "mira_ifft_bn256_fr": [u64p, u32],
             "mira_fft_bn256_fr_device": [vp, u32], "mira_ifft_bn256_fr_device": [vp, u32],

@@ -230,16 +230,57 @@ static MsmPlan make_plan(size_t n, int32_t forced_c, uint32_t count = 1, uint64_
     return p;
 }
 
-// 16-bit fixed-base tables (mira_msm_precompute_ex(handle, 16)): 16 signed 16-bit digits per scalar
-// against the tables 2^(16 w) P_i, ONE set of 2^15 buckets for all windows, 16 partial sums back.
+// Shared-bucket fixed-base tables (mira_msm_precompute_ex(handle, c), c = 8 .. 16): W = ceil(256 / c) signed c-bit
+// digits per scalar against the tables 2^(c w) P_i, ONE set of 2^(c-1) buckets for all windows, `sums` partial
+// sums back (no chain of doublings on the host).  A commit then pays ceil(256 / c) additions per pair and the
+// fix-up / bucket reduction of ONE window of 2^(c-1) buckets: narrow widths for the small commits of a fold
+// step (few buckets: a short tail), 16 bits for the large ones (fewest additions).
 static constexpr uint32_t SHARED_SUMS = 16;
-static MsmPlan make_plan_shared(size_t n, uint64_t table_n, uint32_t count = 1, uint64_t stride = 0) {
-    MsmPlan p = make_plan(n, 16, count, stride);
-    p.shared = true; p.table_n = table_n; p.sums = SHARED_SUMS;
+static MsmPlan make_plan_shared(size_t n, const Bases::SharedSet &set, uint64_t table_n, uint32_t count = 1, uint64_t stride = 0) {
+    MsmPlan p = make_plan(n, (int32_t)set.c, count, stride);
+    p.shared = true; p.shared_tables = set.p; p.table_n = table_n;
     p.NB = count * p.B;                                      // one bucket set per MSM
-    p.m = 4;                                                 // 8192 chunks: the chain of the reduction is what counts here
+    p.m = 4;                                                 // the chain of the reduction is what counts here
     p.nchunks = p.B / p.m;
+    p.sums = std::min<uint32_t>(SHARED_SUMS, p.nchunks);
     return p;
+}
+// Which of a key's shared-bucket sets serves a commit of n pairs (count of them in one submission).  Measured
+// (tools/shared_width_probe.py, profiles/r03_d_shared_widths.txt): wall time of one commit in microseconds under width c at
+// 2^12 .. 2^21 pairs, interpolated in log2 n like the per-window planner's table; beyond the last row proportional to
+// n.  MIRA_TUNE_TABLE_WIDTH names a width outright (calibration, tests).
+static const int shared_log_n[6] = {12, 14, 16, 17, 19, 21};
+static const double shared_wall_us[6][17] = {
+    //                          c = 8     9    10    11    12    13    14    15    16
+    {0, 0, 0, 0, 0, 0, 0, 0,   263,  265,  260,  300,  297,  265,  316,  290,  345},
+    {0, 0, 0, 0, 0, 0, 0, 0,   277,  286,  301,  306,  335,  337,  347,  306,  323},
+    {0, 0, 0, 0, 0, 0, 0, 0,   378,  362,  386,  409,  404,  454,  504,  428,  439},
+    {0, 0, 0, 0, 0, 0, 0, 0,   539,  515,  511,  511,  585,  533,  567,  561,  576},
+    {0, 0, 0, 0, 0, 0, 0, 0,  1477, 1514, 1347, 1266, 1248, 1123, 1151, 1007,  979},
+    {0, 0, 0, 0, 0, 0, 0, 0,  5684, 5620, 5023, 4521, 4120, 3641, 3519, 3084, 2957},
+};
+static double shared_cost_us(uint32_t c, double n) {
+    const double x = std::log2(std::max(n, 1.0));
+    if (x <= shared_log_n[0]) return shared_wall_us[0][c];
+    for (int r = 1; r < 6; r++)
+        if (x <= shared_log_n[r]) {
+            const double t = (x - shared_log_n[r - 1]) / (shared_log_n[r] - shared_log_n[r - 1]);
+            return shared_wall_us[r - 1][c] * (1.0 - t) + shared_wall_us[r][c] * t;
+        }
+    return shared_wall_us[5][c] * n / std::exp2((double)shared_log_n[5]);
+}
+// sharded: every rank must pick the same set whatever its chunk length -> the widest
+static const Bases::SharedSet *pick_shared(const Bases &bs, size_t n, uint32_t count, bool sharded) {
+    if (bs.shared.empty()) return nullptr;
+    const size_t forced = tuned(MIRA_TUNE_TABLE_WIDTH, 0);
+    const Bases::SharedSet *best = nullptr;
+    double best_us = 1e300;
+    for (const auto &set : bs.shared) {
+        if (forced) { if (set.c == forced) return &set; continue; }
+        const double us = sharded ? -(double)set.c : shared_cost_us(set.c, (double)n * count);
+        if (us < best_us) { best_us = us; best = &set; }
+    }
+    return best;
 }
 
 // Horner over the window sums: sum_w 2^(c w) * Wsum[w], then to_affine.
@@ -283,19 +324,21 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
         set_error("Can't commit too long input: input len: " + std::to_string(first + n) + ", but limit is " + std::to_string(bs.n));
         return MIRA_E_TOO_LONG;
     }
-    // 20-bit tables pay from 2^18 pairs (2^19 buckets to reduce whatever n is); 16-bit tables share the
-    // bucket count of ONE window of the per-window path, so they win from a few thousand pairs
-    const size_t table_min_n = tuned(MIRA_TUNE_TABLE_MIN_N, bs.table_c == 16 ? TABLE16_MIN_N : TABLE_MIN_N);
     // window width: the call's own (sharded partials), else this key's (mira_msm_set_handle_window_bits), else the process default
     const int32_t forced_c = bs.forced_c ? bs.forced_c : g.forced_c;
-    const bool table_mode = bs.tables && (sharded || n >= table_min_n) && forced_c == 0 && requested_c == 0;
+    // 20- / 22-bit tables pay from 2^18 pairs (2^19 buckets to reduce whatever n is); the shared-bucket sets have the
+    // bucket count of ONE window of the per-window path, so they win from a few thousand pairs.  A key with both
+    // uses the wide tables where they pay and a shared set below.
+    const bool tables_ok = forced_c == 0 && requested_c == 0;
+    const bool table_mode = bs.tables && tables_ok && (sharded || n >= tuned(MIRA_TUNE_TABLE_MIN_N, TABLE_MIN_N));
+    const Bases::SharedSet *set = (tables_ok && !table_mode && (sharded || n >= tuned(MIRA_TUNE_TABLE_MIN_N, TABLE16_MIN_N))) ? pick_shared(bs, n, 1, sharded) : nullptr;
     // Data-dependent planning for single (unsharded) commits (ranks of a sharded MSM must agree on
     // the window width, so they keep the dense estimate).  The statistics are those of the previous
     // commit of the same length over this key -- successive fold steps commit witnesses of one
     // shape -- so no call waits for a pre-pass: this call's histogram is enqueued ahead of its MSM
     // kernels and read after the synchronisation that ends it.
     const size_t hist_min_n = tuned(MIRA_TUNE_PLAN_HIST_MIN_N, PLAN_HIST_MIN_N);
-    const bool use_hist = !table_mode && !sharded && forced_c == 0 && n >= hist_min_n && d_scalars;
+    const bool use_hist = !table_mode && !set && !sharded && forced_c == 0 && n >= hist_min_n && d_scalars;
     // a rank of a sharded MSM that was not given a width takes 16, whatever its chunk length: partials
     // of different widths cannot be combined, and chunk lengths differ between ranks
     const int32_t width = requested_c ? requested_c : (sharded && forced_c == 0) ? 16 : forced_c;
@@ -303,23 +346,23 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
     if (n >= (1ull << 31) || (uint64_t)n * p.W >= (1ull << 32)) { set_error("n too large for 32-bit entry offsets"); return MIRA_E_UNSUPPORTED; }
     if (p.W > MIRA_MAX_WINDOWS) { set_error("window configuration exceeds MIRA_MAX_WINDOWS"); return MIRA_E_UNSUPPORTED; }
     *c_out = p.c; *W_out = p.W;
-    g.last_c = (int32_t)p.c; g.last_w = (int32_t)p.W;
+    g.last_c = (int32_t)p.c; g.last_w = (int32_t)p.W; g.last_table_c = 0;
     memset(out_partial, 0, MIRA_PARTIAL_U64 * 8);
     if (n == 0) return MIRA_OK;
     if (!d_scalars) { set_error("null scalars"); return MIRA_E_BAD_ARG; }
     // fixed-base mode: window tables present, MSM large enough to be throughput-bound, no forced width
-    if (table_mode && bs.table_c == 16) {                    // shared buckets through the per-window launch sequence
-        if ((uint64_t)n * 16 >= (1ull << 32)) { set_error("n too large for 32-bit entry offsets"); return MIRA_E_UNSUPPORTED; }
-        MsmPlan ps = make_plan_shared(n, bs.n);
-        *c_out = 0; *W_out = SHARED_SUMS;                   // partial sums, combined by a plain sum
-        g.last_c = 0; g.last_w = (int32_t)SHARED_SUMS;
+    if (set) {                                               // shared buckets through the per-window launch sequence
+        MsmPlan ps = make_plan_shared(n, *set, bs.n);
+        if ((uint64_t)n * ps.W >= (1ull << 32)) { set_error("n too large for 32-bit entry offsets"); return MIRA_E_UNSUPPORTED; }
+        *c_out = 0; *W_out = ps.sums;                       // partial sums, combined by a plain sum
+        g.last_c = 0; g.last_w = (int32_t)ps.sums; g.last_table_c = (int32_t)set->c;
         return bs.curve == MIRA_CURVE_BN256 ? msm_launch_bn256(bs, first, d_scalars, h_scalars, n, ps, out_partial)
                                              : msm_launch_grumpkin(bs, first, d_scalars, h_scalars, n, ps, out_partial);
     }
     if (table_mode) {
         if (h_scalars) RT_CHECK(rt_h2d(const_cast<void *>(d_scalars), h_scalars, n * 32, g.stream));
         *c_out = 0; *W_out = 64;                            // 64 partial sums, combined by a plain sum
-        g.last_c = 0; g.last_w = 64;
+        g.last_c = 0; g.last_w = 64; g.last_table_c = (int32_t)bs.table_c;
         return bs.curve == MIRA_CURVE_BN256 ? msm_launch_table_bn256(bs, first, d_scalars, n, out_partial)
                                              : msm_launch_table_grumpkin(bs, first, d_scalars, n, out_partial);
     }
@@ -357,24 +400,27 @@ static int msm_batch_device_locked(uint64_t handle, const void *d_scalars, size_
     }
     if (n == 0) { memset(out_affine, 0, count * 64); return MIRA_OK; }
     if (n >= (1ull << 31)) { set_error("n too large for 32-bit entry offsets"); return MIRA_E_UNSUPPORTED; }
-    // 16-bit fixed-base tables: every commitment of the batch gets ONE bucket set for its 16 windows
-    // (16 additions per pair instead of ceil(256 / c), 2^15 buckets per commitment instead of W 2^(c-1)),
-    // and its 16 partial sums come back to be added -- no chain of doublings
+    // shared-bucket tables: every commitment of the batch gets ONE bucket set for its W windows
+    // (ceil(256 / c) additions per pair, 2^(c-1) buckets per commitment instead of W 2^(c-1)),
+    // and its partial sums come back to be added -- no chain of doublings
     const int32_t forced_c = bs.forced_c ? bs.forced_c : g.forced_c;
-    if (bs.tables && bs.table_c == 16 && forced_c == 0 && n >= tuned(MIRA_TUNE_TABLE_MIN_N, TABLE16_MIN_N)) {
-        const size_t per = std::max<size_t>(1, std::min<size_t>(64, (size_t)(((1ull << 32) - 1) / ((uint64_t)n * 16))));
+    const Bases::SharedSet *set = (forced_c == 0 && n >= tuned(MIRA_TUNE_TABLE_MIN_N, TABLE16_MIN_N)) ? pick_shared(bs, n, (uint32_t)std::min<size_t>(count, 64), false) : nullptr;
+    if (set) {
+        const uint32_t Ws = (256 + set->c - 1) / set->c;
+        const size_t per = std::max<size_t>(1, std::min<size_t>(64, (size_t)(((1ull << 32) - 1) / ((uint64_t)n * Ws))));
         std::vector<uint64_t> sums;
         for (size_t done = 0; done < count; done += per) {
             const size_t cnt = std::min(per, count - done);
-            MsmPlan p = make_plan_shared(n, bs.n, (uint32_t)cnt, stride);
-            sums.assign(cnt * SHARED_SUMS * 16, 0);
+            MsmPlan p = make_plan_shared(n, *set, bs.n, (uint32_t)cnt, stride);
+            g.last_c = 0; g.last_w = (int32_t)p.sums; g.last_table_c = (int32_t)set->c;
+            sums.assign(cnt * p.sums * 16, 0);
             const unsigned char *sc = reinterpret_cast<const unsigned char *>(d_scalars) + done * stride * 32;
             rc = bs.curve == MIRA_CURVE_BN256 ? msm_launch_bn256(bs, 0, sc, nullptr, n, p, sums.data()) : msm_launch_grumpkin(bs, 0, sc, nullptr, n, p, sums.data());
             if (rc) return rc;
             for (size_t b = 0; b < cnt; b++) {
-                const uint64_t *w = sums.data() + b * SHARED_SUMS * 16;
-                if (bs.curve == MIRA_CURVE_BN256) horner_affine<FqP>(w, 0, SHARED_SUMS, out_affine + (done + b) * 8);
-                else horner_affine<FrP>(w, 0, SHARED_SUMS, out_affine + (done + b) * 8);
+                const uint64_t *w = sums.data() + b * p.sums * 16;
+                if (bs.curve == MIRA_CURVE_BN256) horner_affine<FqP>(w, 0, p.sums, out_affine + (done + b) * 8);
+                else horner_affine<FrP>(w, 0, p.sums, out_affine + (done + b) * 8);
             }
         }
         return MIRA_OK;
@@ -387,7 +433,7 @@ static int msm_batch_device_locked(uint64_t handle, const void *d_scalars, size_
     for (size_t done = 0; done < count; done += per) {
         const size_t cnt = std::min(per, count - done);
         MsmPlan p = make_plan(n, forced_c, (uint32_t)cnt, stride);
-        g.last_c = (int32_t)p.c; g.last_w = (int32_t)p.W;
+        g.last_c = (int32_t)p.c; g.last_w = (int32_t)p.W; g.last_table_c = 0;
         win.assign((size_t)p.Wt * 16, 0);
         const unsigned char *sc = reinterpret_cast<const unsigned char *>(d_scalars) + done * stride * 32;
         rc = bs.curve == MIRA_CURVE_BN256 ? msm_launch_bn256(bs, 0, sc, nullptr, n, p, win.data()) : msm_launch_grumpkin(bs, 0, sc, nullptr, n, p, win.data());
@@ -558,6 +604,7 @@ int mira_msm_unregister(uint64_t handle) {
     if (it == g_bases.end()) { set_error("unknown bases handle"); return MIRA_E_BAD_ARG; }
     if (it->second.owned && it->second.d) (void)rt_free(it->second.d);
     if (it->second.tables) (void)rt_free(it->second.tables);
+    for (auto &set : it->second.shared) (void)rt_free(set.p);
     g_bases.erase(it);
     return MIRA_OK;
 }
@@ -567,9 +614,20 @@ static int precompute_locked(uint64_t handle, int32_t window_bits) {
     auto it = g_bases.find(handle);
     if (it == g_bases.end()) { set_error("unknown bases handle"); return MIRA_E_BAD_ARG; }
     Bases &bs = it->second;
-    if (window_bits != 16 && window_bits != 20 && window_bits != 22) { set_error("window tables are built for 16-, 20- or 22-bit windows"); return MIRA_E_BAD_ARG; }
-    if (bs.tables && bs.table_c != (uint32_t)window_bits) { set_error("this key already has tables of another width"); return MIRA_E_BAD_ARG; }
-    const uint32_t W = window_bits == 16 ? 16 : window_bits == 22 ? 12 : 13;   // ceil(256 / c); 12 x 22 = 264 covers a signed 254-bit scalar
+    if (window_bits >= 8 && window_bits <= 16) {             // a shared-bucket set: any number of widths beside each other
+        for (const auto &set : bs.shared) if (set.c == (uint32_t)window_bits) return MIRA_OK;
+        const uint32_t W = (256 + (uint32_t)window_bits - 1) / (uint32_t)window_bits;
+        if ((uint64_t)bs.n * W >= (1ull << 31)) { set_error("key too long for 31-bit table indices"); return MIRA_E_UNSUPPORTED; }
+        Bases tmp = bs;                                      // build_tables fills tables / table_c / table_w of what it is given
+        tmp.tables = nullptr; tmp.table_c = tmp.table_w = 0;
+        rc = bs.curve == MIRA_CURVE_BN256 ? build_tables_bn256(tmp, (uint32_t)window_bits, W) : build_tables_grumpkin(tmp, (uint32_t)window_bits, W);
+        if (rc) return rc;
+        if (tmp.tables) bs.shared.push_back({tmp.tables, (uint32_t)window_bits, W});
+        return MIRA_OK;
+    }
+    if (window_bits != 20 && window_bits != 22) { set_error("window tables are built for 8- to 16-bit (shared buckets), 20- or 22-bit windows"); return MIRA_E_BAD_ARG; }
+    if (bs.tables && bs.table_c != (uint32_t)window_bits) { set_error("this key already has wide tables of another width"); return MIRA_E_BAD_ARG; }
+    const uint32_t W = window_bits == 22 ? 12 : 13;          // ceil(256 / c); 12 x 22 = 264 covers a signed 254-bit scalar
     if ((uint64_t)bs.n * W >= (1ull << 31)) { set_error("key too long for 31-bit table indices"); return MIRA_E_UNSUPPORTED; }
     return bs.curve == MIRA_CURVE_BN256 ? build_tables_bn256(bs, (uint32_t)window_bits, W) : build_tables_grumpkin(bs, (uint32_t)window_bits, W);
 }
@@ -667,7 +725,7 @@ int mira_msm_combine(int curve, const uint64_t *partials, size_t nparts, int32_t
 }
 int mira_set_tuning(int knob, int64_t value) {
     std::lock_guard<std::mutex> lk(g_lock);
-    if (knob < 0 || knob > MIRA_TUNE_NTT_FULL_TW_MAX_LOG) { set_error("unknown tuning knob"); return MIRA_E_BAD_ARG; }
+    if (knob < 0 || knob > MIRA_TUNE_TABLE_WIDTH) { set_error("unknown tuning knob"); return MIRA_E_BAD_ARG; }
     g.tune[knob] = value;
     return MIRA_OK;
 }
@@ -680,6 +738,12 @@ int mira_msm_last_plan(int32_t *window_bits, int32_t *num_windows) {
     std::lock_guard<std::mutex> lk(g_lock);
     if (!window_bits || !num_windows) { set_error("null output"); return MIRA_E_BAD_ARG; }
     *window_bits = g.last_c; *num_windows = g.last_w;
+    return MIRA_OK;
+}
+int mira_msm_last_table_bits(int32_t *table_bits) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    if (!table_bits) { set_error("null output"); return MIRA_E_BAD_ARG; }
+    *table_bits = g.last_table_c;
     return MIRA_OK;
 }
 int mira_msm_set_window_bits(int32_t c) {

@@ -92,7 +92,7 @@ struct Ctx {
     hipStream_t copy_stream = nullptr;   // host scalars travel here, chunk by chunk, beside the kernels of earlier chunks
     std::vector<hipEvent_t> copy_events;
     int32_t forced_c = 0;
-    int64_t tune[8] = {-1, -1, -1, -1, -1, -1, -1, -1};   // mira_set_tuning overrides, < 0 = default
+    int64_t tune[16] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};   // mira_set_tuning overrides, < 0 = default
     Timing tm;
     // MSM workspace (grow-only, shared by all handles: calls are serialised by the ABI lock)
     DevBuf digits, counts, offsets, cursor, block_sums, sorted_idx, bucket_sums, part, coarse_offsets, fine_counts, fine_cursor;
@@ -110,6 +110,7 @@ struct Ctx {
     DevBuf tree_w, tree_a, tree_b;   // weighted tree reduction: level weights, ping-pong partial results
     uint32_t hist_host[256] = {};    // the statistics of the last commit that collected them
     int32_t last_c = 0, last_w = 0;  // mira_msm_last_plan
+    int32_t last_table_c = 0;        // mira_msm_last_table_bits: width of the table set the last commit went through, 0 = none
     uint32_t hist_sel = 0;           // which of the two device histograms the next commit adds into
     unsigned char *out_host = nullptr; size_t out_host_cap = 0;   // pinned staging of window sums + statistics   // cross-term evaluator: staged program, intermediates[slot][lane]
     void *windows_dst = nullptr;     // mira_msm_partial_to_device: device destination of the window sums of the call in flight
@@ -123,8 +124,11 @@ struct Bases {
     void *d = nullptr;
     bool owned = false;
     int32_t forced_c = 0;     // mira_msm_set_handle_window_bits: this key's window width, 0 = planner / process default
-    void *tables = nullptr;   // fixed-base window tables 2^(table_c w) P_i, w < table_w (table_kernels.cuh), or null
+    void *tables = nullptr;   // fixed-base window tables 2^(table_c w) P_i, w < table_w (table_kernels.cuh: 20 or 22 bits), or null
     uint32_t table_c = 0, table_w = 0;
+    // shared-bucket table sets (8 .. 16 bits, msm_host.cuh): any number of widths beside each other, each W x the key
+    struct SharedSet { void *p; uint32_t c, W; };
+    std::vector<SharedSet> shared;
     // bit-length histogram of the scalars of the previous commit of stat_n elements over this key
     // (planning input for the next one of the same length; never affects a result)
     mutable uint32_t stat_hist[256] = {0};
@@ -144,9 +148,10 @@ struct MsmPlan {
     uint32_t c, W, B, NB, tile, ntiles, L, T, m, nchunks, lanes;
     uint32_t count, Wt;   // MSMs in this submission, total windows count * W
     uint64_t stride;      // scalars of MSM b start at element b * stride
-    // fixed-base tables with 16-bit windows: the W windows share ONE set of B buckets (NB = B), entries name
+    // fixed-base tables with 8 .. 16-bit windows: the W windows share ONE set of B buckets (NB = B), entries name
     // table points w * table_n + first + i, and the window sums come back as `sums` plain partial sums
     bool shared = false;
+    const void *shared_tables = nullptr;   // the W tables of this width, table_n points each
     uint64_t table_n = 0;
     uint32_t sums = 0;
     bool stats = false;   // also histogram the bit lengths of the scalars (planning input of the next commit of this shape)

@@ -133,7 +133,7 @@ static int msm_launch_body(const Bases &bs, size_t first, const void *d_scalars,
         const size_t nc = ends[k] - lo, entries = nc * p.Wt;
         const unsigned char *sc = reinterpret_cast<const unsigned char *>(d_scalars) + lo * 32;
         // per-window buckets: entries are chunk-local point indices; shared buckets: entries name table points
-        const unsigned char *bases = p.shared ? reinterpret_cast<const unsigned char *>(bs.tables) : reinterpret_cast<const unsigned char *>(bs.d) + (first + lo) * 64;
+        const unsigned char *bases = p.shared ? reinterpret_cast<const unsigned char *>(p.shared_tables) : reinterpret_cast<const unsigned char *>(bs.d) + (first + lo) * 64;
         const uint32_t wgroup = p.shared ? p.W : 1u, idx_stride = p.shared ? (uint32_t)p.table_n : 0u, idx_first = p.shared ? (uint32_t)(first + lo) : 0u;
         const uint32_t add = k ? 1u : 0u;
         if (h_scalars) {

@@ -251,7 +251,53 @@ def test_emu_shared_bucket_tables_16bit(emu_lib, tune):
     assert (key.commit(dense) == want_dense).all()
     assert (key.commit(sc) == want).all()
     with pytest.raises(_lib.MiraError):
-        key.precompute(20)                                    # one width per key
+        key.precompute(18)                                    # shared buckets are 8 .. 16 bits, wide tables 20 or 22
+
+
+def test_emu_shared_bucket_tables_other_widths(emu_lib, tune):
+    """mira_msm_precompute_ex(handle, c) for c = 8 .. 15: W = ceil(256 / c) tables, ONE set of 2^(c-1) buckets,
+    min(16, 2^(c-3)) partial sums back.  Several widths live beside each other on one key; MIRA_TUNE_TABLE_WIDTH names
+    the set a commit goes through, mira_msm_last_table_bits reports it; without the knob the commit's length picks
+    one.  Same points as the per-window path and the oracle for single commits, prefixes, a batch, chunk partials
+    (ranks of a sharded MSM all take the widest set) and host scalars in point chunks."""
+    tune(_lib.TUNE_TABLE_MIN_N, 1)
+    cid, n = 1, 260
+    bs = C.synth_bases(cid, n, seed=47)
+    bs[5] = 0
+    key = cm.CommitmentKey(cid, bs, lib=emu_lib)
+    sc = C.synth_scalars(cid, n, seed=48, kind=1)
+    sc[:60] = C.to_mont(C.FIELD_FQ, np.array([1, 0, 0, 0], dtype=np.uint64))[0]        # a heavy bucket
+    dense = C.synth_scalars(cid, n, seed=49)
+    want, want_dense = C.commit(cid, bs, sc), C.commit(cid, bs, dense)
+    tb = ctypes.c_int32()
+
+    def last_table():
+        emu_lib.check(emu_lib.c.mira_msm_last_table_bits(ctypes.byref(tb)))
+        return tb.value
+    assert (key.commit(dense) == want_dense).all() and last_table() == 0
+    vs = [dense[:150], sc[:150]]
+    want_b = np.stack([C.commit(cid, bs[:150], v) for v in vs])
+    for c in (8, 11, 13, 15):
+        key.precompute(c)
+        key.precompute(c)                                     # a second build of the same width is a no-op
+        tune(_lib.TUNE_TABLE_WIDTH, c)
+        assert (key.commit(sc) == want).all() and last_table() == c
+        assert (key.commit(dense) == want_dense).all()
+        assert (key.commit(dense[:77]) == C.commit(cid, bs[:77], dense[:77])).all()
+        assert (key.commit_batch(vs) == want_b).all() and last_table() == c
+    tune(_lib.TUNE_TABLE_WIDTH, 8)
+    d = emu_lib.alloc(n * 32); emu_lib.upload(d, dense)
+    pa, ca, wa = key.commit_partial_device(0, d, 100)
+    pb, cb, wb = key.commit_partial_device(100, d + 100 * 32, n - 100)
+    assert (ca, wa) == (0, 16) == (cb, wb) and last_table() == 8
+    assert (cm.combine_partials(cid, np.stack([pa, pb]), ca, wa, lib=emu_lib) == want_dense).all()
+    tune(_lib.TUNE_STAGED_MIN_N, 1)                           # the LDS-staged sort with table indices, 12 fine bits at most
+    tune(_lib.TUNE_TABLE_WIDTH, 13)
+    assert (key.commit(dense) == want_dense).all() and (key.commit_batch(vs) == want_b).all()
+    tune(_lib.TUNE_HOST_CHUNK_MIN_N, 64)                      # host scalars in chunks of 32, 64, 128, ... points
+    assert (key.commit(dense) == want_dense).all() and (key.commit(sc) == want).all()
+    tune(_lib.TUNE_TABLE_WIDTH, -1)                           # the length picks a set
+    assert (key.commit(dense) == want_dense).all() and last_table() in (8, 11, 13, 15)
 
 
 def test_emu_data_dependent_planning(emu_lib, tune):

@@ -7,6 +7,7 @@ import pytest
 
 from helpers import arr_to_point, golden_msm_case, ints_to_mont, load_golden, mont_to_ints, point_to_arr
 from mira_amd import commitment as cm
+from mira_amd import _lib
 from oracle import cref as C
 from oracle import pyref as P
 
@@ -299,6 +300,49 @@ def test_shared_bucket_tables_16bit(gpu_lib, cid, log_n):
     else:
         assert all((got_b[b] == key.commit_device(d + b * (n // 8) * 32, n // 8)).all() for b in range(cnt))
     gpu_lib.free(d); gpu_lib.free(dw)
+
+
+@pytest.mark.parametrize("cid,log_n", [(0, 17), (1, 19)])
+def test_shared_bucket_tables_every_width(gpu_lib, cid, log_n):
+    """mira_msm_precompute_ex(handle, c), c = 8 .. 16, all nine sets beside each other on one key: every width gives the
+    per-window path's point (which the oracle confirms) for a dense and a witness-like vector, a prefix, host scalars and
+    a batch of five; chunk partials of a sharded MSM take the widest set; without MIRA_TUNE_TABLE_WIDTH the commit's
+    length picks a set (mira_msm_last_table_bits)."""
+    n = 1 << log_n
+    key = cm.CommitmentKey.synthetic(cid, n, seed=131)
+    d = cm.synth_scalars_device(cid, n, seed=132)
+    dw = cm.synth_scalars_device(cid, n, seed=133, kind=1)
+    before, before_w = key.commit_device(d, n), key.commit_device(dw, n)
+    sc = gpu_lib.download(d, (n, 4))
+    assert (before == C.commit(cid, key.bases(), sc)).all()
+    m = n // 2 + 1234
+    before_m = key.commit_device(d, m)
+    nb, cnt = n // 8, 5
+    before_b = key.commit_batch_device(d, nb, cnt, stride=nb + 7)
+    tb = ctypes.c_int32()
+    try:
+        for c in range(8, 17):
+            key.precompute(c)
+            gpu_lib.tune(_lib.TUNE_TABLE_WIDTH, c)
+            assert (key.commit_device(d, n) == before).all(), c
+            gpu_lib.check(gpu_lib.c.mira_msm_last_table_bits(ctypes.byref(tb)))
+            assert tb.value == c
+            assert (key.commit_device(dw, n) == before_w).all(), c
+            assert (key.commit_device(d, m) == before_m).all(), c
+            assert (key.commit_batch_device(d, nb, cnt, stride=nb + 7) == before_b).all(), c
+            if c in (8, 12, 16):
+                assert (key.commit(sc) == before).all(), c                      # host scalars
+    finally:
+        gpu_lib.tune(_lib.TUNE_TABLE_WIDTH, -1)
+    assert (key.commit_device(d, n) == before).all()
+    gpu_lib.check(gpu_lib.c.mira_msm_last_table_bits(ctypes.byref(tb)))
+    assert 8 <= tb.value <= 16
+    pa, ca, wa = key.commit_partial_device(0, d, m)
+    gpu_lib.check(gpu_lib.c.mira_msm_last_table_bits(ctypes.byref(tb)))
+    pb, cb, wb = key.commit_partial_device(m, d + m * 32, n - m)
+    assert (ca, wa) == (0, 16) == (cb, wb) and tb.value == 16
+    assert (cm.combine_partials(cid, np.stack([pa, pb]), ca, wa) == before).all()
+    gpu_lib.free(d); gpu_lib.free(dw); key.close()
 
 
 @pytest.mark.parametrize("cid,n,c", [(0, 1 << 17, 8), (1, 1 << 15, 9), (0, 1 << 17, 6), (1, 1 << 13, 5), (0, 20000, 4)])

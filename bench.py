@@ -688,11 +688,22 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
             for _ in range(7):
                 t0 = time.perf_counter(); run_plan(); walls_p.append((time.perf_counter() - t0) * 1e3)
             same = bool((lib.download(d_plan, (len(evs), n, 4)) == lib.download(d_out, (len(evs), n, 4))).all())
+            # once per circuit: a kernel of its own for every evaluation point, compiled at run time from the graph's
+            # instruction stream (mira_graph_specialize, hiprtc) -- intermediates in registers, no decoding
+            t0 = time.perf_counter(); spec_ok = plan.specialize(cols, len(chal)); spec_s = time.perf_counter() - t0
+            walls_s, same_s = [], None
+            if spec_ok:
+                run_plan()
+                for _ in range(7):
+                    t0 = time.perf_counter(); run_plan(); walls_s.append((time.perf_counter() - t0) * 1e3)
+                same_s = bool((lib.download(d_plan, (len(evs), n, 4)) == lib.download(d_out, (len(evs), n, 4))).all())
             lib.free(d_plan)
             res[name] = {"gates": gates, "degree": cg.degree, "graphs": len(evs), "rows": n, "fixed_columns": ctx.num_fixed, "advice_columns": ctx.num_advice,
                          "calculations_per_graph": ncalc, "ms_grouped_graphs": round(wall, 3), "kernel_ms_per_graph_alone": kerns,
                          "G_calculations_per_s": round(sum(ncalc) * n / wall / 1e6, 2),
-                         "ms": round(sorted(walls_p)[3], 3), "calculations_per_point": plan.num_calculations, "points": [str(x) for x in plan.points],
+                         "ms": round(sorted(walls_s)[3], 3) if spec_ok else round(sorted(walls_p)[3], 3), "ms_interpreted": round(sorted(walls_p)[3], 3),
+                         "specialized": bool(spec_ok), "specialize_s": round(spec_s, 1), "specialized_equals_grouped": same_s,
+                         "calculations_per_point": plan.num_calculations, "points": [str(x) for x in plan.points],
                          "interpolated_equals_grouped": same}
             if with_cpu:
                 from oracle import cref as C
@@ -711,10 +722,13 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
             for p in (d_fix, d_w1, d_w2, d_out):
                 lib.free(p)
         res["ms"] = round(res["primary_bn256"]["ms"] + res["secondary_grumpkin"]["ms"], 3)
+        res["ms_interpreted"] = round(res["primary_bn256"]["ms_interpreted"] + res["secondary_grumpkin"]["ms_interpreted"], 3)
         res["ms_grouped_graphs"] = round(res["primary_bn256"]["ms_grouped_graphs"] + res["secondary_grumpkin"]["ms_grouped_graphs"], 3)
         res["note"] = ("the d cross terms of the MainGate<5> circuits over 2^17 rows.  ms_grouped_graphs: the reference's own graphs (grouped terms 1..d of the "
                        "homogenised, challenge-compressed gate), one batched submission per circuit.  ms: the same vectors, bit for bit, from d + 1 evaluations of "
-                       "the gate polynomial at W1 + x W2 and one linear combination per term (CrossTermPlan).  Outputs stay in HBM for the batched commit")
+                       "the gate polynomial at W1 + x W2 and one linear combination per term (CrossTermPlan), every evaluation point through a kernel of its own compiled at "
+                       "run time from the graph (mira_graph_specialize, once per circuit: specialize_s); ms_interpreted: the same through the graph interpreter.  "
+                       "Outputs stay in HBM for the batched commit")
         ex["cross_term_eval_k17"] = res
     except Exception as e:
         import traceback
@@ -778,17 +792,31 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
                 outs[c] = dict(w_commit=w_commit, t_commits=t_commits, d_e_new=d_e_new, folded_w=folded_w, folded_e=folded_e)
             return spans, outs
         fold_step()
+        walls_i = []
+        for _ in range(5):
+            t0 = time.perf_counter(); spans_i, last_i = fold_step(); walls_i.append(((time.perf_counter() - t0) * 1e3, spans_i))
+        wall_i, spans_i = sorted(walls_i, key=lambda x: x[0])[2]
+        # once per circuit: every evaluation point gets its own run-time compiled kernel (mira_graph_specialize)
+        t0 = time.perf_counter()
+        spec_ok = all(s_["plan"].specialize(s_["cols"], len(s_["chal"])) for s_ in st.values())
+        spec_s = time.perf_counter() - t0
+        fold_step()
         walls, last = [], None
         for _ in range(5):
             t0 = time.perf_counter(); spans, last = fold_step(); walls.append(((time.perf_counter() - t0) * 1e3, spans))
         wall, spans = sorted(walls, key=lambda x: x[0])[2]
+        same_spec = all((last[c]["w_commit"] == last_i[c]["w_commit"]).all() and (last[c]["t_commits"] == last_i[c]["t_commits"]).all()
+                        and (last[c]["folded_e"] == last_i[c]["folded_e"]).all() for c in st)
         ex["nifs_fold_step_k17"] = {"ms": round(wall, 3), "spans_ms": {a: round(b * 1e3, 3) for a, b in spans.items()},
+                                    "ms_interpreted_graphs": round(wall_i, 3), "spans_ms_interpreted_graphs": {a: round(b * 1e3, 3) for a, b in spans_i.items()},
+                                    "graphs_specialized": bool(spec_ok), "specialize_s": round(spec_s, 1), "specialized_same_points": bool(same_spec),
                                     "rows": n, "advice_columns": [st[c]["ctx"].num_advice for c in st], "fixed_columns": [st[c]["ctx"].num_fixed for c in st],
                                     "cross_terms": [st[c]["cnt"] for c in st], "calculations_per_graph": [[ev.num_intermediates for ev in st[c]["evs"]] for c in st],
                                     "calculations_per_point": [st[c]["plan"].num_calculations for c in st],
                                     "note": "both curves, device-resident vectors: witness commit, the d cross terms of the MainGate<5> circuits (d + 1 evaluations of the gate polynomial "
-                                            "+ interpolation: the same vectors as the reference's grouped graphs, which the CPU leg evaluates), batched cross-term commits, W / E folding and "
-                                            "instance folding (host g1_mul_add); span names follow the reference's tracing spans"}
+                                            "+ interpolation: the same vectors as the reference's grouped graphs, which the CPU leg evaluates; every evaluation point through its own run-time "
+                                            "compiled kernel, built once per circuit in specialize_s -- ms_interpreted_graphs: through the graph interpreter, as in earlier rounds), "
+                                            "batched cross-term commits, W / E folding and instance folding (host g1_mul_add); span names follow the reference's tracing spans"}
         # opt-in: the same chain over shared-bucket fixed-base tables (mira_msm_precompute_ex(handle, 16) and (handle, 11)) --
         # a commitment key is fixed for the whole IVC run, its tables are built once
         for s_ in st.values():

@@ -163,6 +163,8 @@ int mira_msm_last_table_bits(int32_t *table_bits);
 #define MIRA_TUNE_NTT_FULL_TW_MAX_LOG 7
 /* serve commits from the shared-bucket table set of exactly this width (calibration, tests); 0 / default = choose by length */
 #define MIRA_TUNE_TABLE_WIDTH 8
+/* column reads a specialised cross-term kernel keeps in flight ahead of their use (mira_graph_specialize); default 4 */
+#define MIRA_TUNE_JIT_LOADS_AHEAD 9
 int mira_set_tuning(int knob, int64_t value);
 
 /* Read a range of the registered key back in the reference layout (cache file writing,
@@ -259,6 +261,24 @@ int mira_graph_free(uint64_t handle);
  * graph k writes d_outs[k].  Row for row the values of count mira_graph_eval_compiled calls. */
 int mira_graph_eval_batch(const uint64_t *handles, uint32_t count, const mira_eval_column *columns, uint32_t num_columns,
                           const uint64_t *challenges, uint32_t num_challenges, size_t num_rows, void *const *d_outs);
+/* Optional, once per circuit: give every one of these compiled graphs a kernel of its own.  The engine writes the
+ * graph's instruction stream out as straight-line HIP and compiles it for the device at run time (hiprtc, one host
+ * thread per graph, ~5 s for one evaluation point of a MainGate<5> gate): intermediates live in registers instead of
+ * LDS / workspace slots, there is no decoding, a rotated row is reduced once per row instead of once per column read.
+ * Evaluation then runs at about twice the interpreter's rate; every value is the interpreter's (the same field
+ * operations in the same order).  The gate polynomial of a circuit is fixed for the whole IVC run
+ * (src/ivc/public_params.rs: the PlonkStructure is built once), so this belongs where the GraphEvaluators are built.
+ * MIRA_E_UNSUPPORTED (libhiprtc.so missing, a graph of more than 1536 instructions, a compilation failure):
+ * nothing has changed and the graphs keep being interpreted -- on the GPU, there is no host path.
+ * `columns`: the column table the graphs will be evaluated over -- only the KINDS are read (which columns are selector
+ * bytes is a property of the circuit); an evaluation over columns of other kinds than the kernel was built for is
+ * interpreted.
+ * mira_graph_is_specialized reports 1 / 0; mira_graph_jit_source copies the generated source (NUL-terminated, at most
+ * cap bytes; *len_out = its full length) for inspection and for tests. */
+int mira_graph_specialize(const uint64_t *handles, uint32_t count, const mira_eval_column *columns, uint32_t num_columns);
+int mira_graph_is_specialized(uint64_t handle, int32_t *out);
+int mira_graph_jit_source(uint64_t handle, const mira_eval_column *columns, uint32_t num_columns, char *buf, size_t cap, size_t *len_out);
+
 
 /* ---- ProtoGalaxy's polynomial pipeline around the NTT (src/nifs/protogalaxy/poly/mod.rs) -------
  * mira_pow_tree_reduce_device: the weighted tree reduction of compute_F (:131-166) and compute_G

@@ -29,8 +29,9 @@ SYMBOLS = [
     "mira_set_timing", "mira_get_timings", "mira_set_tuning",
     "mira_msm_register_bases_file", "mira_msm_save_bases_file", "mira_msm_partial_to_device", "mira_msm_set_handle_window_bits",
     "mira_trim", "mira_dev_mem_info", "mira_msm_plan_window_bits", "mira_lincomb_multi_device", "mira_dev_copy", "mira_msm_last_table_bits",
+    "mira_graph_specialize", "mira_graph_is_specialized", "mira_graph_jit_source",
 ]
-TUNE_STAGED_MIN_N, TUNE_TABLE_MIN_N, TUNE_PLAN_HIST_MIN_N, TUNE_NTT_MAX_LOG_LINE, TUNE_NTT_WAVE, TUNE_HOST_CHUNK_MIN_N, TUNE_NTT_SINGLE_TW_LOG, TUNE_NTT_FULL_TW_MAX_LOG, TUNE_TABLE_WIDTH = 0, 1, 2, 3, 4, 5, 6, 7, 8
+TUNE_STAGED_MIN_N, TUNE_TABLE_MIN_N, TUNE_PLAN_HIST_MIN_N, TUNE_NTT_MAX_LOG_LINE, TUNE_NTT_WAVE, TUNE_HOST_CHUNK_MIN_N, TUNE_NTT_SINGLE_TW_LOG, TUNE_NTT_FULL_TW_MAX_LOG, TUNE_TABLE_WIDTH, TUNE_JIT_LOADS_AHEAD = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 
 
 def _preload_hip_runtime():
@@ -93,7 +94,7 @@ class MiraLib:
             "mira_fold_witness_device": [ctypes.c_int, vp, vp, vp, u64p, sz], "mira_fold_error_device": [ctypes.c_int, vp, vp, sz, u64p, sz],
             "mira_g1_mul_add": [ctypes.c_int, u64p, u64p, u64p, u64p], "mira_g1_lincomb": [ctypes.c_int, u64p, u64p, u64p, sz, u64p],
             "mira_graph_eval_device": [ctypes.c_int, vp, vp, u32, u64p, u32, sz, vp],
-            "mira_graph_compile": [ctypes.c_int, vp, u32, u32, vp], "mira_graph_eval_compiled": [u64, vp, u32, u64p, u32, sz, vp], "mira_graph_eval_batch": [vp, u32, vp, u32, vp, u32, sz, vp], "mira_graph_free": [u64],
+            "mira_graph_compile": [ctypes.c_int, vp, u32, u32, vp], "mira_graph_eval_compiled": [u64, vp, u32, u64p, u32, sz, vp], "mira_graph_eval_batch": [vp, u32, vp, u32, vp, u32, sz, vp], "mira_graph_free": [u64], "mira_graph_specialize": [vp, u32, vp, u32], "mira_graph_is_specialized": [u64, vp], "mira_graph_jit_source": [u64, vp, u32, vp, sz, vp],
             "mira_pow_tree_reduce_device": [ctypes.c_int, vp, sz, sz, u64p, u32, u64p],
             "mira_lincomb_device": [ctypes.c_int, vp, vp, u64p, sz, sz],
             "mira_msm_batch": [u64, vp, sz, sz, u64p], "mira_msm_batch_device": [u64, vp, sz, sz, sz, u64p],

@@ -725,7 +725,7 @@ int mira_msm_combine(int curve, const uint64_t *partials, size_t nparts, int32_t
 }
 int mira_set_tuning(int knob, int64_t value) {
     std::lock_guard<std::mutex> lk(g_lock);
-    if (knob < 0 || knob > MIRA_TUNE_TABLE_WIDTH) { set_error("unknown tuning knob"); return MIRA_E_BAD_ARG; }
+    if (knob < 0 || knob > MIRA_TUNE_JIT_LOADS_AHEAD) { set_error("unknown tuning knob"); return MIRA_E_BAD_ARG; }
     g.tune[knob] = value;
     return MIRA_OK;
 }
@@ -993,6 +993,22 @@ int mira_graph_eval_batch(const uint64_t *handles, uint32_t count, const mira_ev
 int mira_graph_free(uint64_t handle) {
     std::lock_guard<std::mutex> lk(g_lock);
     return graph_free(handle);
+}
+int mira_graph_specialize(const uint64_t *handles, uint32_t count, const mira_eval_column *columns, uint32_t num_columns) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    if ((count && !handles) || (num_columns && !columns)) { set_error("null argument"); return MIRA_E_BAD_ARG; }
+    return graph_specialize(handles, count, columns, num_columns);
+}
+int mira_graph_is_specialized(uint64_t handle, int32_t *out) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    return graph_is_specialized(handle, out);
+}
+int mira_graph_jit_source(uint64_t handle, const mira_eval_column *columns, uint32_t num_columns, char *buf, size_t cap, size_t *len_out) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    if (num_columns && !columns) { set_error("null argument"); return MIRA_E_BAD_ARG; }
+    return graph_jit_source(handle, columns, num_columns, buf, cap, len_out);
 }
 int mira_g1_mul_add(int curve, const uint64_t acc[8], const uint64_t scalar[4], const uint64_t point[8], uint64_t out[8]) {
     if ((curve != MIRA_CURVE_BN256 && curve != MIRA_CURVE_GRUMPKIN) || !acc || !scalar || !point || !out) { set_error("bad arguments"); return MIRA_E_BAD_ARG; }

@@ -197,6 +197,9 @@ int graph_eval_compiled(uint64_t handle, const mira_eval_column *columns, uint32
 int graph_free(uint64_t handle);
 int graph_eval_batch(const uint64_t *handles, uint32_t count, const mira_eval_column *columns, uint32_t num_columns, const uint64_t *challenges,
                      uint32_t num_challenges, size_t num_rows, void *const *d_outs);
+int graph_specialize(const uint64_t *handles, uint32_t count, const mira_eval_column *columns, uint32_t num_columns);
+int graph_is_specialized(uint64_t handle, int32_t *out);
+int graph_jit_source(uint64_t handle, const mira_eval_column *columns, uint32_t num_columns, char *buf, size_t cap, size_t *len_out);
 int graph_eval_device(int field, const mira_graph *gr, const mira_eval_column *columns, uint32_t num_columns, const uint64_t *challenges,
                       uint32_t num_challenges, size_t num_rows, void *d_out);
 

@@ -7,7 +7,12 @@
 // of a fold step, with one small upload and one launch.
 #include "ctx.h"
 #include "graph_kernels.cuh"
+#include "graph_jit.hpp"
 #include "host_field.hpp"
+#ifndef MIRA_CPU_EMU
+#include <dlfcn.h>
+#include <thread>
+#endif
 
 namespace {
 
@@ -63,6 +68,13 @@ struct Program {
     std::vector<std::pair<uint32_t, int>> chal_vars;   // (challenge, form) of every challenge operand: converted per evaluation
     void *d_static = nullptr;                  // code | constants | rotations
     size_t o_code = 0, o_const = 0, o_rot = 0;
+    std::vector<uint32_t> h_stream;            // the instruction stream and rotations again on the host: what graph_jit.hpp writes out as a kernel
+    std::vector<int32_t> h_rot;
+#ifndef MIRA_CPU_EMU
+    hipModule_t jit_mod = nullptr;             // the specialised kernel of this program (mira_graph_specialize), or null: interpreted
+    hipFunction_t jit_fn = nullptr;
+#endif
+    std::vector<uint32_t> jit_kinds;           // the column kinds that kernel was built for (an evaluation with others is interpreted)
     DevBuf dyn;                                // challenges | column table of the current evaluation
     unsigned char *h_dyn = nullptr;            // pinned staging of the same
     size_t o_chal = 0, o_cols = 0, o_jobs = 0, dyn_bytes = 0;   // | job table of the batch this program leads
@@ -548,6 +560,8 @@ int graph_compile(int field, const mira_graph *gr, uint32_t num_challenges, uint
     pg.o_const = align16(stream.size() * 4);
     pg.o_rot = align16(pg.o_const + pool.size() * 36);
     pg.chal_vars = chal_vars;
+    pg.h_stream = stream;
+    pg.h_rot.assign(gr->rotations, gr->rotations + gr->num_rotations);
     const size_t total = align16(pg.o_rot + (size_t)gr->num_rotations * 4) + 16;
     std::vector<unsigned char> stage(total, 0);
     memcpy(stage.data() + pg.o_code, stream.data(), stream.size() * 4);
@@ -576,6 +590,9 @@ int graph_free(uint64_t handle) {
     auto it = g_programs.find(handle);
     if (it == g_programs.end()) { set_error("unknown graph handle"); return MIRA_E_BAD_ARG; }
     Program &pg = it->second;
+#ifndef MIRA_CPU_EMU
+    if (pg.jit_mod) (void)hipModuleUnload(pg.jit_mod);
+#endif
     if (pg.d_static) (void)rt_free(pg.d_static);
     if (pg.dyn.p) (void)rt_free(pg.dyn.p);
     if (pg.h_dyn) (void)rt_host_free(pg.h_dyn);
@@ -637,6 +654,9 @@ int graph_eval_batch(const uint64_t *handles, uint32_t count, const mira_eval_co
     }
 #endif
     tm_begin();
+#ifndef MIRA_CPU_EMU
+    std::vector<std::pair<hipFunction_t, GraphJob>> jit_jobs;
+#endif
     for (uint32_t done = 0; done < count; done += GRAPH_MAX_BATCH) {
         const uint32_t cnt = std::min<uint32_t>(GRAPH_MAX_BATCH, count - done);
         if (done) RT_CHECK(rt_sync(g.stream));               // the previous launch's copy still reads the pinned staging
@@ -658,14 +678,35 @@ int graph_eval_batch(const uint64_t *handles, uint32_t count, const mira_eval_co
                          reinterpret_cast<const int32_t *>(st + pg.o_rot), reinterpret_cast<unsigned char *>(d_outs[done + k]), pg.ninstr,
                          std::min<uint32_t>(pg.nslots, lds_slots)};
             chal_at += pg.chal_vars.size();
+#ifndef MIRA_CPU_EMU
+            if (pg.jit_fn) {
+                bool same = true;
+                for (uint32_t col : pg.used_columns) same &= columns[col].kind == pg.jit_kinds[col];
+                if (same) { jit_jobs.push_back({pg.jit_fn, job}); continue; }
+            }
+#endif
             memcpy(p0.h_dyn + p0.o_jobs + (size_t)live * sizeof(GraphJob), &job, sizeof job);
             max_slots = std::max(max_slots, pg.nslots);
             live++;
         }
+#ifdef MIRA_CPU_EMU
+        if (live) RT_CHECK(rt_h2d(p0.dyn.p, p0.h_dyn, p0.dyn_bytes, g.stream));
+#else
+        if (live || !jit_jobs.empty()) RT_CHECK(rt_h2d(p0.dyn.p, p0.h_dyn, p0.dyn_bytes, g.stream));
+        // specialised programs: one launch each (a launch of 2^17 rows is two waves per SIMD, what their 256 VGPRs allow)
+        for (auto &jj : jit_jobs) {
+            struct { const uint32_t *consts29, *chal29; const GraphCol *cols; unsigned char *out; uint64_t nrows; } args{
+                jj.second.consts29, jj.second.challenges29, reinterpret_cast<const GraphCol *>(reinterpret_cast<const unsigned char *>(p0.dyn.p) + p0.o_cols), jj.second.out, (uint64_t)num_rows};
+            size_t arg_bytes = sizeof args;
+            void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &arg_bytes, HIP_LAUNCH_PARAM_END};
+            const uint32_t jgrid = (uint32_t)std::min<size_t>((num_rows + graphjit::BLOCK - 1) / graphjit::BLOCK, 256 * 4 * 2 * 4);
+            RT_CHECK(hipModuleLaunchKernel(jj.first, jgrid, 1, 1, graphjit::BLOCK, 1, 1, 0, g.stream, nullptr, cfg));
+        }
+        jit_jobs.clear();
+#endif
         if (live) {
             const size_t ws_stride = (size_t)max_slots * 9 * T;
             if ((rc = g.graph_ws.ensure(ws_stride * live * 4))) return rc;
-            RT_CHECK(rt_h2d(p0.dyn.p, p0.h_dyn, p0.dyn_bytes, g.stream));
             const unsigned char *dy = reinterpret_cast<const unsigned char *>(p0.dyn.p);
             if (p0.field == MIRA_FIELD_FQ)
                 LAUNCH(k_graph_eval<Fq29>, dim3(grid, live), block, (size_t)lds_slots * 9 * block * 4, g.stream, reinterpret_cast<const GraphJob *>(dy + p0.o_jobs),
@@ -698,4 +739,139 @@ int graph_eval_device(int field, const mira_graph *gr, const mira_eval_column *c
     graph_free(h);
     if (rc) set_error(err);
     return rc;
+}
+
+// ---- specialised kernels (graph_jit.hpp) ----------------------------------------------------------------------------
+static std::vector<uint32_t> kinds_of(const mira_eval_column *columns, uint32_t num_columns) {
+    std::vector<uint32_t> k(num_columns, MIRA_COL_FIELD);
+    for (uint32_t c = 0; c < num_columns; c++) if (columns) k[c] = columns[c].kind;
+    return k;
+}
+int graph_jit_source(uint64_t handle, const mira_eval_column *columns, uint32_t num_columns, char *buf, size_t cap, size_t *len_out) {
+    auto it = g_programs.find(handle);
+    if (it == g_programs.end()) { set_error("unknown graph handle"); return MIRA_E_BAD_ARG; }
+    const Program &pg = it->second;
+    if (!len_out) { set_error("null output"); return MIRA_E_BAD_ARG; }
+    if (pg.num_calculations == 0 || pg.ninstr == 0) { *len_out = 0; return MIRA_OK; }
+    if (num_columns != pg.num_columns) { set_error("the graph was compiled for " + std::to_string(pg.num_columns) + " columns"); return MIRA_E_BAD_ARG; }
+    const std::string src = graphjit::source(pg.field, pg.h_stream, pg.ninstr, pg.h_rot, kinds_of(columns, num_columns), tuned(MIRA_TUNE_JIT_LOADS_AHEAD, graphjit::LOADS_AHEAD_DEFAULT));
+    *len_out = src.size();
+    if (buf && cap) {
+        const size_t ncopy = std::min(cap - 1, src.size());
+        memcpy(buf, src.data(), ncopy);
+        buf[ncopy] = 0;
+    }
+    return MIRA_OK;
+}
+
+#ifndef MIRA_CPU_EMU
+namespace graphjit {
+Rtc &rtc() {
+    static Rtc r;
+    if (r.tried) return r;
+    r.tried = true;
+    for (const char *name : {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"}) {
+        r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (r.lib) break;
+    }
+    if (!r.lib) { r.error = "libhiprtc.so not found: graphs stay interpreted"; return r; }
+    auto sym = [&](const char *n) { void *p = dlsym(r.lib, n); if (!p) r.error = std::string("libhiprtc.so lacks ") + n; return p; };
+    r.create = reinterpret_cast<decltype(r.create)>(sym("hiprtcCreateProgram"));
+    r.compile = reinterpret_cast<decltype(r.compile)>(sym("hiprtcCompileProgram"));
+    r.log_size = reinterpret_cast<decltype(r.log_size)>(sym("hiprtcGetProgramLogSize"));
+    r.log = reinterpret_cast<decltype(r.log)>(sym("hiprtcGetProgramLog"));
+    r.code_size = reinterpret_cast<decltype(r.code_size)>(sym("hiprtcGetCodeSize"));
+    r.code = reinterpret_cast<decltype(r.code)>(sym("hiprtcGetCode"));
+    r.destroy = reinterpret_cast<decltype(r.destroy)>(sym("hiprtcDestroyProgram"));
+    Dl_info info;                                            // the kernel headers lie beside this library
+    if (dladdr(reinterpret_cast<const void *>(&graph_specialize), &info) && info.dli_fname) {
+        std::string path(info.dli_fname);
+        const size_t slash = path.rfind('/');
+        r.include_dir = slash == std::string::npos ? "." : path.substr(0, slash);
+    } else if (r.error.empty()) r.error = "cannot locate libmira_gpu.so (dladdr)";
+    return r;
+}
+std::vector<char> compile(const std::string &src, std::string &err) {
+    Rtc &r = rtc();
+    std::vector<char> out;
+    if (!r.error.empty()) { err = r.error; return out; }
+    void *prog = nullptr;
+    if (r.create(&prog, src.c_str(), "mira_jit.hip", 0, nullptr, nullptr) != 0) { err = "hiprtcCreateProgram failed"; return out; }
+    const std::string inc = "-I" + r.include_dir;
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", inc.c_str()};
+    const int rc = r.compile(prog, 4, opts);
+    if (rc != 0) {
+        size_t n = 0;
+        (void)r.log_size(prog, &n);
+        std::string log(n, 0);
+        if (n > 1) (void)r.log(prog, &log[0]);
+        err = "hiprtcCompileProgram failed (" + std::to_string(rc) + "): " + log.substr(0, 2000);
+        (void)r.destroy(&prog);
+        return out;
+    }
+    size_t n = 0;
+    if (r.code_size(prog, &n) == 0 && n) { out.resize(n); if (r.code(prog, out.data()) != 0) out.clear(); }
+    if (out.empty()) err = "hiprtcGetCode failed";
+    (void)r.destroy(&prog);
+    return out;
+}
+}   // namespace graphjit
+#endif
+
+// Every handle gets its own kernel; the compilations run on one host thread each (a MainGate<5> evaluation point takes
+// ~5 s).  A handle that is specialised already, or has no calculations, is left as it is.  On failure nothing changes:
+// the graphs stay interpreted.
+int graph_specialize(const uint64_t *handles, uint32_t count, const mira_eval_column *columns, uint32_t num_columns) {
+#ifdef MIRA_CPU_EMU
+    (void)handles; (void)count; (void)columns; (void)num_columns;
+    set_error("the host emulation has no run-time compiler: graphs stay interpreted");
+    return MIRA_E_UNSUPPORTED;
+#else
+    std::vector<Program *> todo;
+    for (uint32_t k = 0; k < count; k++) {
+        auto it = g_programs.find(handles[k]);
+        if (it == g_programs.end()) { set_error("unknown graph handle"); return MIRA_E_BAD_ARG; }
+        Program &pg = it->second;
+        if (num_columns != pg.num_columns) { set_error("the graph was compiled for " + std::to_string(pg.num_columns) + " columns"); return MIRA_E_BAD_ARG; }
+        if (pg.jit_fn || pg.num_calculations == 0 || pg.ninstr == 0) continue;
+        if (pg.ninstr > graphjit::MAX_INSTR) { set_error("graph of " + std::to_string(pg.ninstr) + " instructions is too long to specialise"); return MIRA_E_UNSUPPORTED; }
+        if (std::find(todo.begin(), todo.end(), &pg) == todo.end()) todo.push_back(&pg);
+    }
+    if (todo.empty()) return MIRA_OK;
+    if (!graphjit::rtc().error.empty()) { set_error(graphjit::rtc().error); return MIRA_E_UNSUPPORTED; }
+    std::vector<std::vector<char>> code(todo.size());
+    std::vector<std::string> errs(todo.size());
+    std::vector<std::thread> workers;
+    const std::vector<uint32_t> kinds = kinds_of(columns, num_columns);
+    const size_t ahead = tuned(MIRA_TUNE_JIT_LOADS_AHEAD, graphjit::LOADS_AHEAD_DEFAULT);
+    auto work = [&](size_t k) { code[k] = graphjit::compile(graphjit::source(todo[k]->field, todo[k]->h_stream, todo[k]->ninstr, todo[k]->h_rot, kinds, ahead), errs[k]); };
+    for (size_t k = 1; k < todo.size(); k++) workers.emplace_back(work, k);
+    work(0);
+    for (auto &t : workers) t.join();
+    for (size_t k = 0; k < todo.size(); k++)
+        if (code[k].empty()) { set_error(errs[k]); return MIRA_E_UNSUPPORTED; }
+    std::vector<hipModule_t> mods(todo.size(), nullptr);
+    std::vector<hipFunction_t> fns(todo.size(), nullptr);
+    for (size_t k = 0; k < todo.size(); k++) {
+        hipError_t e = hipModuleLoadData(&mods[k], code[k].data());
+        if (e == hipSuccess) e = hipModuleGetFunction(&fns[k], mods[k], "mira_jit_eval");
+        if (e != hipSuccess) {
+            for (size_t q = 0; q <= k; q++) if (mods[q]) (void)hipModuleUnload(mods[q]);
+            set_error(std::string("loading a specialised kernel failed: ") + hipGetErrorString(e));
+            return MIRA_E_UNSUPPORTED;
+        }
+    }
+    for (size_t k = 0; k < todo.size(); k++) { todo[k]->jit_mod = mods[k]; todo[k]->jit_fn = fns[k]; todo[k]->jit_kinds = kinds; }
+    return MIRA_OK;
+#endif
+}
+int graph_is_specialized(uint64_t handle, int32_t *out) {
+    auto it = g_programs.find(handle);
+    if (it == g_programs.end() || !out) { set_error("unknown graph handle"); return MIRA_E_BAD_ARG; }
+#ifdef MIRA_CPU_EMU
+    *out = 0;
+#else
+    *out = it->second.jit_fn ? 1 : 0;
+#endif
+    return MIRA_OK;
 }

@@ -6,13 +6,26 @@
 // indexing can be checked, and sanitizers run, in a container without a GPU.  It is never
 // part of libmira_gpu.so and mira_amd/ never loads it.
 #pragma once
+#ifdef __HIPCC_RTC__
+// Runtime compilation of a specialised cross-term kernel (graph.hip, graph_jit.cuh): hiprtc brings the HIP device
+// environment and the fixed-width integer types, but no libc headers; only the device-side arithmetic is needed.
+typedef unsigned int uint32_t;
+typedef int int32_t;
+typedef unsigned long long uint64_t;
+typedef long long int64_t;
+typedef unsigned long size_t;
+#define HD __device__ __forceinline__
+#define DEV __device__ __forceinline__
+#else
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#endif
 
-#ifndef MIRA_CPU_EMU
+#if defined(__HIPCC_RTC__)
+#elif !defined(MIRA_CPU_EMU)
 #include <hip/hip_runtime.h>
 #define HD __host__ __device__ __forceinline__
 #define DEV __device__ __forceinline__

@@ -206,6 +206,46 @@ class GraphEvaluator:
         outs = (ctypes.c_void_p * len(evaluators))(*d_outs)
         lib.check(lib.c.mira_graph_eval_batch(handles, len(evaluators), cols, len(columns), ch.ctypes.data_as(ctypes.c_void_p), len(ch), num_rows, outs))
 
+    @staticmethod
+    def _column_table(columns):
+        cols = (_lib.MiraEvalColumn * max(1, len(columns)))()
+        for k, c in enumerate(columns):
+            cols[k].d_data, cols[k].kind = (None, 0) if c is None else (c[0], c[1])
+        return cols
+
+    @staticmethod
+    def specialize(evaluators, columns, num_challenges, lib=None):
+        """mira_graph_specialize: every one of these graphs gets a kernel of its own, compiled for the device at run
+        time from its instruction stream (once per circuit: the gate polynomial is fixed for the whole IVC run).  Only
+        the KINDS of `columns` matter here.  Returns True when the graphs are specialised, False when the library has
+        no run-time compiler at hand (they stay interpreted: same values, about half the rate)."""
+        lib = lib or _lib.load()
+        evaluators = [ev for ev in evaluators if ev is not None]
+        if not evaluators:
+            return True
+        handles = (ctypes.c_uint64 * len(evaluators))(*[ev.compiled(num_challenges, len(columns), lib) for ev in evaluators])
+        rc = lib.c.mira_graph_specialize(handles, len(evaluators), GraphEvaluator._column_table(columns), len(columns))
+        if rc == _lib.MIRA_E_UNSUPPORTED:
+            return False
+        lib.check(rc)
+        return True
+
+    def is_specialized(self, num_challenges, num_columns, lib=None):
+        lib = lib or _lib.load()
+        out = ctypes.c_int32()
+        lib.check(lib.c.mira_graph_is_specialized(self.compiled(num_challenges, num_columns, lib), ctypes.byref(out)))
+        return bool(out.value)
+
+    def jit_source(self, columns, num_challenges, lib=None):
+        """mira_graph_jit_source: the HIP source mira_graph_specialize would compile for this graph over columns of these kinds."""
+        lib = lib or _lib.load()
+        h = self.compiled(num_challenges, len(columns), lib)
+        cols, n = GraphEvaluator._column_table(columns), ctypes.c_size_t()
+        lib.check(lib.c.mira_graph_jit_source(h, cols, len(columns), None, 0, ctypes.byref(n)))
+        buf = ctypes.create_string_buffer(n.value + 1)
+        lib.check(lib.c.mira_graph_jit_source(h, cols, len(columns), buf, n.value + 1, ctypes.byref(n)))
+        return buf.value.decode()
+
     def evaluate(self, getter, lib=None):
         """Host-array convenience: getter = dict(selectors=[bool arrays], fixed=[(n, 4) uint64],
         advice=[(n, 4) uint64], challenges=[ints]) as the reference's test mock
@@ -366,6 +406,7 @@ class CrossTermPlan:
         ainv = [row[m:] for row in A]                                      # ainv[k - 1][index of x]
         # coefficients of T_k (k = 1 .. d - 1) on [p_0, p_inf, p_x ...]
         self.coeffs = [[(-sum(ainv[k])) % mod, (-sum(ainv[k][r] * pow(x, d, mod) for r, x in enumerate(xs))) % mod] + ainv[k] for k in range(m)]
+        self._coeffs_mont = {}                                             # the same in the library's form, converted once
 
     @classmethod
     def from_compressed_gates(cls, cg, ctx, field=FIELD_FR):
@@ -376,6 +417,10 @@ class CrossTermPlan:
     def num_calculations(self):
         return [ev.num_intermediates for ev in self.evaluators]
 
+    def specialize(self, columns, num_challenges, lib=None):
+        """One run-time compiled kernel per evaluation point (GraphEvaluator.specialize); once per circuit."""
+        return GraphEvaluator.specialize(self.evaluators, columns, num_challenges, lib=lib)
+
     def evaluate_device(self, columns, challenges, num_rows, d_terms, lib=None):
         """d_terms: device buffer of degree x num_rows elements; term k (1 .. d) lands at d_terms + (k - 1) * num_rows * 32,
         the layout commit_cross_terms hands to mira_msm_batch_device and mira_fold_error_device."""
@@ -384,16 +429,40 @@ class CrossTermPlan:
         if d == 1:                                                         # one cross term: the leading coefficient
             self.evaluators[1].evaluate_device(columns, challenges, n, d_out=d_terms, lib=lib)
             return
-        d_p = lib.alloc((d + 1) * max(1, n) * 32)
+        d_p = self._scratch(lib, (d + 1) * max(1, n) * 32)                 # kept between fold steps: an allocation and a release of 29 MiB cost 0.3 ms per call
+        outs = [d_p + j * n * 32 for j in range(d + 1)]
+        outs[1] = d_terms + (d - 1) * n * 32                               # p_inf IS T_d
+        GraphEvaluator.evaluate_batch_device(self.evaluators, columns, challenges, n, outs, lib=lib)
+        vecs = (ctypes.c_void_p * (d + 1))(*outs)
+        for k0 in range(0, d - 1, 8):                                      # mira_lincomb_multi_device: up to 8 terms per sweep over the d + 1 vectors
+            ks = range(k0, min(d - 1, k0 + 8))
+            c = self._coeffs_mont.get(k0)
+            if c is None:
+                c = self._coeffs_mont[k0] = to_montgomery([v for k in ks for v in self.coeffs[k]], self.field)
+            dst = (ctypes.c_void_p * len(ks))(*[d_terms + k * n * 32 for k in ks])
+            lib.check(lib.c.mira_lincomb_multi_device(self.field, dst, len(ks), vecs, d + 1, c.ctypes.data_as(ctypes.c_void_p), n))
+
+    def _scratch(self, lib, nbytes):
+        have = self.__dict__.get("_scratch_buf")
+        if have and have[0] is lib and have[2] >= nbytes:
+            return have[1]
+        if have:
+            have[0].free(have[1])
+        self._scratch_buf = (lib, lib.alloc(nbytes), nbytes)
+        return self._scratch_buf[1]
+
+    def close(self):
+        """Release the evaluation scratch and the compiled graphs."""
+        have = self.__dict__.pop("_scratch_buf", None)
+        if have:
+            have[0].free(have[1])
+        for ev in self.evaluators:
+            ev.close()
+
+    def __del__(self):
         try:
-            outs = [d_p + j * n * 32 for j in range(d + 1)]
-            outs[1] = d_terms + (d - 1) * n * 32                           # p_inf IS T_d
-            GraphEvaluator.evaluate_batch_device(self.evaluators, columns, challenges, n, outs, lib=lib)
-            vecs = (ctypes.c_void_p * (d + 1))(*outs)
-            for k0 in range(0, d - 1, 8):                                  # mira_lincomb_multi_device: up to 8 terms per sweep over the d + 1 vectors
-                ks = range(k0, min(d - 1, k0 + 8))
-                c = to_montgomery([v for k in ks for v in self.coeffs[k]], self.field)
-                dst = (ctypes.c_void_p * len(ks))(*[d_terms + k * n * 32 for k in ks])
-                lib.check(lib.c.mira_lincomb_multi_device(self.field, dst, len(ks), vecs, d + 1, c.ctypes.data_as(ctypes.c_void_p), n))
-        finally:
-            lib.free(d_p)
+            have = self.__dict__.pop("_scratch_buf", None)
+            if have:
+                have[0].free(have[1])
+        except Exception:
+            pass

@@ -38,7 +38,7 @@ def test_specialised_random_graphs(gpu_lib, field, log_rows, seed):
             assert not ge.is_specialized(len(arrs["challenges"]), len(cols), lib=gpu_lib)
             evs.append(ge); wants.append(want)
         src = evs[1].jit_source(cols, len(arrs["challenges"]), lib=gpu_lib)
-        assert "mira_jit_eval" in src and "jit_col_bool" in src
+        assert "mira_jit_eval" in src and "jit_bool(c" in src
         assert G.GraphEvaluator.specialize(evs[:3], cols, len(arrs["challenges"]), lib=gpu_lib), gpu_lib.c.mira_last_error()
         assert all(ev.is_specialized(len(arrs["challenges"]), len(cols), lib=gpu_lib) for ev in evs[:3])
         assert not evs[3].is_specialized(len(arrs["challenges"]), len(cols), lib=gpu_lib)

@@ -165,6 +165,9 @@ int mira_msm_last_table_bits(int32_t *table_bits);
 #define MIRA_TUNE_TABLE_WIDTH 8
 /* column reads a specialised cross-term kernel keeps in flight ahead of their use (mira_graph_specialize); default 4 */
 #define MIRA_TUNE_JIT_LOADS_AHEAD 9
+/* smallest number of sorted entries one lane of k_accumulate adds (shorter segments: more lanes busy on a small commit,
+ * more cut runs for the fix-up); default 10 */
+#define MIRA_TUNE_MIN_SEGMENT 10
 int mira_set_tuning(int knob, int64_t value);
 
 /* Read a range of the registered key back in the reference layout (cache file writing,

@@ -117,7 +117,7 @@ static int upload_consts() {
 // Estimated time of one submission in microseconds for window width c.
 //
 // Dense vectors: measured.  plan_wall_us[r][c] is the wall time of one commit of 2^plan_log_n[r]
-// uniform scalars under width c on MI355X (tools/plan_calibrate.py, one box, one run, profiles/r03_b_plan_calibrate.txt; boxes differ
+// uniform scalars under width c on MI355X (tools/plan_calibrate.py, one box, one run, profiles/r03_d_plan_calibrate.txt; boxes differ
 // by 5 - 10 %, the ORDER of the widths within a row is what is used).  Between rows: linear in
 // log2 n; beyond the last row: proportional to n.
 //
@@ -133,16 +133,16 @@ static int upload_consts() {
 static const int plan_log_n[10] = {6, 10, 13, 15, 16, 17, 18, 19, 20, 21};
 static const double plan_wall_us[10][17] = {
     //            c = 4     5     6     7     8     9    10    11    12    13    14    15    16
-    {0, 0, 0, 0,   221,   233,   263,   285,   340,   372,   378,   424,   420,   516,   557,   921,   893},
-    {0, 0, 0, 0,   299,   245,   286,   289,   260,   310,   351,   352,   436,   518,   604,   685,   813},
-    {0, 0, 0, 0,   294,   276,   310,   354,   321,   327,   330,   347,   375,   493,   547,   656,   757},
-    {0, 0, 0, 0,   396,   402,   401,   390,   393,   489,   423,   434,   453,   530,   592,   656,   720},
-    {0, 0, 0, 0,   516,   483,   499,   512,   401,   490,   529,   461,   474,   601,   657,   659,   781},
-    {0, 0, 0, 0,   783,   694,   686,   697,   551,   597,   634,   723,   571,   633,   718,   735,   839},
-    {0, 0, 0, 0,  1310,  1127,  1056,  1020,   841,   860,   875,   937,   787,   814,   886,   879,   949},
-    {0, 0, 0, 0,  2450,  2076,  1851,  1708,  1413,  1522,  1394,  1376,  1190,  1160,  1207,  1170,  1215},
-    {0, 0, 0, 0,  4803,  3984,  3484,  3133,  2667,  2746,  2436,  2328,  1997,  1957,  1934,  1827,  1854},
-    {0, 0, 0, 0,  9521,  7961,  7017,  6183,  5248,  5336,  4607,  4349,  3792,  3554,  3459,  3208,  3167},
+    {0, 0, 0, 0,   198,   201,   227,   246,   293,   300,   312,   381,   379,   479,   521,   895,   905},
+    {0, 0, 0, 0,   277,   263,   267,   270,   237,   278,   325,   315,   384,   452,   542,   612,   726},
+    {0, 0, 0, 0,   301,   298,   303,   314,   288,   306,   313,   331,   345,   452,   504,   577,   665},
+    {0, 0, 0, 0,   377,   388,   401,   343,   344,   425,   443,   427,   440,   470,   546,   597,   707},
+    {0, 0, 0, 0,   505,   479,   488,   535,   398,   458,   521,   539,   468,   535,   598,   606,   727},
+    {0, 0, 0, 0,   769,   688,   674,   695,   545,   595,   604,   710,   559,   606,   680,   692,   791},
+    {0, 0, 0, 0,  1311,  1126,  1045,  1014,   830,   858,   841,   929,   785,   806,   876,   867,   945},
+    {0, 0, 0, 0,  2434,  2016,  1856,  1707,  1410,  1496,  1382,  1367,  1185,  1158,  1203,  1163,  1205},
+    {0, 0, 0, 0,  4812,  4027,  3504,  3120,  2645,  2733,  2427,  2347,  2046,  1950,  1928,  1811,  1837},
+    {0, 0, 0, 0,  9716,  7999,  7002,  6254,  5259,  5270,  4675,  4343,  3871,  3564,  3452,  3171,  3128},
 };
 static double plan_table_us(uint32_t c, double n_eff) {
     const double x = std::log2(std::max(n_eff, 1.0));
@@ -222,7 +222,7 @@ static MsmPlan make_plan(size_t n, int32_t forced_c, uint32_t count = 1, uint64_
     // segment length on the device from the number of non-zero digits); 142 VGPRs -> 3 waves/SIMD
     uint64_t entries = (uint64_t)n * p.Wt;
     p.lanes = 256u * 4u * 3u * 64u;
-    p.L = 16;   // minimum segment length (small MSMs: more, shorter segments beat fewer fix-up links)
+    p.L = (uint32_t)tuned(MIRA_TUNE_MIN_SEGMENT, 10);   // minimum segment length: more, shorter segments keep the lanes of a small commit busy (16 -> 10: 2^15 pairs 0.40 -> 0.35 ms), below 10 the cut runs cost the fix-up more than the additions gain (tools/min_segment_probe.py)
     p.T = (uint32_t)std::min<uint64_t>(p.lanes, ceil_div(entries, p.L));   // upper bound of segments
     // reduction chunk: the chain is 2m running-sum adds, then ceil(B/m/512) + 9 in k_window_sum
     p.m = std::min<uint32_t>(p.B, p.B <= 4096 ? 4 : 8);    // measured (tools/window_probe.py): 4 / 8 beat 16 and 32 at every size
@@ -240,7 +240,9 @@ static MsmPlan make_plan_shared(size_t n, const Bases::SharedSet &set, uint64_t 
     MsmPlan p = make_plan(n, (int32_t)set.c, count, stride);
     p.shared = true; p.shared_tables = set.p; p.table_n = table_n;
     p.NB = count * p.B;                                      // one bucket set per MSM
-    p.m = 4;                                                 // the chain of the reduction is what counts here
+    // the chain of the reduction is what counts here: chunks of four buckets, by quads of lanes -- of eight where four would
+    // leave more chunks than quads fit (a batch of 16-bit sets: 6 x 8192 chunks by single lanes took 0.19 ms, 6 x 4096 by quads 0.1x)
+    p.m = (uint64_t)count * p.B / 4 > 24576 ? 8 : 4;
     p.nchunks = p.B / p.m;
     p.sums = std::min<uint32_t>(SHARED_SUMS, p.nchunks);
     return p;
@@ -252,12 +254,12 @@ static MsmPlan make_plan_shared(size_t n, const Bases::SharedSet &set, uint64_t 
 static const int shared_log_n[6] = {12, 14, 16, 17, 19, 21};
 static const double shared_wall_us[6][17] = {
     //                          c = 8     9    10    11    12    13    14    15    16
-    {0, 0, 0, 0, 0, 0, 0, 0,   263,  265,  260,  300,  297,  265,  316,  290,  345},
-    {0, 0, 0, 0, 0, 0, 0, 0,   277,  286,  301,  306,  335,  337,  347,  306,  323},
-    {0, 0, 0, 0, 0, 0, 0, 0,   378,  362,  386,  409,  404,  454,  504,  428,  439},
-    {0, 0, 0, 0, 0, 0, 0, 0,   539,  515,  511,  511,  585,  533,  567,  561,  576},
-    {0, 0, 0, 0, 0, 0, 0, 0,  1477, 1514, 1347, 1266, 1248, 1123, 1151, 1007,  979},
-    {0, 0, 0, 0, 0, 0, 0, 0,  5684, 5620, 5023, 4521, 4120, 3641, 3519, 3084, 2957},
+    {0, 0, 0, 0, 0, 0, 0, 0,   238,   249,   244,   285,   285,   285,   293,   268,   311},
+    {0, 0, 0, 0, 0, 0, 0, 0,   294,   301,   309,   324,   347,   322,   348,   283,   298},
+    {0, 0, 0, 0, 0, 0, 0, 0,   366,   363,   375,   405,   453,   411,   441,   418,   437},
+    {0, 0, 0, 0, 0, 0, 0, 0,   532,   512,   506,   514,   571,   519,   539,   501,   532},
+    {0, 0, 0, 0, 0, 0, 0, 0,  1412,  1438,  1290,  1211,  1218,  1082,  1117,   978,   955},
+    {0, 0, 0, 0, 0, 0, 0, 0,  5677,  5603,  4802,  4429,  4033,  3733,  3514,  3057,  2926},
 };
 static double shared_cost_us(uint32_t c, double n) {
     const double x = std::log2(std::max(n, 1.0));
@@ -269,15 +271,26 @@ static double shared_cost_us(uint32_t c, double n) {
         }
     return shared_wall_us[5][c] * n / std::exp2((double)shared_log_n[5]);
 }
-// sharded: every rank must pick the same set whatever its chunk length -> the widest
-static const Bases::SharedSet *pick_shared(const Bases &bs, size_t n, uint32_t count, bool sharded) {
+// sharded: every rank must pick the same set whatever its chunk length -> the widest.  bitlen_hist (or null): the bit
+// lengths of the scalars of the previous commit of this shape -- a witness vector (mostly zeros and short values) is looked
+// up as the dense vector with as many bucket additions, as the per-window planner does (1.8 M witness scalars are 0.23 M
+// dense ones under 16-bit windows: a narrow set serves them, not the 16-bit one their length suggests).
+static const Bases::SharedSet *pick_shared(const Bases &bs, size_t n, uint32_t count, bool sharded, const uint32_t *bitlen_hist = nullptr) {
     if (bs.shared.empty()) return nullptr;
     const size_t forced = tuned(MIRA_TUNE_TABLE_WIDTH, 0);
     const Bases::SharedSet *best = nullptr;
-    double best_us = 1e300;
+    double best_us = 1e300, h[256];
+    if (bitlen_hist)
+        for (int len = 0; len < 256; len++) h[len] = (double)bitlen_hist[len];
     for (const auto &set : bs.shared) {
         if (forced) { if (set.c == forced) return &set; continue; }
-        const double us = sharded ? -(double)set.c : shared_cost_us(set.c, (double)n * count);
+        double n_eff = (double)n * count;
+        if (bitlen_hist) {
+            double adds, load;
+            plan_len_stats(set.c, h, &adds, &load);
+            n_eff = std::max(1.0, adds / set.W);
+        }
+        const double us = sharded ? -(double)set.c : shared_cost_us(set.c, n_eff);
         if (us < best_us) { best_us = us; best = &set; }
     }
     return best;
@@ -331,18 +344,20 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
     // uses the wide tables where they pay and a shared set below.
     const bool tables_ok = forced_c == 0 && requested_c == 0;
     const bool table_mode = bs.tables && tables_ok && (sharded || n >= tuned(MIRA_TUNE_TABLE_MIN_N, TABLE_MIN_N));
-    const Bases::SharedSet *set = (tables_ok && !table_mode && (sharded || n >= tuned(MIRA_TUNE_TABLE_MIN_N, TABLE16_MIN_N))) ? pick_shared(bs, n, 1, sharded) : nullptr;
     // Data-dependent planning for single (unsharded) commits (ranks of a sharded MSM must agree on
     // the window width, so they keep the dense estimate).  The statistics are those of the previous
     // commit of the same length over this key -- successive fold steps commit witnesses of one
     // shape -- so no call waits for a pre-pass: this call's histogram is enqueued ahead of its MSM
     // kernels and read after the synchronisation that ends it.
     const size_t hist_min_n = tuned(MIRA_TUNE_PLAN_HIST_MIN_N, PLAN_HIST_MIN_N);
-    const bool use_hist = !table_mode && !set && !sharded && forced_c == 0 && n >= hist_min_n && d_scalars;
+    const bool can_hist = !table_mode && !sharded && forced_c == 0 && requested_c == 0 && n >= hist_min_n && d_scalars;
+    const uint32_t *stat = (can_hist && bs.stat_n == n) ? bs.stat_hist : nullptr;
+    const Bases::SharedSet *set = (tables_ok && !table_mode && (sharded || n >= tuned(MIRA_TUNE_TABLE_MIN_N, TABLE16_MIN_N))) ? pick_shared(bs, n, 1, sharded, stat) : nullptr;
+    const bool use_hist = can_hist && !set;
     // a rank of a sharded MSM that was not given a width takes 16, whatever its chunk length: partials
     // of different widths cannot be combined, and chunk lengths differ between ranks
     const int32_t width = requested_c ? requested_c : (sharded && forced_c == 0) ? 16 : forced_c;
-    MsmPlan p = make_plan(n, width, 1, 0, (use_hist && bs.stat_n == n) ? bs.stat_hist : nullptr);
+    MsmPlan p = make_plan(n, width, 1, 0, use_hist ? stat : nullptr);
     if (n >= (1ull << 31) || (uint64_t)n * p.W >= (1ull << 32)) { set_error("n too large for 32-bit entry offsets"); return MIRA_E_UNSUPPORTED; }
     if (p.W > MIRA_MAX_WINDOWS) { set_error("window configuration exceeds MIRA_MAX_WINDOWS"); return MIRA_E_UNSUPPORTED; }
     *c_out = p.c; *W_out = p.W;
@@ -356,8 +371,14 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
         if ((uint64_t)n * ps.W >= (1ull << 32)) { set_error("n too large for 32-bit entry offsets"); return MIRA_E_UNSUPPORTED; }
         *c_out = 0; *W_out = ps.sums;                       // partial sums, combined by a plain sum
         g.last_c = 0; g.last_w = (int32_t)ps.sums; g.last_table_c = (int32_t)set->c;
-        return bs.curve == MIRA_CURVE_BN256 ? msm_launch_bn256(bs, first, d_scalars, h_scalars, n, ps, out_partial)
-                                             : msm_launch_grumpkin(bs, first, d_scalars, h_scalars, n, ps, out_partial);
+        ps.stats = can_hist;
+        rc = bs.curve == MIRA_CURVE_BN256 ? msm_launch_bn256(bs, first, d_scalars, h_scalars, n, ps, out_partial)
+                                          : msm_launch_grumpkin(bs, first, d_scalars, h_scalars, n, ps, out_partial);
+        if (rc == MIRA_OK && can_hist) {                     // msm_launch ends with a stream synchronisation
+            memcpy(bs.stat_hist, g.hist_host, sizeof bs.stat_hist);
+            bs.stat_n = n;
+        }
+        return rc;
     }
     if (table_mode) {
         if (h_scalars) RT_CHECK(rt_h2d(const_cast<void *>(d_scalars), h_scalars, n * 32, g.stream));
@@ -725,7 +746,7 @@ int mira_msm_combine(int curve, const uint64_t *partials, size_t nparts, int32_t
 }
 int mira_set_tuning(int knob, int64_t value) {
     std::lock_guard<std::mutex> lk(g_lock);
-    if (knob < 0 || knob > MIRA_TUNE_JIT_LOADS_AHEAD) { set_error("unknown tuning knob"); return MIRA_E_BAD_ARG; }
+    if (knob < 0 || knob > MIRA_TUNE_MIN_SEGMENT) { set_error("unknown tuning knob"); return MIRA_E_BAD_ARG; }
     g.tune[knob] = value;
     return MIRA_OK;
 }

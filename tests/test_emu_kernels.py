@@ -298,6 +298,10 @@ def test_emu_shared_bucket_tables_other_widths(emu_lib, tune):
     assert (key.commit(dense) == want_dense).all() and (key.commit(sc) == want).all()
     tune(_lib.TUNE_TABLE_WIDTH, -1)                           # the length picks a set
     assert (key.commit(dense) == want_dense).all() and last_table() in (8, 11, 13, 15)
+    # ... and, from the second commit of a shape on, the bit lengths of the previous one do (they never change a result)
+    tune(_lib.TUNE_PLAN_HIST_MIN_N, 1)
+    for v, w in ((sc, want), (sc, want), (dense, want_dense), (dense, want_dense), (sc, want)):
+        assert (key.commit(v) == w).all() and last_table() in (8, 11, 13, 15)
 
 
 def test_emu_data_dependent_planning(emu_lib, tune):

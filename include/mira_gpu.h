@@ -77,9 +77,10 @@ int mira_msm_precompute(uint64_t handle);
  * W additions per pair, the fix-up and bucket reduction of one window instead of W, and no Horner
  * epilogue on the host -- the latency-bound part of the small commits of a fold step.  Several shared
  * widths may be built beside each other (and beside the wide tables): every commit of >= 2^12 pairs
- * picks the set that is fastest for its length (narrow for 2^17 pairs, 16 bits for 2^21), commits of
+ * picks the set that is fastest for its length (narrow for 2^17 pairs, 16 bits for 2^21) and -- from the second commit of
+ * a shape on -- for the bit lengths of its scalars (a witness vector of mostly zeros is served like the short dense one it amounts to), commits of
  * >= 2^18 pairs the wide tables when the key has them.  mira_msm_partial_device reports window_bits = 0,
- * num_windows = 16 (fewer below 8 buckets per sum); a rank of a sharded MSM takes the wide tables if
+ * num_windows = 16; a rank of a sharded MSM takes the wide tables if
  * present, else the widest shared set, whatever its chunk length.  Results are bit-identical whichever
  * set serves a commit.  Building a width twice is a no-op. */
 int mira_msm_precompute_ex(uint64_t handle, int32_t window_bits);

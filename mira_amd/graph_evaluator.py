@@ -381,7 +381,8 @@ class CrossTermPlan:
             def fold(first, second):                                       # first + x * second in the cheapest calculations
                 if x == 0:
                     return first
-                mag = second if abs(x) == 1 else Product(Constant(2), second) if abs(x) == 2 else Scaled(second, abs(x))   # (2 * v is a DOUBLE)
+                two = Product(Constant(2), second)                         # (2 * v is a DOUBLE)
+                mag = second if abs(x) == 1 else two if abs(x) == 2 else Sum(two, second) if abs(x) == 3 else Scaled(second, abs(x))   # 3 v = 2 v + v: no product
                 return Sum(first, mag if x > 0 else Negated(mag))          # a + (-b) is one SUB
 
             def chal(i):

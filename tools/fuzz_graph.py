@@ -11,7 +11,7 @@ from oracle import cref as C
 lib = _lib.load()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-t_end, graphs, ntts, biggest = time.time() + budget, 0, 0, 0
+t_end, graphs, ntts, biggest, jitted = time.time() + budget, 0, 0, 0, 0
 while time.time() < t_end:
     field = rng.randrange(2)
     mod = MODS[field]
@@ -26,6 +26,13 @@ while time.time() < t_end:
     got = ge.evaluate(arrs, lib=lib)
     assert (got == want).all(), (field, n, ge.num_intermediates)
     graphs += 1; biggest = max(biggest, ge.num_intermediates)
+    if graphs % 6 == 0:                                   # the same graph through a run-time compiled kernel of its own
+        kinds = [(1, G.COL_BOOL)] * nsel + [(1, G.COL_FIELD)] * (nfix + nadv)
+        if G.GraphEvaluator.specialize([ge], kinds, len(ints["challenges"]), lib=lib):
+            assert ge.is_specialized(len(ints["challenges"]), ncols, lib=lib)
+            assert (ge.evaluate(arrs, lib=lib) == want).all(), ("specialised", field, n, ge.num_intermediates)
+            jitted += 1
+    ge.close()
     if graphs % 10 == 0:
         k = rng.randrange(0, 19)
         a = C.synth_scalars(0, 1 << k, seed=rng.getrandbits(30), kind=rng.randrange(2))
@@ -34,4 +41,4 @@ while time.time() < t_end:
         got = getattr(F, op)(a, k) if op in ("fft", "ifft") else getattr(F, op)(a)
         assert (got == want).all(), (op, k)
         ntts += 1
-print(f"fuzz: {graphs} graphs (largest {biggest} calculations) and {ntts} transforms, all bit-exact", flush=True)
+print(f"fuzz: {graphs} graphs (largest {biggest} calculations; {jitted} of them also through a specialised kernel) and {ntts} transforms, all bit-exact", flush=True)

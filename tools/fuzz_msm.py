@@ -64,11 +64,15 @@ while time.time() < t_end:
             assert (got == got2).all(), desc
         elif mode == "tables" and n <= (1 << 16):
             lib.check(lib.c.mira_msm_set_window_bits(0))
-            key.precompute(rng.choice([16, 16, 20, 20, 22]))
+            for width in rng.sample([8, 9, 10, 11, 12, 13, 14, 15, 16, 16, 20, 22], rng.randrange(1, 4)):   # several sets beside each other (one wide one at most)
+                if width < 20 or not getattr(key, "_wide", False):
+                    key.precompute(width)
+                    key._wide = getattr(key, "_wide", False) or width >= 20
             got = key.commit(sc)
+            assert (got == key.commit(sc)).all(), desc      # second call: the set chosen from the first one's statistics
         elif mode == "tables_batch" and n <= (1 << 16):     # 16-bit shared-bucket tables, one bucket set per commitment
             lib.check(lib.c.mira_msm_set_window_bits(0))
-            key.precompute(16)
+            key.precompute(rng.choice([8, 10, 12, 13, 15, 16]))
             m = max(1, n // 2)
             vs = [sc[:m], scalars(cid, m, rng.randrange(3)), np.zeros((m, 4), dtype=np.uint64)]
             res = key.commit_batch(vs)

@@ -860,6 +860,7 @@ int graph_specialize(const uint64_t *handles, uint32_t count, const mira_eval_co
     for (auto &t : workers) t.join();
     for (size_t k = 0; k < todo.size(); k++)
         if (code[k].empty()) { set_error(errs[k]); return MIRA_E_UNSUPPORTED; }
+    if (compiled.size() + fresh.size() > 256) compiled.clear();   // a bound on what a long-lived process keeps (a code object is ~200 KiB)
     for (size_t k : fresh) compiled[src[k]] = code[k];
     std::vector<hipModule_t> mods(todo.size(), nullptr);
     std::vector<hipFunction_t> fns(todo.size(), nullptr);

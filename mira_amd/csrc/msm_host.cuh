@@ -229,8 +229,8 @@ static int msm_launch_body(const Bases &bs, size_t first, const void *d_scalars,
     if (g.windows_dst) {                                     // mira_msm_partial_to_device: the sums stay in device memory
         RT_CHECK(rt_d2d(g.windows_dst, g.window_sums.p, (size_t)nsum * 128, st));
         RT_CHECK(rt_sync(st));
-    } else if (p.stats) {                                    // sums and statistics in one copy, through pinned memory
-        const size_t bytes = (size_t)nsum * 128 + 1024;
+    } else {                                                 // sums (and statistics) in one copy, through pinned memory
+        const size_t bytes = (size_t)nsum * 128 + (p.stats ? 1024 : 0);
         if (g.out_host_cap < bytes) {
             if (g.out_host) (void)rt_host_free(g.out_host);
             g.out_host = nullptr; g.out_host_cap = 0;
@@ -240,10 +240,7 @@ static int msm_launch_body(const Bases &bs, size_t first, const void *d_scalars,
         RT_CHECK(rt_d2h(g.out_host, g.window_sums.p, bytes, st));
         RT_CHECK(rt_sync(st));
         memcpy(host_windows, g.out_host, (size_t)nsum * 128);
-        memcpy(g.hist_host, g.out_host + (size_t)nsum * 128, 1024);
-    } else {
-        RT_CHECK(rt_d2h(host_windows, g.window_sums.p, (size_t)nsum * 128, st));
-        RT_CHECK(rt_sync(st));
+        if (p.stats) memcpy(g.hist_host, g.out_host + (size_t)nsum * 128, 1024);
     }
     tm_end();
     return MIRA_OK;

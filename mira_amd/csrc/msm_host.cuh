@@ -5,6 +5,7 @@
 #include "msm_kernels.cuh"
 #include "table_kernels.cuh"
 #include "sort_kernels.cuh"
+#include "host_field.hpp"
 #include <cerrno>
 #include <thread>
 #include <unistd.h>
@@ -91,7 +92,7 @@ static int msm_launch_body(const Bases &bs, size_t first, const void *d_scalars,
     if ((rc = g.heavy.ensure(64 + ((size_t)p.T / 2 + 8) * 32))) return rc;            // counters, runs, sub-job descriptors
     if ((rc = g.heavy_out.ensure(((size_t)p.T / 2 + 8) * XYZZ29_BYTES))) return rc;
     if ((rc = g.chunks.ensure((size_t)(p.shared ? p.count : p.Wt) * p.nchunks * XYZZ29_BYTES))) return rc;
-    if ((rc = g.window_sums.ensure((size_t)std::max(p.Wt, p.count * p.sums) * 128 + 1024))) return rc;   // + the planning statistics
+    if ((rc = g.window_sums.ensure((size_t)std::max(p.Wt * 4, p.count * p.sums) * 128 + 1024))) return rc;   // (up to four partial sums per window) + the planning statistics
 #ifndef MIRA_CPU_EMU
     if (h_scalars) {
         if (!g.copy_stream) RT_CHECK(hipStreamCreateWithFlags(&g.copy_stream, hipStreamNonBlocking));
@@ -207,8 +208,14 @@ static int msm_launch_body(const Bases &bs, size_t first, const void *d_scalars,
         tm_mark("fixup");
     }
     // bucket sets: one per window, or one per MSM (shared: the chunk results of a set are summed by `sums` workgroups)
-    const uint32_t Wb = p.shared ? p.count : p.Wt, nsum = p.shared ? p.count * p.sums : p.Wt, per_sum = p.shared ? p.nchunks / p.sums : p.nchunks;
-    const uint64_t items = (uint64_t)Wb * p.nchunks;
+    const uint64_t items = (uint64_t)(p.shared ? p.count : p.Wt) * p.nchunks;
+    // A single large per-window commit (2^22 pairs under 16-bit windows: 16 windows of 4096 chunk results) gives k_window_sum one
+    // workgroup per window -- 16 lone workgroups, 8 + 9 dependent additions each, 0.17 ms.  Four workgroups per window take a
+    // quarter of the chunks each and the host adds the four partial sums of every window (48 additions, 10 us) before its Horner
+    // chain.  Not for batches (hundreds of windows already; the host additions would cost more than the kernel) nor where the
+    // sums stay on the device.
+    const uint32_t split = (!p.shared && p.count == 1 && !g.windows_dst && !reduce_with_quads(items) && p.nchunks >= 2048 && p.Wt <= 16) ? 4u : 1u;
+    const uint32_t Wb = p.shared ? p.count : p.Wt, nsum = p.shared ? p.count * p.sums : p.Wt * split, per_sum = p.shared ? p.nchunks / p.sums : p.nchunks / split;
     if (reduce_with_quads(items)) {
         LAUNCH((k_reduce_chunks<F, true>), ceil_div(items * 4, 64), 64, 0, st, reinterpret_cast<const unsigned char *>(g.bucket_sums.p),
                p.B, p.m, Wb, reinterpret_cast<unsigned char *>(g.chunks.p));
@@ -239,7 +246,19 @@ static int msm_launch_body(const Bases &bs, size_t first, const void *d_scalars,
         }
         RT_CHECK(rt_d2h(g.out_host, g.window_sums.p, bytes, st));
         RT_CHECK(rt_sync(st));
-        memcpy(host_windows, g.out_host, (size_t)nsum * 128);
+        if (split == 1) memcpy(host_windows, g.out_host, (size_t)nsum * 128);
+        else {
+            using FB = typename F::Sat;
+            for (uint32_t w = 0; w < p.Wt; w++) {
+                hostf::HXyzz<FB> acc = hostf::identity<FB>();
+                for (uint32_t k = 0; k < split; k++) {
+                    hostf::HXyzz<FB> t;
+                    memcpy(&t, g.out_host + ((size_t)w * split + k) * 128, 128);
+                    acc = hostf::add_pt(acc, t);
+                }
+                memcpy(host_windows + (size_t)w * 16, &acc, 128);
+            }
+        }
         if (p.stats) memcpy(g.hist_host, g.out_host + (size_t)nsum * 128, 1024);
     }
     tm_end();

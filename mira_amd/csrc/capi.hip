@@ -8,6 +8,8 @@
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <thread>
+#include <condition_variable>
+#include <functional>
 #include <unistd.h>
 
 #ifdef MIRA_CPU_EMU
@@ -296,6 +298,67 @@ static const Bases::SharedSet *pick_shared(const Bases &bs, size_t n, uint32_t c
     return best;
 }
 
+// A few resident host threads for the independent epilogues of a batch (creating and joining five threads per batch cost more
+// than the 45 us chain each of them ran).  The pool is created on first use and never destroyed: its threads sleep on a
+// condition variable until the process ends.  Callers hold the ABI lock, so there is one parallel_for at a time.
+#ifndef MIRA_CPU_EMU
+namespace {
+struct HostPool {
+    std::mutex m;
+    std::condition_variable wake, done_cv;
+    const std::function<void(size_t)> *fn = nullptr;
+    size_t next = 0, count = 0, running = 0;
+    uint64_t epoch = 0;
+    std::vector<std::thread> threads;
+    explicit HostPool(size_t n) {
+        for (size_t t = 0; t < n; t++)
+            threads.emplace_back([this] {
+                uint64_t seen = 0;
+                std::unique_lock<std::mutex> lk(m);
+                for (;;) {
+                    wake.wait(lk, [&] { return epoch != seen && next < count; });
+                    seen = epoch;
+                    while (next < count) {
+                        const size_t i = next++;
+                        running++;
+                        lk.unlock();
+                        (*fn)(i);
+                        lk.lock();
+                        running--;
+                    }
+                    if (running == 0) done_cv.notify_all();
+                }
+            });
+        for (auto &t : threads) t.detach();
+    }
+};
+}   // namespace
+#endif
+static void host_parallel_for(size_t count, const std::function<void(size_t)> &fn) {
+#ifdef MIRA_CPU_EMU
+    for (size_t i = 0; i < count; i++) fn(i);
+#else
+    if (count <= 1) { if (count) fn(0); return; }
+    static HostPool *pool = new HostPool(std::max<size_t>(1, std::min<size_t>(7, std::thread::hardware_concurrency() > 1 ? std::thread::hardware_concurrency() - 1 : 1)));
+    {
+        std::lock_guard<std::mutex> lk(pool->m);
+        pool->fn = &fn; pool->next = 0; pool->count = count; pool->epoch++;
+    }
+    pool->wake.notify_all();
+    std::unique_lock<std::mutex> lk(pool->m);
+    while (pool->next < pool->count) {                      // the caller works too
+        const size_t i = pool->next++;
+        pool->running++;
+        lk.unlock();
+        fn(i);
+        lk.lock();
+        pool->running--;
+    }
+    pool->done_cv.wait(lk, [&] { return pool->running == 0; });
+    pool->count = 0;
+#endif
+}
+
 // Horner over the window sums: sum_w 2^(c w) * Wsum[w], then to_affine.
 template <class FB>
 static void horner_affine(const uint64_t *windows, uint32_t c, uint32_t W, uint64_t out[8]) {
@@ -465,10 +528,7 @@ static int msm_batch_device_locked(uint64_t handle, const void *d_scalars, size_
             if (bs.curve == MIRA_CURVE_BN256) horner_affine<FqP>(w, p.c, p.W, out_affine + (done + b) * 8);
             else horner_affine<FrP>(w, p.c, p.W, out_affine + (done + b) * 8);
         };
-        std::vector<std::thread> workers;
-        for (size_t b = 1; b < cnt; b++) workers.emplace_back(epilogue, b);
-        epilogue(0);
-        for (auto &t : workers) t.join();
+        host_parallel_for(cnt, epilogue);
     }
     return MIRA_OK;
 }

@@ -608,12 +608,12 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
         single = []
         for _ in range(9):
             t0 = time.perf_counter(); keys[cm.CURVE_BN256].commit_device(cross[cm.CURVE_BN256], n); single.append((time.perf_counter() - t0) * 1e3)
-        # opt-in: shared-bucket fixed-base tables on both keys (mira_msm_precompute_ex(handle, 16), (handle, 13) and
-        # (handle, 10): 16 + 20 + 26 x the key's HBM): all windows share one bucket set, no Horner epilogue; every commit
-        # takes the set that is fastest for its length and, from the second commit of a shape on, for the bit lengths of
-        # its scalars (2^17 dense pairs: 10 bits, the witness commits: 13, the batches: 16) -- the same 13 calls, one per commit
+        # opt-in: shared-bucket fixed-base tables on both keys (mira_msm_precompute_ex(handle, 15) and (handle, 13):
+        # 18 + 20 x the key's HBM): all windows share one bucket set, no Horner epilogue; every commit takes the set that
+        # is fastest for its length and, from the second commit of a shape on, for the bit lengths of its scalars (the
+        # witness commits: 13 bits, dense 2^17-pair commits and the batches: 15) -- the same 13 calls, one per commit
         for c in plan:
-            for width in (16, 13, 10):
+            for width in (15, 13):
                 keys[c].precompute(width)
         run(False)
         t16, single16 = [], []
@@ -630,7 +630,7 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
                                "gpu_ms_host_scalars_one_call_per_commit": round(sorted(hs)[2], 3), "gpu_ms_host_scalars_batched": round(sorted(hb)[2], 3),
                                "one_commit_131072_pairs_ms": round(sorted(single)[4], 3),
                                "gpu_ms_one_call_per_commit_tables": round(sorted(t16)[2], 3), "one_commit_131072_pairs_ms_tables": round(sorted(single16)[4], 3),
-                               "gpu_ms_tables": round(sorted(t16b)[2], 3), "table_widths": [10, 13, 16],
+                               "gpu_ms_tables": round(sorted(t16b)[2], 3), "table_widths": [13, 15],
                                "tables_same_points": bool(all((a == b).all() for a, b in zip(seq_pts, t16_pts)) and all((a == b).all() for a, b in zip(seq_pts, t16b_pts))),
                                "host_scalar_bytes": 32 * sum(nw + cnt * n for nw, cnt in plan.values()),
                                "batched_equals_sequential": bool(all((a == b).all() for a, b in zip(seq_pts, bat_pts))
@@ -834,10 +834,10 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
                                             "+ interpolation: the same vectors as the reference's grouped graphs, which the CPU leg evaluates; every evaluation point through its own run-time "
                                             "compiled kernel, built once per circuit in specialize_s -- ms_interpreted_graphs: through the graph interpreter, as in earlier rounds), "
                                             "batched cross-term commits, W / E folding and instance folding (host g1_mul_add); span names follow the reference's tracing spans"}
-        # opt-in: the same chain over shared-bucket fixed-base tables (mira_msm_precompute_ex(handle, 16), (handle, 13), (handle, 10)) --
+        # opt-in: the same chain over shared-bucket fixed-base tables (mira_msm_precompute_ex(handle, 15), (handle, 13)) --
         # a commitment key is fixed for the whole IVC run, its tables are built once
         for s_ in st.values():
-            for width in (16, 13, 10):
+            for width in (15, 13):
                 s_["key"].precompute(width)
         fold_step()
         walls16 = []
@@ -846,7 +846,7 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
         wall16, spans16 = sorted(walls16, key=lambda x: x[0])[2]
         same16 = all((last16[c]["w_commit"] == last[c]["w_commit"]).all() and (last16[c]["t_commits"] == last[c]["t_commits"]).all()
                      and (last16[c]["folded_e"] == last[c]["folded_e"]).all() for c in st)
-        ex["nifs_fold_step_k17"].update({"ms_tables": round(wall16, 3), "spans_ms_tables": {a: round(b * 1e3, 3) for a, b in spans16.items()}, "table_widths": [10, 13, 16],
+        ex["nifs_fold_step_k17"].update({"ms_tables": round(wall16, 3), "spans_ms_tables": {a: round(b * 1e3, 3) for a, b in spans16.items()}, "table_widths": [13, 15],
                                          "tables_same_points": bool(same16)})
         if with_cpu:
             from oracle import cref as C

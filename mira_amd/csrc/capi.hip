@@ -286,13 +286,20 @@ static const Bases::SharedSet *pick_shared(const Bases &bs, size_t n, uint32_t c
         for (int len = 0; len < 256; len++) h[len] = (double)bitlen_hist[len];
     for (const auto &set : bs.shared) {
         if (forced) { if (set.c == forced) return &set; continue; }
-        double n_eff = (double)n * count;
+        double n_eff = (double)n * count, heavy = 0;
         if (bitlen_hist) {
-            double adds, load;
+            double adds, load, u_adds, u_load;
             plan_len_stats(set.c, h, &adds, &load);
             n_eff = std::max(1.0, adds / set.W);
+            // ... plus what the length distribution makes heavy beyond a uniform vector with as many additions (the measured table
+            // holds the latter): 32-bit witness values under 15-bit windows share TWO top-digit values, under 16-bit windows all
+            // carry a one into the third window, under 13-bit windows they spread over 32
+            plan_len_stats(set.c, plan_uniform_fractions(), &u_adds, &u_load);
+            heavy = std::max(0.0, plan_heavy_us(adds, load, 1) - plan_heavy_us(u_adds * n_eff, u_load * n_eff, 1));
         }
-        const double us = sharded ? -(double)set.c : shared_cost_us(set.c, n_eff);
+        // a batch is count bucket sets to reduce: ~1 ns per bucket of every further set (6 x 2^15 buckets: 0.19 ms of k_reduce_chunks
+        // against 0.03 for one set; profiles/r03_d_batch_tables.txt)
+        const double us = sharded ? -(double)set.c : shared_cost_us(set.c, n_eff) + heavy + (count - 1) * (double)(1u << (set.c - 1)) / 1000.0;
         if (us < best_us) { best_us = us; best = &set; }
     }
     return best;

@@ -26,6 +26,8 @@ while time.time() < t_end:
     got = ge.evaluate(arrs, lib=lib)
     assert (got == want).all(), (field, n, ge.num_intermediates)
     graphs += 1; biggest = max(biggest, ge.num_intermediates)
+    if graphs % 100 == 0:
+        print(f"{graphs} graphs ok ({jitted} specialised)", flush=True)     # (a run that is silent for seven minutes is taken to be hung)
     if graphs % 6 == 0:                                   # the same graph through a run-time compiled kernel of its own
         kinds = [(1, G.COL_BOOL)] * nsel + [(1, G.COL_FIELD)] * (nfix + nadv)
         if G.GraphEvaluator.specialize([ge], kinds, len(ints["challenges"]), lib=lib):

@@ -801,9 +801,9 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
                 d_e_new = s_["d_enew"]
                 lib.copy(d_e_new, s_["d_e"], n * 32)                                # E' starts as the accumulator's E, then the terms are folded in
                 FD.fold_error_device(s_["field"], d_e_new, [s_["d_terms"] + i * n * 32 for i in range(s_["cnt"])], s_["r"], n)
-                folded_w = FD.g1_mul_add(c, s_["acc_w"], s_["r"], w_commit)
-                powers = G.to_montgomery([pow(s_["r_int"], i + 1, G.MODULUS[s_["field"]]) for i in range(s_["cnt"])], s_["field"])
-                folded_e = FD.g1_lincomb(c, s_["acc_e"], powers, t_commits)     # E_commit + sum r^(k+1) T_k, src/plonk/mod.rs:1049-1053
+                # W1 + r W2 and E_commit + sum r^(k+1) T_k (src/plonk/mod.rs:986-999, 1049-1053), one parallel region on the host
+                folded_ws, folded_e = FD.fold_instance_commitments(c, s_["acc_w"], w_commit, s_["r"], s_["acc_e"], t_commits)
+                folded_w = folded_ws[0]
                 t4 = time.perf_counter()
                 spans["witness_commit"] += t1 - t0; spans["evaluation"] += t2 - t1; spans["commit"] += t3 - t2; spans["fold"] += t4 - t3
                 outs[c] = dict(w_commit=w_commit, t_commits=t_commits, d_e_new=d_e_new, folded_w=folded_w, folded_e=folded_e)
@@ -833,7 +833,7 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
                                     "note": "both curves, device-resident vectors: witness commit, the d cross terms of the MainGate<5> circuits (d + 1 evaluations of the gate polynomial "
                                             "+ interpolation: the same vectors as the reference's grouped graphs, which the CPU leg evaluates; every evaluation point through its own run-time "
                                             "compiled kernel, built once per circuit in specialize_s -- ms_interpreted_graphs: through the graph interpreter, as in earlier rounds), "
-                                            "batched cross-term commits, W / E folding and instance folding (host g1_mul_add); span names follow the reference's tracing spans"}
+                                            "batched cross-term commits, W / E folding and instance folding (mira_g1_fold_commitments, host threads); span names follow the reference's tracing spans"}
         # opt-in: the same chain over shared-bucket fixed-base tables (mira_msm_precompute_ex(handle, 15), (handle, 13)) --
         # a commitment key is fixed for the whole IVC run, its tables are built once
         for s_ in st.values():

@@ -187,9 +187,16 @@ int mira_fold_witness_device(int field, void *d_out, const void *d_w1, const voi
 int mira_fold_error_device(int field, void *d_e, const void *const *d_cross_terms, size_t num_terms, const uint64_t r[4], size_t n);
 int mira_g1_mul_add(int curve, const uint64_t acc[8], const uint64_t scalar[4], const uint64_t point[8], uint64_t out[8]);
 /* out = acc + sum_i scalars[i] * points[i], count <= 64: E_commit + sum_k r^(k+1) T_k over the cross-term
- * commitments (src/plonk/mod.rs:1049-1053) with one shared chain of doublings; host, O(256 + 64 count). */
+ * commitments (src/plonk/mod.rs:1049-1053); host: width-5 NAFs, the terms dealt to the library's resident host
+ * threads, one chain of doublings per thread. */
 int mira_g1_lincomb(int curve, const uint64_t acc[8], const uint64_t *scalars /* count * 4 */, const uint64_t *points /* count * 8 */,
                     size_t count, uint64_t out[8]);
+/* The commitment side of RelaxedPlonkInstance::fold in one call (src/plonk/mod.rs:986-999, 1049-1053):
+ *   w_out[i] = w1[i] + r * w2[i], i < nw <= 64;   e_out = e + sum_k r^(k+1) * t_commits[k], k < count <= 64
+ * -- the same points as nw calls of mira_g1_mul_add and one of mira_g1_lincomb over the powers of r, as ONE parallel
+ * region on the host threads (every W commitment and every group of cross-term commitments is a task). */
+int mira_g1_fold_commitments(int curve, const uint64_t r[4], const uint64_t *w1 /* nw * 8 */, const uint64_t *w2 /* nw * 8 */, size_t nw,
+                             const uint64_t e[8], const uint64_t *t_commits /* count * 8 */, size_t count, uint64_t *w_out /* nw * 8 */, uint64_t e_out[8]);
 
 /* ---- the step before the MSM in one fold: cross-term evaluation ----------------------------
  * GraphEvaluator::evaluate over all rows (src/polynomial/graph_evaluator.rs:361-390, called per

@@ -341,12 +341,28 @@ struct HostPool {
 };
 }   // namespace
 #endif
+#ifndef MIRA_CPU_EMU
+static HostPool &host_pool() {
+    static HostPool *pool = new HostPool(std::max<size_t>(1, std::min<size_t>(7, std::thread::hardware_concurrency() > 1 ? std::thread::hardware_concurrency() - 1 : 1)));
+    return *pool;                                            // never destroyed: its threads wait on it until the process ends
+}
+#endif
+// threads a parallel region can count on, the caller included
+static size_t host_parallel_width() {
+#ifdef MIRA_CPU_EMU
+    return 1;
+#else
+    return host_pool().threads.size() + 1;
+#endif
+}
 static void host_parallel_for(size_t count, const std::function<void(size_t)> &fn) {
 #ifdef MIRA_CPU_EMU
     for (size_t i = 0; i < count; i++) fn(i);
 #else
     if (count <= 1) { if (count) fn(0); return; }
-    static HostPool *pool = new HostPool(std::max<size_t>(1, std::min<size_t>(7, std::thread::hardware_concurrency() > 1 ? std::thread::hardware_concurrency() - 1 : 1)));
+    HostPool *pool = &host_pool();
+    static std::mutex one_region;                           // callers outside the library lock (mira_g1_*) take turns
+    std::lock_guard<std::mutex> region(one_region);
     {
         std::lock_guard<std::mutex> lk(pool->m);
         pool->fn = &fn; pool->next = 0; pool->count = count; pool->epoch++;
@@ -559,64 +575,124 @@ static int ntt_kind_host_locked(uint64_t *a, uint32_t log_n, NttKind kind, const
     return MIRA_OK;
 }
 
-// acc + scalar * point on affine points: the single-scalar best_multiexp calls of
-// RelaxedPlonkInstance::fold (src/plonk/mod.rs:986-999, 1049-1053).  O(256) host work.
-template <class FB, class FS> static void g1_mul_add_t(const uint64_t acc[8], const uint64_t scalar[4], const uint64_t point[8], uint64_t out[8]) {
+// ---- the instance side of a fold: a handful of single-scalar multiplications on the host ----------------------
+// k * P for a canonical integer k < 2^255 by a width-5 NAF: 256 doublings and on average 43 additions of
+// +- (1, 3, .. 15) P, against 128 additions bit by bit.
+template <class FB> static hostf::HXyzz<FB> lift_affine(const uint64_t p[8]) {
     using namespace hostf;
-    HFe<FS> s;
-    memcpy(s.l, scalar, 32);
-    HFe<FS> one_plain = {{1, 0, 0, 0}};
-    s = mul(s, one_plain);                                  // leave Montgomery form: canonical integer
-    auto lift = [](const uint64_t p[8]) {
-        HXyzz<FB> r = identity<FB>();
-        bool zero = true;
-        for (int i = 0; i < 8; i++) zero &= (p[i] == 0);
-        if (!zero) { memcpy(r.x.l, p, 32); memcpy(r.y.l, p + 4, 32); r.zz = one<FB>(); r.zzz = one<FB>(); }
-        return r;
-    };
-    HXyzz<FB> P = lift(point), R = identity<FB>();
-    for (int bit = 255; bit >= 0; bit--) {
-        R = dbl_pt(R);
-        if ((s.l[bit / 64] >> (bit % 64)) & 1) R = add_pt(R, P);
-    }
-    R = add_pt(R, lift(acc));
-    to_affine(R, out);
+    HXyzz<FB> r = identity<FB>();
+    bool zero = true;
+    for (int i = 0; i < 8; i++) zero &= (p[i] == 0);
+    if (!zero) { memcpy(r.x.l, p, 32); memcpy(r.y.l, p + 4, 32); r.zz = one<FB>(); r.zzz = one<FB>(); }
+    return r;
 }
-
-// acc + sum_i scalars[i] * points[i] on affine points with ONE shared chain of doublings (Straus,
-// 4-bit windows): the instance side of a fold, E_commit + sum_k r^(k+1) T_k over the d - 1 cross-term
-// commitments (src/plonk/mod.rs:1049-1053), costs 256 doublings + 64 additions per term instead of
-// a full double-and-add per term.
-template <class FB, class FS>
-static void g1_lincomb_t(const uint64_t acc[8], const uint64_t *scalars, const uint64_t *points, size_t count, uint64_t out[8]) {
-    using namespace hostf;
-    auto lift = [](const uint64_t p[8]) {
-        HXyzz<FB> r = identity<FB>();
-        bool zero = true;
-        for (int i = 0; i < 8; i++) zero &= (p[i] == 0);
-        if (!zero) { memcpy(r.x.l, p, 32); memcpy(r.y.l, p + 4, 32); r.zz = one<FB>(); r.zzz = one<FB>(); }
-        return r;
-    };
-    std::vector<HFe<FS>> s(count);
-    std::vector<std::vector<HXyzz<FB>>> table(count, std::vector<HXyzz<FB>>(16));
-    const HFe<FS> one_plain = {{1, 0, 0, 0}};
-    for (size_t i = 0; i < count; i++) {
-        memcpy(s[i].l, scalars + 4 * i, 32);
-        s[i] = mul(s[i], one_plain);                        // leave Montgomery form: canonical integer
-        table[i][0] = identity<FB>();
-        table[i][1] = lift(points + 8 * i);
-        for (int k = 2; k < 16; k++) table[i][k] = (k & 1) ? add_pt(table[i][k - 1], table[i][1]) : dbl_pt(table[i][k / 2]);
-    }
-    HXyzz<FB> R = identity<FB>();
-    for (int w = 63; w >= 0; w--) {
-        for (int k = 0; k < 4; k++) R = dbl_pt(R);
-        for (size_t i = 0; i < count; i++) {
-            const uint32_t d = (uint32_t)(s[i].l[w / 16] >> (4 * (w % 16))) & 15u;
-            if (d) R = add_pt(R, table[i][d]);
+struct Wnaf5 {
+    int8_t d[260];
+    int len = 0;
+    explicit Wnaf5(const uint64_t k_in[4]) {
+        uint64_t k[5] = {k_in[0], k_in[1], k_in[2], k_in[3], 0};
+        while (k[0] | k[1] | k[2] | k[3] | k[4]) {
+            int digit = 0;
+            if (k[0] & 1) {
+                digit = (int)(k[0] & 31u);
+                if (digit >= 16) {                               // k += 32 - digit: the low five bits become zero
+                    digit -= 32;
+                    uint64_t add = (uint64_t)(-digit);
+                    for (int i = 0; i < 5 && add; i++) { const uint64_t t = k[i] + add; add = t < add; k[i] = t; }
+                } else {
+                    k[0] -= (uint64_t)digit;                     // clears the low bits, no borrow
+                }
+            }
+            d[len++] = (int8_t)digit;
+            for (int i = 0; i < 4; i++) k[i] = (k[i] >> 1) | (k[i + 1] << 63);
+            k[4] >>= 1;
         }
     }
-    R = add_pt(R, lift(acc));
-    to_affine(R, out);
+};
+template <class FB> struct OddMultiples {                        // (2 i + 1) P, i < 8
+    hostf::HXyzz<FB> t[8];
+    explicit OddMultiples(const hostf::HXyzz<FB> &P) {
+        const hostf::HXyzz<FB> P2 = hostf::dbl_pt(P);
+        t[0] = P;
+        for (int i = 1; i < 8; i++) t[i] = hostf::add_pt(t[i - 1], P2);
+    }
+    hostf::HXyzz<FB> signed_multiple(int digit) const {          // digit odd, |digit| <= 15
+        hostf::HXyzz<FB> r = t[(digit < 0 ? -digit : digit) >> 1];
+        if (digit < 0) r.y = hostf::sub(hostf::zero<FB>(), r.y);
+        return r;
+    }
+};
+// sum_i k_i P_i, one shared chain of doublings (Straus over the NAFs); scalars in Montgomery form, points affine
+template <class FB, class FS> static hostf::HXyzz<FB> g1_straus(const uint64_t *scalars, const uint64_t *points, size_t count) {
+    using namespace hostf;
+    std::vector<Wnaf5> naf;
+    std::vector<OddMultiples<FB>> table;
+    naf.reserve(count); table.reserve(count);
+    const HFe<FS> one_plain = {{1, 0, 0, 0}};
+    int top = 0;
+    for (size_t i = 0; i < count; i++) {
+        HFe<FS> s;
+        memcpy(s.l, scalars + 4 * i, 32);
+        s = mul(s, one_plain);                                   // leave Montgomery form: canonical integer
+        naf.emplace_back(s.l);
+        table.emplace_back(lift_affine<FB>(points + 8 * i));
+        top = std::max(top, naf.back().len);
+    }
+    HXyzz<FB> R = identity<FB>();
+    for (int b = top - 1; b >= 0; b--) {
+        R = dbl_pt(R);
+        for (size_t i = 0; i < count; i++)
+            if (b < naf[i].len && naf[i].d[b]) R = add_pt(R, table[i].signed_multiple(naf[i].d[b]));
+    }
+    return R;
+}
+// acc + scalar * point on affine points: the single-scalar best_multiexp calls of
+// RelaxedPlonkInstance::fold (src/plonk/mod.rs:986-999, 1049-1053).
+template <class FB, class FS> static void g1_mul_add_t(const uint64_t acc[8], const uint64_t scalar[4], const uint64_t point[8], uint64_t out[8]) {
+    hostf::to_affine(hostf::add_pt(g1_straus<FB, FS>(scalar, point, 1), lift_affine<FB>(acc)), out);
+}
+// acc + sum_i scalars[i] * points[i] on affine points: the instance side of a fold, E_commit + sum_k r^(k+1) T_k over the
+// d - 1 cross-term commitments (src/plonk/mod.rs:1049-1053).  The terms are dealt to the resident host threads, every
+// thread walks ONE chain of doublings for its terms.
+template <class FB, class FS> static hostf::HXyzz<FB> g1_lincomb_xyzz(const uint64_t *scalars, const uint64_t *points, size_t count) {
+    using namespace hostf;
+    const size_t groups = std::min<size_t>(count, host_parallel_width());
+    if (groups <= 1) return g1_straus<FB, FS>(scalars, points, count);
+    std::vector<HXyzz<FB>> part(groups);
+    host_parallel_for(groups, [&](size_t gi) {
+        const size_t lo = count * gi / groups, hi = count * (gi + 1) / groups;
+        part[gi] = g1_straus<FB, FS>(scalars + 4 * lo, points + 8 * lo, hi - lo);
+    });
+    HXyzz<FB> R = part[0];
+    for (size_t gi = 1; gi < groups; gi++) R = add_pt(R, part[gi]);
+    return R;
+}
+template <class FB, class FS>
+static void g1_lincomb_t(const uint64_t acc[8], const uint64_t *scalars, const uint64_t *points, size_t count, uint64_t out[8]) {
+    hostf::to_affine(hostf::add_pt(g1_lincomb_xyzz<FB, FS>(scalars, points, count), lift_affine<FB>(acc)), out);
+}
+// RelaxedPlonkInstance::fold, the commitments (src/plonk/mod.rs:986-999: W1_i + r W2_i; :1049-1053: E + sum_k r^(k+1) T_k),
+// all of it one parallel region: every W commitment and every group of cross-term commitments is one task.
+template <class FB, class FS>
+static void g1_fold_commitments_t(const uint64_t r[4], const uint64_t *w1, const uint64_t *w2, size_t nw, const uint64_t e[8], const uint64_t *t_commits,
+                                  size_t count, uint64_t *w_out, uint64_t e_out[8]) {
+    using namespace hostf;
+    std::vector<uint64_t> powers(4 * count);
+    HFe<FS> rr, p;
+    memcpy(rr.l, r, 32);
+    p = rr;
+    for (size_t k = 0; k < count; k++) { memcpy(&powers[4 * k], p.l, 32); p = mul(p, rr); }    // r^1, r^2, ... (iter::successors)
+    const size_t width = host_parallel_width();
+    const size_t egroups = count ? std::min<size_t>(count, width > nw ? width - nw : 1) : 0;
+    std::vector<HXyzz<FB>> part(egroups);
+    host_parallel_for(nw + egroups, [&](size_t i) {
+        if (i < nw) { g1_mul_add_t<FB, FS>(w1 + 8 * i, r, w2 + 8 * i, w_out + 8 * i); return; }
+        const size_t gi = i - nw, lo = count * gi / egroups, hi = count * (gi + 1) / egroups;
+        part[gi] = g1_straus<FB, FS>(&powers[4 * lo], t_commits + 8 * lo, hi - lo);
+    });
+    HXyzz<FB> R = lift_affine<FB>(e);
+    for (size_t gi = 0; gi < egroups; gi++) R = add_pt(R, part[gi]);
+    to_affine(R, e_out);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1108,6 +1184,16 @@ int mira_g1_lincomb(int curve, const uint64_t acc[8], const uint64_t *scalars, c
     if ((curve != MIRA_CURVE_BN256 && curve != MIRA_CURVE_GRUMPKIN) || !acc || !out || (count && (!scalars || !points)) || count > 64) { set_error("bad arguments"); return MIRA_E_BAD_ARG; }
     if (curve == MIRA_CURVE_BN256) g1_lincomb_t<FqP, FrP>(acc, scalars, points, count, out);
     else g1_lincomb_t<FrP, FqP>(acc, scalars, points, count, out);
+    return MIRA_OK;
+}
+int mira_g1_fold_commitments(int curve, const uint64_t r[4], const uint64_t *w1, const uint64_t *w2, size_t nw, const uint64_t e[8], const uint64_t *t_commits,
+                             size_t count, uint64_t *w_out, uint64_t e_out[8]) {
+    if ((curve != MIRA_CURVE_BN256 && curve != MIRA_CURVE_GRUMPKIN) || !r || !e || !e_out || (nw && (!w1 || !w2 || !w_out)) || (count && !t_commits) || nw > 64 || count > 64) {
+        set_error("bad arguments");
+        return MIRA_E_BAD_ARG;
+    }
+    if (curve == MIRA_CURVE_BN256) g1_fold_commitments_t<FqP, FrP>(r, w1, w2, nw, e, t_commits, count, w_out, e_out);
+    else g1_fold_commitments_t<FrP, FqP>(r, w1, w2, nw, e, t_commits, count, w_out, e_out);
     return MIRA_OK;
 }
 int mira_msm_download_bases(uint64_t handle, size_t first, size_t n, uint64_t *bases_out) {

@@ -89,3 +89,17 @@ def g1_lincomb(curve, acc, scalars, points, lib=None):
     lib.check(lib.c.mira_g1_lincomb(curve, acc.ctypes.data_as(ctypes.c_void_p), scalars.ctypes.data_as(ctypes.c_void_p),
                                     points.ctypes.data_as(ctypes.c_void_p), len(scalars), out.ctypes.data_as(ctypes.c_void_p)))
     return out
+
+
+def fold_instance_commitments(curve, w1_commits, w2_commits, r, e_commit, cross_term_commits, lib=None):
+    """The commitments of `RelaxedPlonkInstance::fold` in one call (src/plonk/mod.rs:986-999, 1049-1053):
+    returns ([W1_i + r W2_i], E + sum_k r^(k+1) T_k) as affine points.  `r` in Montgomery form, like g1_mul_add's scalar."""
+    lib = lib or _lib.load()
+    w1, w2 = _u64(w1_commits, 8).reshape(-1, 8), _u64(w2_commits, 8).reshape(-1, 8)
+    assert len(w1) == len(w2), "zip: the instances differ in their number of W commitments"
+    t = _u64(cross_term_commits, 8).reshape(-1, 8)
+    r, e = _u64(r, 4), _u64(e_commit, 8)
+    w_out, e_out = np.empty((len(w1), 8), dtype=np.uint64), np.empty(8, dtype=np.uint64)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    lib.check(lib.c.mira_g1_fold_commitments(curve, vp(r), vp(w1), vp(w2), len(w1), vp(e), vp(t), len(t), vp(w_out), vp(e_out)))
+    return w_out, e_out

@@ -91,6 +91,54 @@ def test_emu_g1_lincomb_matches_oracle_and_mul_add(emu_lib):
         assert (FD.g1_lincomb(cid, pts[0], sc[:0], terms[:0], lib=emu_lib) == pts[0]).all()
 
 
+def test_emu_g1_mul_add_naf_edge_scalars(emu_lib):
+    """The width-5 NAF behind every host scalar multiplication: scalars around its digit boundaries (15 / 16 / 17, 31 / 32 / 33),
+    all-ones low bits (a carry that runs through the limbs), r - 1 and r - 16, against the oracle's double-and-add."""
+    for cid in (0, 1):
+        cv = P.CURVES[cid]
+        pts = C.synth_bases(cid, 2, seed=21)
+        ks = [1, 2, 3, 15, 16, 17, 31, 32, 33, (1 << 64) - 1, (1 << 64) + 15, (1 << 128) - 1, (1 << 192) - 17, (1 << 253) + (1 << 64) - 1, cv.r - 1, cv.r - 16, cv.r - 17]
+        for k, s in zip(ks, ints_to_mont(ks, cv.r)):
+            want = P.ec_add(arr_to_point(pts[0], cid), P.ec_mul(k, arr_to_point(pts[1], cid), cv), cv)
+            assert arr_to_point(FD.g1_mul_add(cid, pts[0], s, pts[1], lib=emu_lib), cid) == want, k
+
+
+def _instance_fold_case(cid, lib, nw, count, seed):
+    cv = P.CURVES[cid]
+    pts = C.synth_bases(cid, 2 * nw + count + 1, seed=seed)
+    r = C.synth_scalars(cid, 1, seed=seed + 1)[0]
+    w1, w2, e, t = pts[:nw], pts[nw:2 * nw], pts[2 * nw], pts[2 * nw + 1:]
+    w_out, e_out = FD.fold_instance_commitments(cid, w1, w2, r, e, t, lib=lib)
+    r_int = mont_to_ints(r, cv.r)[0]
+    powers = ints_to_mont([pow(r_int, k + 1, cv.r) for k in range(count)], cv.r) if count else np.zeros((0, 4), dtype=np.uint64)
+    for i in range(nw):
+        assert (w_out[i] == C.ec_add(cid, w1[i], C.msm_naive(cid, r[None, :], w2[i:i + 1]))).all()
+    want_e = C.ec_add(cid, e, C.msm_naive(cid, powers, t)) if count else e
+    assert (e_out == want_e).all()
+    return w_out, e_out
+
+
+def test_emu_fold_instance_commitments_matches_oracle(emu_lib):
+    """mira_g1_fold_commitments = RelaxedPlonkInstance::fold's commitments (src/plonk/mod.rs:986-999, 1049-1053):
+    W1_i + r W2_i and E + sum_k r^(k+1) T_k against the oracle; no W commitments, no cross terms."""
+    for cid in (0, 1):
+        for nw, count in ((1, 5), (2, 6), (0, 3), (3, 0), (0, 0)):
+            _instance_fold_case(cid, emu_lib, nw, count, seed=30 + nw * 7 + count)
+
+
+def test_product_host_fold_runs_on_its_threads():
+    """The same calls through libmira_gpu.so: these entry points are host arithmetic (no device call), and in the product
+    build their terms are dealt to the library's resident threads -- the points must not depend on how."""
+    from mira_amd import _lib
+    lib = _lib.load()
+    for cid in (0, 1):
+        for nw, count in ((1, 6), (2, 5), (1, 13), (0, 1), (4, 0)):
+            _instance_fold_case(cid, lib, nw, count, seed=50 + nw * 5 + count)
+        pts = C.synth_bases(cid, 10, seed=61)
+        sc = C.synth_scalars(cid, 9, seed=62)
+        assert (FD.g1_lincomb(cid, pts[0], sc, pts[1:], lib=lib) == C.ec_add(cid, pts[0], C.msm_naive(cid, sc, pts[1:]))).all()
+
+
 def test_emu_key_cache_roundtrip(emu_lib, tmp_path):
     """src/commitment.rs:96-167 and its test `consistency` (:178-194): save, load, compare."""
     cid, k = 0, 6

@@ -289,6 +289,15 @@ int mira_graph_eval_batch(const uint64_t *handles, uint32_t count, const mira_ev
 int mira_graph_specialize(const uint64_t *handles, uint32_t count, const mira_eval_column *columns, uint32_t num_columns);
 int mira_graph_is_specialized(uint64_t handle, int32_t *out);
 int mira_graph_jit_source(uint64_t handle, const mira_eval_column *columns, uint32_t num_columns, char *buf, size_t cap, size_t *len_out);
+/* Code objects on disk.  mira_graph_set_cache_dir(dir): every kernel mira_graph_specialize compiles from now on is also
+ * written to `dir` (which must exist), and a graph whose kernel lies there is loaded instead of compiled -- the second
+ * process of an IVC run over the same circuit specialises in milliseconds.  A file is taken only if the generated source,
+ * the kernel headers beside libmira_gpu.so and the hiprtc version are the ones it was built from, byte for byte; writing
+ * is best effort (an unwritable directory costs compilations, not errors).  NULL or "" (the default): no files.  The
+ * reference keeps its commitment keys the same way (src/commitment.rs:96-167, `.cache/`).
+ * mira_graph_jit_stats: how many kernels the last mira_graph_specialize compiled / read from the directory. */
+int mira_graph_set_cache_dir(const char *dir);
+int mira_graph_jit_stats(uint32_t *compiled_out, uint32_t *from_disk_out);
 
 
 /* ---- ProtoGalaxy's polynomial pipeline around the NTT (src/nifs/protogalaxy/poly/mod.rs) -------

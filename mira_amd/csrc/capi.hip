@@ -1169,6 +1169,14 @@ int mira_graph_is_specialized(uint64_t handle, int32_t *out) {
     std::lock_guard<std::mutex> lk(g_lock);
     return graph_is_specialized(handle, out);
 }
+int mira_graph_set_cache_dir(const char *dir) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    return graph_set_cache_dir(dir);
+}
+int mira_graph_jit_stats(uint32_t *compiled_out, uint32_t *from_disk_out) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    return graph_jit_stats(compiled_out, from_disk_out);
+}
 int mira_graph_jit_source(uint64_t handle, const mira_eval_column *columns, uint32_t num_columns, char *buf, size_t cap, size_t *len_out) {
     std::lock_guard<std::mutex> lk(g_lock);
     if (num_columns && !columns) { set_error("null argument"); return MIRA_E_BAD_ARG; }

@@ -11,6 +11,7 @@
 #include "host_field.hpp"
 #ifndef MIRA_CPU_EMU
 #include <dlfcn.h>
+#include <unistd.h>
 #include <thread>
 #endif
 
@@ -80,6 +81,7 @@ struct Program {
     size_t o_chal = 0, o_cols = 0, o_jobs = 0, dyn_bytes = 0;   // | job table of the batch this program leads
 };
 std::map<uint64_t, Program> g_programs;
+uint32_t g_jit_last_compiled = 0, g_jit_last_from_disk = 0;   // of the last mira_graph_specialize: kernels compiled / read from the cache directory
 constexpr uint32_t GRAPH_MAX_BATCH = 16;           // graphs per launch
 // Intermediates kept in LDS per workgroup (9 KiB each at 256 lanes).  Measured at k = 17: with a batch
 // that fills the wave slots two slots are best (eleven graphs 1.98 -> 1.87 ms; eight cost occupancy, 2.14),
@@ -815,8 +817,100 @@ std::vector<char> compile(const std::string &src, std::string &err) {
     (void)r.destroy(&prog);
     return out;
 }
+
+// ---- code objects on disk (mira_graph_set_cache_dir) --------------------------------------------------------------
+// A file per kernel: magic | key of the build environment | source length | source | code length | code.  The file
+// name is a hash of source and environment; a hit must match both byte for byte, so a colliding or stale file (another
+// version of the headers the source includes, another hiprtc) is a miss, never a wrong kernel.
+static std::string g_cache_dir;
+static uint64_t fnv1a(const void *p, size_t n, uint64_t h = 0xcbf29ce484222325ull) {
+    const unsigned char *b = static_cast<const unsigned char *>(p);
+    for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 0x100000001b3ull; }
+    return h;
+}
+static bool read_file(const std::string &path, std::vector<char> &out) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    out.clear();
+    char buf[65536];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) out.insert(out.end(), buf, buf + n);
+    const bool ok = !ferror(f);
+    fclose(f);
+    return ok;
+}
+// everything besides the source text that decides the code object: the headers it includes and the compiler
+static const std::string &environment_key() {
+    static std::string key;
+    if (!key.empty()) return key;
+    Rtc &r = rtc();
+    uint64_t h = fnv1a("gfx950 -O3 c++17", 16);
+    for (const char *name : {"field29.cuh", "field.cuh", "platform.h"}) {
+        std::vector<char> text;
+        (void)read_file(r.include_dir + "/" + name, text);       // unreadable: the compilation fails as well
+        h = fnv1a(text.data(), text.size(), h);
+        h = fnv1a(name, strlen(name), h);
+    }
+    int major = 0, minor = 0;
+    if (r.lib) {
+        auto version = reinterpret_cast<int (*)(int *, int *)>(dlsym(r.lib, "hiprtcVersion"));
+        if (version) (void)version(&major, &minor);
+    }
+    char buf[96];
+    snprintf(buf, sizeof buf, "mira-jit-1 %016llx hiprtc %d.%d", (unsigned long long)h, major, minor);
+    key = buf;
+    return key;
+}
+static std::string cache_path(const std::string &src) {
+    const std::string &env = environment_key();
+    const uint64_t a = fnv1a(src.data(), src.size()), b = fnv1a(env.data(), env.size(), a ^ 0x9e3779b97f4a7c15ull);
+    char name[64];
+    snprintf(name, sizeof name, "/mira_jit_%016llx%016llx.bin", (unsigned long long)a, (unsigned long long)b);
+    return g_cache_dir + name;
+}
+static constexpr char CACHE_MAGIC[8] = {'M', 'I', 'R', 'A', 'J', 'I', 'T', '1'};
+static std::vector<char> cache_load(const std::string &src) {
+    std::vector<char> file, code;
+    if (g_cache_dir.empty() || !read_file(cache_path(src), file)) return code;
+    const std::string &env = environment_key();
+    size_t pos = 0;
+    auto take = [&](const void *want, size_t n) { const bool ok = pos + n <= file.size() && memcmp(file.data() + pos, want, n) == 0; pos += n; return ok; };
+    auto take_len = [&](uint64_t &v) { if (pos + 8 > file.size()) return false; memcpy(&v, file.data() + pos, 8); pos += 8; return true; };
+    uint64_t n_env = 0, n_src = 0, n_code = 0;
+    if (!take(CACHE_MAGIC, 8) || !take_len(n_env) || n_env != env.size() || !take(env.data(), env.size())) return code;
+    if (!take_len(n_src) || n_src != src.size() || !take(src.data(), src.size())) return code;
+    if (!take_len(n_code) || n_code == 0 || pos + n_code != file.size()) return code;
+    code.assign(file.begin() + (long)pos, file.end());
+    return code;
+}
+static void cache_store(const std::string &src, const std::vector<char> &code) {   // best effort: a failure costs the next process a compilation
+    if (g_cache_dir.empty() || code.empty()) return;
+    const std::string path = cache_path(src), tmp = path + ".tmp" + std::to_string((unsigned long long)getpid());
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return;
+    const std::string &env = environment_key();
+    const uint64_t n_env = env.size(), n_src = src.size(), n_code = code.size();
+    bool ok = fwrite(CACHE_MAGIC, 1, 8, f) == 8 && fwrite(&n_env, 8, 1, f) == 1 && fwrite(env.data(), 1, env.size(), f) == env.size();
+    ok = ok && fwrite(&n_src, 8, 1, f) == 1 && fwrite(src.data(), 1, src.size(), f) == src.size();
+    ok = ok && fwrite(&n_code, 8, 1, f) == 1 && fwrite(code.data(), 1, code.size(), f) == code.size();
+    ok = (fclose(f) == 0) && ok;
+    if (!ok || rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());   // rename: readers see a whole file or none
+}
 }   // namespace graphjit
 #endif
+
+// Directory for the code objects of specialised kernels, or null / "" for none (the default): a later process -- or this
+// one after mira_graph_free -- that specialises the same graph loads the kernel instead of compiling it.
+int graph_set_cache_dir(const char *dir) {
+#ifdef MIRA_CPU_EMU
+    (void)dir;
+    return MIRA_OK;
+#else
+    graphjit::g_cache_dir = dir ? dir : "";
+    while (graphjit::g_cache_dir.size() > 1 && graphjit::g_cache_dir.back() == '/') graphjit::g_cache_dir.pop_back();
+    return MIRA_OK;
+#endif
+}
 
 // Every handle gets its own kernel; the compilations run on one host thread each (a MainGate<5> evaluation point takes
 // ~5 s).  A handle that is specialised already, or has no calculations, is left as it is.  On failure nothing changes:
@@ -837,6 +931,7 @@ int graph_specialize(const uint64_t *handles, uint32_t count, const mira_eval_co
         if (pg.ninstr > graphjit::MAX_INSTR) { set_error("graph of " + std::to_string(pg.ninstr) + " instructions is too long to specialise"); return MIRA_E_UNSUPPORTED; }
         if (std::find(todo.begin(), todo.end(), &pg) == todo.end()) todo.push_back(&pg);
     }
+    g_jit_last_compiled = g_jit_last_from_disk = 0;
     if (todo.empty()) return MIRA_OK;
     if (!graphjit::rtc().error.empty()) { set_error(graphjit::rtc().error); return MIRA_E_UNSUPPORTED; }
     std::vector<std::vector<char>> code(todo.size());
@@ -849,10 +944,13 @@ int graph_specialize(const uint64_t *handles, uint32_t count, const mira_eval_co
     static std::map<std::string, std::vector<char>> compiled;
     std::vector<std::string> src(todo.size());
     std::vector<size_t> fresh;
+    size_t from_disk = 0;
     for (size_t k = 0; k < todo.size(); k++) {
         src[k] = graphjit::source(todo[k]->field, todo[k]->h_stream, todo[k]->ninstr, todo[k]->h_rot, kinds, ahead);
         auto hit = compiled.find(src[k]);
-        if (hit != compiled.end()) code[k] = hit->second; else fresh.push_back(k);
+        if (hit != compiled.end()) { code[k] = hit->second; continue; }
+        code[k] = graphjit::cache_load(src[k]);              // a file of an earlier process (mira_graph_set_cache_dir)
+        if (code[k].empty()) fresh.push_back(k); else { compiled[src[k]] = code[k]; from_disk++; }
     }
     auto work = [&](size_t k) { code[k] = graphjit::compile(src[k], errs[k]); };
     for (size_t q = 1; q < fresh.size(); q++) workers.emplace_back(work, fresh[q]);
@@ -861,7 +959,8 @@ int graph_specialize(const uint64_t *handles, uint32_t count, const mira_eval_co
     for (size_t k = 0; k < todo.size(); k++)
         if (code[k].empty()) { set_error(errs[k]); return MIRA_E_UNSUPPORTED; }
     if (compiled.size() + fresh.size() > 256) compiled.clear();   // a bound on what a long-lived process keeps (a code object is ~200 KiB)
-    for (size_t k : fresh) compiled[src[k]] = code[k];
+    for (size_t k : fresh) { compiled[src[k]] = code[k]; graphjit::cache_store(src[k], code[k]); }
+    g_jit_last_compiled = (uint32_t)fresh.size(); g_jit_last_from_disk = (uint32_t)from_disk;
     std::vector<hipModule_t> mods(todo.size(), nullptr);
     std::vector<hipFunction_t> fns(todo.size(), nullptr);
     for (size_t k = 0; k < todo.size(); k++) {
@@ -876,6 +975,11 @@ int graph_specialize(const uint64_t *handles, uint32_t count, const mira_eval_co
     for (size_t k = 0; k < todo.size(); k++) { todo[k]->jit_mod = mods[k]; todo[k]->jit_fn = fns[k]; todo[k]->jit_kinds = kinds; }
     return MIRA_OK;
 #endif
+}
+int graph_jit_stats(uint32_t *compiled_out, uint32_t *from_disk_out) {
+    if (compiled_out) *compiled_out = g_jit_last_compiled;
+    if (from_disk_out) *from_disk_out = g_jit_last_from_disk;
+    return MIRA_OK;
 }
 int graph_is_specialized(uint64_t handle, int32_t *out) {
     auto it = g_programs.find(handle);

@@ -14,6 +14,7 @@
 Constants and challenges are plain Python integers below the field modulus on this side; device
 data is in the reference's Montgomery layout like everywhere else in this package."""
 import ctypes
+import os
 
 import numpy as np
 
@@ -229,6 +230,20 @@ class GraphEvaluator:
             return False
         lib.check(rc)
         return True
+
+    @staticmethod
+    def set_jit_cache_dir(path, lib=None):
+        """mira_graph_set_cache_dir: keep the code objects of specialised kernels in this directory (None: no files)."""
+        lib = lib or _lib.load()
+        lib.check(lib.c.mira_graph_set_cache_dir(None if path is None else os.fsencode(path)))
+
+    @staticmethod
+    def jit_stats(lib=None):
+        """mira_graph_jit_stats: (kernels compiled, kernels read from the cache directory) by the last specialize call."""
+        lib = lib or _lib.load()
+        compiled, from_disk = ctypes.c_uint32(), ctypes.c_uint32()
+        lib.check(lib.c.mira_graph_jit_stats(ctypes.byref(compiled), ctypes.byref(from_disk)))
+        return compiled.value, from_disk.value
 
     def is_specialized(self, num_challenges, num_columns, lib=None):
         lib = lib or _lib.load()

@@ -128,3 +128,39 @@ def test_specialised_main_gate_cross_terms(gpu_lib, gates, field, curve):
     finally:
         for p in (d_a, d_b, d_fix, d_w1, d_w2):
             gpu_lib.free(p)
+
+
+def test_code_objects_on_disk(gpu_lib, tmp_path):
+    """mira_graph_set_cache_dir: a second PROCESS specialising the same graphs loads the kernels the first one compiled
+    (same values); a truncated file and a file of another build environment are misses, not wrong kernels."""
+    import json
+    import os
+    import subprocess
+    import sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "jit_cache_child.py")
+
+    def run():
+        out = subprocess.run([sys.executable, child, str(tmp_path), "1", "31"], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    first = run()
+    if not first["ok"]:
+        pytest.skip("no run-time compiler on this machine")
+    assert (first["compiled"], first["from_disk"]) == (2, 0) and all(first["specialised"])
+    files = sorted(p for p in os.listdir(tmp_path) if p.startswith("mira_jit_") and p.endswith(".bin"))
+    assert len(files) == 2 and not [p for p in os.listdir(tmp_path) if ".tmp" in p]
+    second = run()
+    assert (second["compiled"], second["from_disk"]) == (0, 2) and all(second["specialised"])
+    assert second["digest"] == first["digest"]
+    # a truncated file, and one whose environment key differs in one byte: both are compiled again and rewritten
+    a, b = (os.path.join(tmp_path, f) for f in files)
+    blob = open(a, "rb").read()
+    open(a, "wb").write(blob[:len(blob) // 2])
+    blob_b = bytearray(open(b, "rb").read())
+    blob_b[20] ^= 1                                               # inside the environment key (offset 16 .. 16 + its length)
+    open(b, "wb").write(bytes(blob_b))
+    third = run()
+    assert (third["compiled"], third["from_disk"]) == (2, 0) and third["digest"] == first["digest"]
+    assert open(a, "rb").read() == blob
+    fourth = run()
+    assert (fourth["compiled"], fourth["from_disk"]) == (0, 2) and fourth["digest"] == first["digest"]

@@ -279,6 +279,8 @@ int mira_graph_eval_batch(const uint64_t *handles, uint32_t count, const mira_ev
  * Evaluation then runs at about twice the interpreter's rate; every value is the interpreter's (the same field
  * operations in the same order).  The gate polynomial of a circuit is fixed for the whole IVC run
  * (src/ivc/public_params.rs: the PlonkStructure is built once), so this belongs where the GraphEvaluators are built.
+ * The call blocks for the compilation but releases the library's lock meanwhile: other threads keep committing and
+ * evaluating (interpreted), and a handle freed before the compiler is done is skipped.
  * MIRA_E_UNSUPPORTED (libhiprtc.so missing, a graph of more than 1536 instructions, a compilation failure):
  * nothing has changed and the graphs keep being interpreted -- on the GPU, there is no host path.
  * `columns`: the column table the graphs will be evaluated over -- only the KINDS are read (which columns are selector

@@ -1159,11 +1159,11 @@ int mira_graph_free(uint64_t handle) {
     return graph_free(handle);
 }
 int mira_graph_specialize(const uint64_t *handles, uint32_t count, const mira_eval_column *columns, uint32_t num_columns) {
-    std::lock_guard<std::mutex> lk(g_lock);
+    std::unique_lock<std::mutex> lk(g_lock);
     int rc = ensure_ctx();
     if (rc) return rc;
     if ((count && !handles) || (num_columns && !columns)) { set_error("null argument"); return MIRA_E_BAD_ARG; }
-    return graph_specialize(handles, count, columns, num_columns);
+    return graph_specialize(handles, count, columns, num_columns, &lk);
 }
 int mira_graph_is_specialized(uint64_t handle, int32_t *out) {
     std::lock_guard<std::mutex> lk(g_lock);

@@ -197,7 +197,8 @@ int graph_eval_compiled(uint64_t handle, const mira_eval_column *columns, uint32
 int graph_free(uint64_t handle);
 int graph_eval_batch(const uint64_t *handles, uint32_t count, const mira_eval_column *columns, uint32_t num_columns, const uint64_t *challenges,
                      uint32_t num_challenges, size_t num_rows, void *const *d_outs);
-int graph_specialize(const uint64_t *handles, uint32_t count, const mira_eval_column *columns, uint32_t num_columns);
+int graph_specialize(const uint64_t *handles, uint32_t count, const mira_eval_column *columns, uint32_t num_columns,
+                     std::unique_lock<std::mutex> *library_lock);   // held on entry and on return; released while the compiler runs
 int graph_is_specialized(uint64_t handle, int32_t *out);
 int graph_set_cache_dir(const char *dir);
 int graph_jit_stats(uint32_t *compiled_out, uint32_t *from_disk_out);

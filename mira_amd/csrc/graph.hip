@@ -915,21 +915,21 @@ int graph_set_cache_dir(const char *dir) {
 // Every handle gets its own kernel; the compilations run on one host thread each (a MainGate<5> evaluation point takes
 // ~5 s).  A handle that is specialised already, or has no calculations, is left as it is.  On failure nothing changes:
 // the graphs stay interpreted.
-int graph_specialize(const uint64_t *handles, uint32_t count, const mira_eval_column *columns, uint32_t num_columns) {
+int graph_specialize(const uint64_t *handles, uint32_t count, const mira_eval_column *columns, uint32_t num_columns, std::unique_lock<std::mutex> *library_lock) {
 #ifdef MIRA_CPU_EMU
-    (void)handles; (void)count; (void)columns; (void)num_columns;
+    (void)handles; (void)count; (void)columns; (void)num_columns; (void)library_lock;
     set_error("the host emulation has no run-time compiler: graphs stay interpreted");
     return MIRA_E_UNSUPPORTED;
 #else
-    std::vector<Program *> todo;
+    std::vector<uint64_t> todo;                              // handles, not pointers: the lock is released while the compiler runs
     for (uint32_t k = 0; k < count; k++) {
         auto it = g_programs.find(handles[k]);
         if (it == g_programs.end()) { set_error("unknown graph handle"); return MIRA_E_BAD_ARG; }
-        Program &pg = it->second;
+        const Program &pg = it->second;
         if (num_columns != pg.num_columns) { set_error("the graph was compiled for " + std::to_string(pg.num_columns) + " columns"); return MIRA_E_BAD_ARG; }
         if (pg.jit_fn || pg.num_calculations == 0 || pg.ninstr == 0) continue;
         if (pg.ninstr > graphjit::MAX_INSTR) { set_error("graph of " + std::to_string(pg.ninstr) + " instructions is too long to specialise"); return MIRA_E_UNSUPPORTED; }
-        if (std::find(todo.begin(), todo.end(), &pg) == todo.end()) todo.push_back(&pg);
+        if (std::find(todo.begin(), todo.end(), handles[k]) == todo.end()) todo.push_back(handles[k]);
     }
     g_jit_last_compiled = g_jit_last_from_disk = 0;
     if (todo.empty()) return MIRA_OK;
@@ -946,24 +946,35 @@ int graph_specialize(const uint64_t *handles, uint32_t count, const mira_eval_co
     std::vector<size_t> fresh;
     size_t from_disk = 0;
     for (size_t k = 0; k < todo.size(); k++) {
-        src[k] = graphjit::source(todo[k]->field, todo[k]->h_stream, todo[k]->ninstr, todo[k]->h_rot, kinds, ahead);
+        const Program &pg = g_programs.find(todo[k])->second;
+        src[k] = graphjit::source(pg.field, pg.h_stream, pg.ninstr, pg.h_rot, kinds, ahead);
         auto hit = compiled.find(src[k]);
         if (hit != compiled.end()) { code[k] = hit->second; continue; }
         code[k] = graphjit::cache_load(src[k]);              // a file of an earlier process (mira_graph_set_cache_dir)
         if (code[k].empty()) fresh.push_back(k); else { compiled[src[k]] = code[k]; from_disk++; }
     }
+    // The compiler runs for seconds and touches nothing of the library's: other threads may commit, transform and evaluate
+    // (interpreted) meanwhile.  They may also free one of these handles -- looked up again below.
+    if (library_lock && !fresh.empty()) library_lock->unlock();
     auto work = [&](size_t k) { code[k] = graphjit::compile(src[k], errs[k]); };
     for (size_t q = 1; q < fresh.size(); q++) workers.emplace_back(work, fresh[q]);
     if (!fresh.empty()) work(fresh[0]);
     for (auto &t : workers) t.join();
+    if (library_lock && !fresh.empty()) library_lock->lock();
     for (size_t k = 0; k < todo.size(); k++)
         if (code[k].empty()) { set_error(errs[k]); return MIRA_E_UNSUPPORTED; }
     if (compiled.size() + fresh.size() > 256) compiled.clear();   // a bound on what a long-lived process keeps (a code object is ~200 KiB)
     for (size_t k : fresh) { compiled[src[k]] = code[k]; graphjit::cache_store(src[k], code[k]); }
     g_jit_last_compiled = (uint32_t)fresh.size(); g_jit_last_from_disk = (uint32_t)from_disk;
+    std::vector<Program *> live(todo.size(), nullptr);       // freed meanwhile, or specialised by another thread: nothing to do
+    for (size_t k = 0; k < todo.size(); k++) {
+        auto it = g_programs.find(todo[k]);
+        if (it != g_programs.end() && !it->second.jit_fn) live[k] = &it->second;
+    }
     std::vector<hipModule_t> mods(todo.size(), nullptr);
     std::vector<hipFunction_t> fns(todo.size(), nullptr);
     for (size_t k = 0; k < todo.size(); k++) {
+        if (!live[k]) continue;
         hipError_t e = hipModuleLoadData(&mods[k], code[k].data());
         if (e == hipSuccess) e = hipModuleGetFunction(&fns[k], mods[k], "mira_jit_eval");
         if (e != hipSuccess) {
@@ -972,7 +983,8 @@ int graph_specialize(const uint64_t *handles, uint32_t count, const mira_eval_co
             return MIRA_E_UNSUPPORTED;
         }
     }
-    for (size_t k = 0; k < todo.size(); k++) { todo[k]->jit_mod = mods[k]; todo[k]->jit_fn = fns[k]; todo[k]->jit_kinds = kinds; }
+    for (size_t k = 0; k < todo.size(); k++)
+        if (live[k]) { live[k]->jit_mod = mods[k]; live[k]->jit_fn = fns[k]; live[k]->jit_kinds = kinds; }
     return MIRA_OK;
 #endif
 }

@@ -164,3 +164,59 @@ def test_code_objects_on_disk(gpu_lib, tmp_path):
     assert open(a, "rb").read() == blob
     fourth = run()
     assert (fourth["compiled"], fourth["from_disk"]) == (0, 2) and fourth["digest"] == first["digest"]
+
+
+def test_library_stays_usable_while_the_compiler_runs(gpu_lib):
+    """mira_graph_specialize releases the library's lock for the compilation: another thread's evaluations (of the very graph
+    being specialised: interpreted until the kernel is in place) and commits go on meanwhile, and a handle freed during the
+    compilation is simply skipped."""
+    import threading
+    import time
+    field, n, seed = 1, 1 << 10, 41
+    mod = MODS[field]
+    arrs = synth_data(field, n, 2, 3, 7, 3, seed)
+    ptrs, cols = device_columns(gpu_lib, arrs)
+    rng = random.Random(seed)
+    key = cm.CommitmentKey.synthetic(cm.CURVE_BN256, 1 << 12, lib=gpu_lib)
+    d_s = cm.synth_scalars_device(cm.CURVE_BN256, 1 << 12, seed=5)
+    try:
+        ge = G.GraphEvaluator.new(gate_like_expression(rng, 20, 7, 12, 3), field)
+        doomed = G.GraphEvaluator.new(gate_like_expression(rng, 4, 6, 12, 3), field)
+        code, consts, rots = ge.flatten()
+        want = C.graph_eval(field, code, ge.num_intermediates, consts, rots, oracle_columns(arrs), ints_to_mont(arrs["challenges"], mod), n)
+        want_point = key.commit_device(d_s, 1 << 12)
+        nchal = len(arrs["challenges"])
+        doomed.compiled(nchal, len(cols), gpu_lib)
+        ge.compiled(nchal, len(cols), gpu_lib)
+        result = {}
+
+        def compile_thread():
+            t0 = time.perf_counter()
+            result["ok"] = G.GraphEvaluator.specialize([ge, doomed], cols, nchal, lib=gpu_lib)
+            result["seconds"] = time.perf_counter() - t0
+        th = threading.Thread(target=compile_thread)
+        th.start()
+        time.sleep(0.3)                                            # the compiler is running by now (a kernel takes seconds)
+        done_meanwhile = 0
+        freed = False
+        while th.is_alive():
+            d = ge.evaluate_device(cols, arrs["challenges"], n, lib=gpu_lib)
+            assert (gpu_lib.download(d, (n, 4)) == want).all()
+            gpu_lib.free(d)
+            assert (key.commit_device(d_s, 1 << 12) == want_point).all()
+            if not freed:
+                doomed.close()                                     # mira_graph_free(h_doomed) while its kernel is being compiled
+                freed = True
+            if th.is_alive():
+                done_meanwhile += 1
+        th.join()
+        assert result["ok"], gpu_lib.c.mira_last_error()
+        assert done_meanwhile >= 3, (done_meanwhile, result)       # each round is ~1 ms; the compilation takes seconds
+        assert ge.is_specialized(nchal, len(cols), lib=gpu_lib)
+        d = ge.evaluate_device(cols, arrs["challenges"], n, lib=gpu_lib)
+        assert (gpu_lib.download(d, (n, 4)) == want).all()
+        gpu_lib.free(d)
+    finally:
+        key.close(); gpu_lib.free(d_s)
+        for p in ptrs:
+            gpu_lib.free(p)

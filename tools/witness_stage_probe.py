@@ -8,7 +8,7 @@ lib = _lib.load()
 for cid, cols in ((0, 14), (1, 7)):
     n = cols << 17
     key = cm.CommitmentKey.synthetic(cid, n); d = cm.synth_scalars_device(cid, n, seed=0x1000 + cid, kind=1)
-    for tables in (0, 16):
+    for tables in (0, 13):
         if tables: key.precompute(tables)
         for _ in range(3): key.commit_device(d, n)
         t0 = time.perf_counter()

@@ -785,6 +785,7 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
                          d_wout=lib.alloc(nw * 32), d_enew=lib.alloc(n * 32), r_int=(0x5EED0000 + 7919 * c) ** 5 % G.MODULUS[field],
                          acc_w=cm.CommitmentKey.default_value(), acc_e=cm.CommitmentKey.default_value())
             st[c]["r"] = G.to_montgomery([st[c]["r_int"]], field)[0]
+            st[c]["term_ptrs"] = [st[c]["d_terms"] + i * n * 32 for i in range(cnt)]
 
         def fold_step():
             spans = {"witness_commit": 0.0, "evaluation": 0.0, "commit": 0.0, "fold": 0.0}
@@ -797,10 +798,8 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
                 t2 = time.perf_counter()
                 t_commits = s_["key"].commit_batch_device(s_["d_terms"], n, s_["cnt"])
                 t3 = time.perf_counter()
-                FD.fold_witness_device(s_["field"], s_["d_wout"], s_["d_w1"], s_["d_w2"], s_["r"], s_["nw"])
-                d_e_new = s_["d_enew"]
-                lib.copy(d_e_new, s_["d_e"], n * 32)                                # E' starts as the accumulator's E, then the terms are folded in
-                FD.fold_error_device(s_["field"], d_e_new, [s_["d_terms"] + i * n * 32 for i in range(s_["cnt"])], s_["r"], n)
+                d_e_new = s_["d_enew"]                                              # W' = W1 + r W2 and E' = E + sum r^(k+1) T_k, one submission
+                FD.fold_relaxed_witness_device(s_["field"], s_["d_wout"], s_["d_w1"], s_["d_w2"], s_["nw"], d_e_new, s_["d_e"], s_["term_ptrs"], s_["r"], n)
                 # W1 + r W2 and E_commit + sum r^(k+1) T_k (src/plonk/mod.rs:986-999, 1049-1053), one parallel region on the host
                 folded_ws, folded_e = FD.fold_instance_commitments(c, s_["acc_w"], w_commit, s_["r"], s_["acc_e"], t_commits)
                 folded_w = folded_ws[0]

@@ -185,6 +185,11 @@ int mira_msm_download_bases(uint64_t handle, size_t first, size_t n, uint64_t *b
 #define MIRA_FIELD_FR 1
 int mira_fold_witness_device(int field, void *d_out, const void *d_w1, const void *d_w2, const uint64_t r[4], size_t n);
 int mira_fold_error_device(int field, void *d_e, const void *const *d_cross_terms, size_t num_terms, const uint64_t r[4], size_t n);
+/* Both halves of RelaxedPlonkWitness::fold in one submission (src/plonk/mod.rs:1097-1134): w_out[i] = w1[i] + r * w2[i], i < n_w,
+ * and e_out[i] = e[i] + sum_k r^(k+1) * cross_terms[k][i], i < n, k < num_terms <= 16 (d_e_out may be d_e: in place) -- the values
+ * of the two calls above, with one copy of constants and one synchronisation instead of two each. */
+int mira_fold_relaxed_witness_device(int field, void *d_w_out, const void *d_w1, const void *d_w2, size_t n_w, void *d_e_out, const void *d_e,
+                                     const void *const *d_cross_terms, size_t num_terms, const uint64_t r[4], size_t n);
 int mira_g1_mul_add(int curve, const uint64_t acc[8], const uint64_t scalar[4], const uint64_t point[8], uint64_t out[8]);
 /* out = acc + sum_i scalars[i] * points[i], count <= 64: E_commit + sum_k r^(k+1) T_k over the cross-term
  * commitments (src/plonk/mod.rs:1049-1053); host: width-5 NAFs, the terms dealt to the library's resident host

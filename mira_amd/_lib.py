@@ -20,7 +20,7 @@ MIRA_PARTIAL_U64 = MIRA_MAX_WINDOWS * 16
 SYMBOLS = [
     "mira_device_count", "mira_init", "mira_set_stream", "mira_last_error",
     "mira_msm_register_bases", "mira_msm_register_bases_device", "mira_msm_unregister", "mira_msm_check_bases", "mira_msm_precompute", "mira_msm_precompute_ex",
-    "mira_msm_download_bases", "mira_fold_witness_device", "mira_fold_error_device", "mira_g1_mul_add", "mira_g1_lincomb", "mira_g1_fold_commitments", "mira_graph_set_cache_dir", "mira_graph_jit_stats", "mira_graph_eval_device", "mira_graph_compile", "mira_graph_eval_compiled", "mira_graph_eval_batch", "mira_graph_free", "mira_pow_tree_reduce_device", "mira_lincomb_device",
+    "mira_msm_download_bases", "mira_fold_witness_device", "mira_fold_error_device", "mira_fold_relaxed_witness_device", "mira_g1_mul_add", "mira_g1_lincomb", "mira_g1_fold_commitments", "mira_graph_set_cache_dir", "mira_graph_jit_stats", "mira_graph_eval_device", "mira_graph_compile", "mira_graph_eval_compiled", "mira_graph_eval_batch", "mira_graph_free", "mira_pow_tree_reduce_device", "mira_lincomb_device",
     "mira_msm", "mira_msm_device", "mira_msm_batch", "mira_msm_batch_device", "mira_msm_partial_device", "mira_msm_combine", "mira_msm_set_window_bits", "mira_msm_last_plan",
     "mira_ntt_bn256_fr", "mira_ntt_bn256_fr_device", "mira_fft_bn256_fr", "mira_ifft_bn256_fr",
     "mira_fft_bn256_fr_device", "mira_ifft_bn256_fr_device", "mira_coset_fft_bn256_fr", "mira_coset_ifft_bn256_fr",
@@ -93,6 +93,7 @@ class MiraLib:
             "mira_msm_download_bases": [u64, sz, sz, u64p],
             "mira_fold_witness_device": [ctypes.c_int, vp, vp, vp, u64p, sz], "mira_fold_error_device": [ctypes.c_int, vp, vp, sz, u64p, sz],
             "mira_g1_mul_add": [ctypes.c_int, u64p, u64p, u64p, u64p], "mira_g1_lincomb": [ctypes.c_int, u64p, u64p, u64p, sz, u64p],
+            "mira_fold_relaxed_witness_device": [ctypes.c_int, vp, vp, vp, sz, vp, vp, vp, sz, u64p, sz],
             "mira_graph_set_cache_dir": [ctypes.c_char_p], "mira_graph_jit_stats": [vp, vp],
             "mira_g1_fold_commitments": [ctypes.c_int, u64p, u64p, u64p, sz, u64p, u64p, sz, u64p, u64p],
             "mira_graph_eval_device": [ctypes.c_int, vp, vp, u32, u64p, u32, sz, vp],

@@ -1070,6 +1070,20 @@ int mira_fold_error_device(int field, void *d_e, const void *const *d_cross_term
     if (!n || !num_terms) return MIRA_OK;
     return fold_error_device(field, d_e, d_cross_terms, num_terms, r, n);
 }
+int mira_fold_relaxed_witness_device(int field, void *d_w_out, const void *d_w1, const void *d_w2, size_t n_w, void *d_e_out, const void *d_e,
+                                     const void *const *d_cross_terms, size_t num_terms, const uint64_t r[4], size_t n) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    if ((field != 0 && field != 1) || !r || num_terms > 16 || (num_terms && !d_cross_terms) || (n_w && (!d_w_out || !d_w1 || !d_w2)) || (n && (!d_e_out || !d_e))) {
+        set_error("bad fold arguments");
+        return MIRA_E_BAD_ARG;
+    }
+    for (size_t k = 0; k < num_terms; k++)
+        if (n && !d_cross_terms[k]) { set_error("null cross term"); return MIRA_E_BAD_ARG; }
+    if (!n_w && !n) return MIRA_OK;
+    return fold_relaxed_device(field, d_w_out, d_w1, d_w2, n_w, d_e_out, d_e, d_cross_terms, num_terms, r, n);
+}
 int mira_lincomb_device(int field, void *d_out, const void *const *d_vecs, const uint64_t *coeffs, size_t num_vecs, size_t n) {
     std::lock_guard<std::mutex> lk(g_lock);
     int rc = ensure_ctx();

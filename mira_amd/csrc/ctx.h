@@ -184,6 +184,8 @@ int save_bases_file_grumpkin(const Bases &b, int fd);
 // fold.hip
 int fold_witness_device(int field, void *d_out, const void *d_w1, const void *d_w2, const uint64_t r[4], size_t n);
 int fold_error_device(int field, void *d_e, const void *const *d_terms, size_t K, const uint64_t r[4], size_t n);
+int fold_relaxed_device(int field, void *d_w_out, const void *d_w1, const void *d_w2, size_t n_w, void *d_e_out, const void *d_e, const void *const *d_terms, size_t K,
+                        const uint64_t r[4], size_t n);
 int lincomb_device(int field, void *d_out, const void *const *d_vecs, const uint64_t *coeffs, size_t K, size_t n);
 int lincomb_multi_device(int field, void *const *d_outs, size_t M, const void *const *d_vecs, size_t J, const uint64_t *coeffs, size_t n);
 int pow_tree_reduce_device(int field, const void *d_leaves, uint32_t levels, size_t leaf_point_stride, const uint64_t *weights, uint32_t P, uint64_t *out);

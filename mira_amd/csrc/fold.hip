@@ -49,8 +49,44 @@ template <class F, class FP> static int fold_error_t(void *d_e, const void *cons
     }
     RT_CHECK(rt_h2d(reinterpret_cast<unsigned char *>(g.fold_consts.p) + 48, pw, 48 * K, g.stream));
     tm_begin();
-    LAUNCH(k_fold_error<F>, fold_grid(n), 256, 0, g.stream, reinterpret_cast<unsigned char *>(d_e), terms, (uint32_t)K,
+    LAUNCH(k_fold_error<F>, fold_grid(n), 256, 0, g.stream, reinterpret_cast<unsigned char *>(d_e), (const unsigned char *)d_e, terms, (uint32_t)K,
            (const unsigned char *)(reinterpret_cast<unsigned char *>(g.fold_consts.p) + 48), (uint64_t)n);
+    tm_mark("fold_error");
+    RT_CHECK(rt_last());
+    RT_CHECK(rt_sync(g.stream));
+    tm_end();
+    return MIRA_OK;
+}
+// RelaxedPlonkWitness::fold in one submission (src/plonk/mod.rs:1097-1134): W' = W1 + r W2 over n_w elements and
+// E' = E + sum_k r^(k+1) T_k over n, constants in one copy, one synchronisation.  d_e_out may be d_e.
+template <class F, class FP>
+static int fold_relaxed_t(void *d_w_out, const void *d_w1, const void *d_w2, size_t n_w, void *d_e_out, const void *d_e, const void *const *d_terms, size_t K,
+                          const uint64_t r[4], size_t n) {
+    int rc;
+    if ((rc = g.fold_consts.ensure(48 * (FOLD_MAX_TERMS + 1)))) return rc;
+    uint32_t cm[12 * (FOLD_MAX_TERMS + 1)];
+    to_mult48<FP>(r, cm);
+    hostf::HFe<FP> rr, p;
+    memcpy(rr.l, r, 32);
+    p = rr;
+    FoldTerms terms;
+    memset(&terms, 0, sizeof terms);
+    for (size_t k = 0; k < K; k++) {
+        to_mult48<FP>(p.l, cm + 12 * (k + 1));
+        p = hostf::mul(p, rr);
+        terms.t[k] = reinterpret_cast<const unsigned char *>(d_terms[k]);
+    }
+    RT_CHECK(rt_h2d(g.fold_consts.p, cm, 48 * (K + 1), g.stream));
+    tm_begin();
+    if (n_w)
+        LAUNCH(k_fold_axpy<F>, fold_grid(n_w), 256, 0, g.stream, reinterpret_cast<const unsigned char *>(d_w1), reinterpret_cast<const unsigned char *>(d_w2),
+               reinterpret_cast<const unsigned char *>(g.fold_consts.p), (uint64_t)n_w, reinterpret_cast<unsigned char *>(d_w_out));
+    tm_mark("fold_witness");
+    if (n && K)
+        LAUNCH(k_fold_error<F>, fold_grid(n), 256, 0, g.stream, reinterpret_cast<unsigned char *>(d_e_out), reinterpret_cast<const unsigned char *>(d_e), terms, (uint32_t)K,
+               (const unsigned char *)(reinterpret_cast<unsigned char *>(g.fold_consts.p) + 48), (uint64_t)n);
+    else if (n && d_e_out != d_e)
+        RT_CHECK(rt_d2d(d_e_out, d_e, n * 32, g.stream));
     tm_mark("fold_error");
     RT_CHECK(rt_last());
     RT_CHECK(rt_sync(g.stream));
@@ -151,6 +187,11 @@ int pow_tree_reduce_device(int field, const void *d_leaves, uint32_t levels, siz
 
 int fold_witness_device(int field, void *d_out, const void *d_w1, const void *d_w2, const uint64_t r[4], size_t n) {
     return field == 1 ? fold_witness_t<Fr29, FrP>(d_out, d_w1, d_w2, r, n) : fold_witness_t<Fq29, FqP>(d_out, d_w1, d_w2, r, n);
+}
+int fold_relaxed_device(int field, void *d_w_out, const void *d_w1, const void *d_w2, size_t n_w, void *d_e_out, const void *d_e, const void *const *d_terms, size_t K,
+                        const uint64_t r[4], size_t n) {
+    return field == 1 ? fold_relaxed_t<Fr29, FrP>(d_w_out, d_w1, d_w2, n_w, d_e_out, d_e, d_terms, K, r, n)
+                      : fold_relaxed_t<Fq29, FqP>(d_w_out, d_w1, d_w2, n_w, d_e_out, d_e, d_terms, K, r, n);
 }
 int fold_error_device(int field, void *d_e, const void *const *d_terms, size_t K, const uint64_t r[4], size_t n) {
     return field == 1 ? fold_error_t<Fr29, FrP>(d_e, d_terms, K, r, n) : fold_error_t<Fq29, FqP>(d_e, d_terms, K, r, n);

@@ -38,10 +38,11 @@ KERNEL void k_fold_axpy(const unsigned char *__restrict__ a, const unsigned char
 }
 // e[i] += sum_k powers[k] * T_k[i],  powers[k] = r^(k+1) in multiplier form (48 B each)
 template <class F>
-KERNEL void k_fold_error(unsigned char *__restrict__ e, FoldTerms terms, uint32_t K, const unsigned char *__restrict__ powers, uint64_t n) {
+KERNEL void k_fold_error(unsigned char *e, const unsigned char *e_in /* may be e: element i is read before it is written */, FoldTerms terms, uint32_t K,
+                         const unsigned char *__restrict__ powers, uint64_t n) {
     using S = typename F::Sat;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        Fe<S> acc = fe_load<S>(e + i * 32);
+        Fe<S> acc = fe_load<S>(e_in + i * 32);
         for (uint32_t k = 0; k < K; k++) {
             Fe<S> t = fe_load<S>(terms.t[k] + i * 32);
             acc = fe_add(acc, fold_canonical(f29_mul(f29_unpack_canonical<F>(t), fold_const_load<F>(powers + (size_t)k * 48))));

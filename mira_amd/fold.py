@@ -33,6 +33,17 @@ def fold_error_device(field, d_e, d_cross_terms, r, n, lib=None):
     lib.check(lib.c.mira_fold_error_device(field, ctypes.c_void_p(d_e), ptrs, len(d_cross_terms), r.ctypes.data_as(ctypes.c_void_p), n))
 
 
+def fold_relaxed_witness_device(field, d_w_out, d_w1, d_w2, n_w, d_e_out, d_e, d_cross_terms, r, n, lib=None):
+    """`RelaxedPlonkWitness::fold` in one submission (src/plonk/mod.rs:1097-1134): w_out = w1 + r w2 over n_w elements and
+    e_out = e + sum_k r^(k+1) cross_terms[k] over n (d_e_out may be d_e)."""
+    lib = lib or _lib.load()
+    r = _u64(r, 4)
+    ptrs = (ctypes.c_void_p * max(1, len(d_cross_terms)))(*d_cross_terms)
+    lib.check(lib.c.mira_fold_relaxed_witness_device(field, ctypes.c_void_p(d_w_out), ctypes.c_void_p(d_w1), ctypes.c_void_p(d_w2), n_w,
+                                                     ctypes.c_void_p(d_e_out), ctypes.c_void_p(d_e), ptrs, len(d_cross_terms),
+                                                     r.ctypes.data_as(ctypes.c_void_p), n))
+
+
 def fold_witness(field, w1, w2, r, lib=None):
     """Host-array convenience around fold_witness_device (uploads, folds, downloads)."""
     lib = lib or _lib.load()

@@ -41,6 +41,36 @@ def test_emu_fold(emu_lib, field):
         FD.fold_witness(field, w1, w2[:-1], r, lib=emu_lib)        # zip_eq
 
 
+def _relaxed_fold_case(lib, field, n_w, n, nterms, in_place):
+    """mira_fold_relaxed_witness_device against the oracle's fold_witness / fold_error (src/plonk/mod.rs:1097-1134)."""
+    cid = CURVE_OF_FIELD[field]
+    w1, w2 = C.synth_scalars(cid, max(n_w, 1), seed=71, kind=1)[:n_w], C.synth_scalars(cid, max(n_w, 1), seed=72)[:n_w]
+    e = C.synth_scalars(cid, max(n, 1), seed=73)[:n]
+    terms = [C.synth_scalars(cid, max(n, 1), seed=80 + k)[:n] for k in range(nterms)]
+    r = C.synth_scalars(cid, 1, seed=74)[0]
+    up = lambda a: (lambda d: (lib.upload(d, np.ascontiguousarray(a)), d)[1])(lib.alloc(max(32, a.nbytes)))
+    d_w1, d_w2, d_e = up(w1), up(w2), up(e)
+    d_t = [up(t) for t in terms]
+    d_w_out, d_e_out = lib.alloc(max(32, n_w * 32)), (d_e if in_place else lib.alloc(max(32, n * 32)))
+    try:
+        FD.fold_relaxed_witness_device(field, d_w_out, d_w1, d_w2, n_w, d_e_out, d_e, d_t, r, n, lib=lib)
+        if n_w:
+            assert (lib.download(d_w_out, (n_w, 4)) == C.fold_witness(field, w1, w2, r)).all()
+        if n:
+            assert (lib.download(d_e_out, (n, 4)) == (C.fold_error(field, e, terms, r) if nterms else e)).all()
+            if not in_place:
+                assert (lib.download(d_e, (n, 4)) == e).all()             # the accumulator's E is left alone
+    finally:
+        for d in [d_w1, d_w2, d_e, d_w_out] + d_t + ([] if in_place else [d_e_out]):
+            lib.free(d)
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_emu_fold_relaxed_witness_in_one_submission(emu_lib, field):
+    for n_w, n, nterms, in_place in ((1400, 200, 6, False), (700, 100, 5, True), (0, 64, 3, False), (300, 0, 0, False), (100, 50, 0, False), (100, 50, 0, True)):
+        _relaxed_fold_case(emu_lib, field, n_w, n, nterms, in_place)
+
+
 def test_emu_commit_is_homomorphic_over_fold(emu_lib):
     """is_sat_relaxed's check (src/plonk/mod.rs:547-557): the commitment of the folded witness
     equals the folded commitment -- with every piece coming from this library."""

@@ -21,6 +21,16 @@ def test_fold_parity(gpu_lib, field, n):
     assert (FD.fold_error(field, w1, terms, r) == C.fold_error(field, w1, terms, r)).all()
 
 
+@pytest.mark.parametrize("field", [0, 1])
+def test_fold_relaxed_witness_in_one_submission(gpu_lib, field):
+    """mira_fold_relaxed_witness_device at the fold step's shapes (14 / 7 columns of 2^17 rows, 6 / 5 cross terms) and at ragged
+    ones, out of place and in place, against the oracle."""
+    from test_fold_and_cache import _relaxed_fold_case
+    cols, nterms = (14, 6) if field == 1 else (7, 5)
+    for n_w, n, k, in_place in ((cols << 17, 1 << 17, nterms, False), (12345, 777, 16, True), (0, 4096, 2, False), (4096, 0, 0, False), (513, 511, 0, False)):
+        _relaxed_fold_case(gpu_lib, field, n_w, n, k, in_place)
+
+
 def test_fold_then_commit_matches_folded_commitment(gpu_lib):
     """Com(W1 + r W2) == Com(W1) + r Com(W2) (src/plonk/mod.rs:547-557) with fold, commits and the
     commitment-side fold all on this library, vectors staying in HBM between the steps."""

@@ -608,6 +608,17 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
         single = []
         for _ in range(9):
             t0 = time.perf_counter(); keys[cm.CURVE_BN256].commit_device(cross[cm.CURVE_BN256], n); single.append((time.perf_counter() - t0) * 1e3)
+        # opt-in, 2 x the key's HBM: the endomorphism copy (mira_msm_precompute_ex(handle, MIRA_TABLE_GLV)) -- single commits split
+        # every scalar into two 127-bit halves over half the windows; the same 13 calls, one per commit
+        from mira_amd import _lib as L_
+        for c in plan:
+            keys[c].precompute(L_.TABLE_GLV)
+        run(False)
+        tglv, single_glv = [], []
+        for _ in range(5):
+            t0 = time.perf_counter(); glv_pts = run(False); tglv.append((time.perf_counter() - t0) * 1e3)
+        for _ in range(9):
+            t0 = time.perf_counter(); keys[cm.CURVE_BN256].commit_device(cross[cm.CURVE_BN256], n); single_glv.append((time.perf_counter() - t0) * 1e3)
         # opt-in: shared-bucket fixed-base tables on both keys (mira_msm_precompute_ex(handle, 15) and (handle, 13):
         # 18 + 20 x the key's HBM): all windows share one bucket set, no Horner epilogue; every commit takes the set that
         # is fastest for its length and, from the second commit of a shape on, for the bit lengths of its scalars (the
@@ -629,6 +640,8 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
                                "gpu_ms": round(bat_ms, 3), "gpu_ms_one_call_per_commit": round(seq_ms, 3),
                                "gpu_ms_host_scalars_one_call_per_commit": round(sorted(hs)[2], 3), "gpu_ms_host_scalars_batched": round(sorted(hb)[2], 3),
                                "one_commit_131072_pairs_ms": round(sorted(single)[4], 3),
+                               "gpu_ms_one_call_per_commit_glv": round(sorted(tglv)[2], 3), "one_commit_131072_pairs_ms_glv": round(sorted(single_glv)[4], 3),
+                               "glv_same_points": bool(all((a == b).all() for a, b in zip(seq_pts, glv_pts))),
                                "gpu_ms_one_call_per_commit_tables": round(sorted(t16)[2], 3), "one_commit_131072_pairs_ms_tables": round(sorted(single16)[4], 3),
                                "gpu_ms_tables": round(sorted(t16b)[2], 3), "table_widths": [13, 15],
                                "tables_same_points": bool(all((a == b).all() for a, b in zip(seq_pts, t16_pts)) and all((a == b).all() for a, b in zip(seq_pts, t16b_pts))),

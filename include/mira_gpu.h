@@ -82,7 +82,14 @@ int mira_msm_precompute(uint64_t handle);
  * >= 2^18 pairs the wide tables when the key has them.  mira_msm_partial_device reports window_bits = 0,
  * num_windows = 16; a rank of a sharded MSM takes the wide tables if
  * present, else the widest shared set, whatever its chunk length.  Results are bit-identical whichever
- * set serves a commit.  Building a width twice is a no-op. */
+ * set serves a commit.  Building a width twice is a no-op.
+ * window_bits = MIRA_TABLE_GLV: not a table but the ENDOMORPHISM COPY of the key, [P_0, phi(P_0), P_1, phi(P_1), ...] with
+ * phi(x, y) = (beta x, y) (2 x the key's memory).  Both curves have j = 0, so phi(P) = lambda P for a cube root of unity
+ * lambda of the scalar field: a single commit through the per-window path then splits every scalar into two 128-bit halves
+ * (k = k1 + k2 lambda, k P = k1 P + k2 phi(P)) -- the same bucket additions over half the windows: half the bucket reduction,
+ * half the chain of doublings on the host.  The same points bit for bit; mira_msm_last_plan reports ceil(129 / c) windows.
+ * Commits that go through a table set, batches and ranks of a sharded MSM do not use it. */
+#define MIRA_TABLE_GLV 2
 int mira_msm_precompute_ex(uint64_t handle, int32_t window_bits);
 /* Validate every registered base against the curve equation on the GPU, as
  * load_or_setup_cache does with is_on_curve (src/commitment.rs:145-154). */
@@ -169,6 +176,8 @@ int mira_msm_last_table_bits(int32_t *table_bits);
 /* smallest number of sorted entries one lane of k_accumulate adds (shorter segments: more lanes busy on a small commit,
  * more cut runs for the fix-up); default 10 */
 #define MIRA_TUNE_MIN_SEGMENT 10
+/* 0: do not use a key's endomorphism copy (MIRA_TABLE_GLV) -- same-key A/B runs and tests; default 1 */
+#define MIRA_TUNE_GLV 11
 int mira_set_tuning(int knob, int64_t value);
 
 /* Read a range of the registered key back in the reference layout (cache file writing,

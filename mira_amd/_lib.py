@@ -31,7 +31,8 @@ SYMBOLS = [
     "mira_trim", "mira_dev_mem_info", "mira_msm_plan_window_bits", "mira_lincomb_multi_device", "mira_dev_copy", "mira_msm_last_table_bits",
     "mira_graph_specialize", "mira_graph_is_specialized", "mira_graph_jit_source",
 ]
-TUNE_STAGED_MIN_N, TUNE_TABLE_MIN_N, TUNE_PLAN_HIST_MIN_N, TUNE_NTT_MAX_LOG_LINE, TUNE_NTT_WAVE, TUNE_HOST_CHUNK_MIN_N, TUNE_NTT_SINGLE_TW_LOG, TUNE_NTT_FULL_TW_MAX_LOG, TUNE_TABLE_WIDTH, TUNE_JIT_LOADS_AHEAD, TUNE_MIN_SEGMENT = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+TUNE_STAGED_MIN_N, TUNE_TABLE_MIN_N, TUNE_PLAN_HIST_MIN_N, TUNE_NTT_MAX_LOG_LINE, TUNE_NTT_WAVE, TUNE_HOST_CHUNK_MIN_N, TUNE_NTT_SINGLE_TW_LOG, TUNE_NTT_FULL_TW_MAX_LOG, TUNE_TABLE_WIDTH, TUNE_JIT_LOADS_AHEAD, TUNE_MIN_SEGMENT, TUNE_GLV = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
+TABLE_GLV = 2   # mira_msm_precompute_ex(handle, MIRA_TABLE_GLV): the endomorphism copy of a key
 
 
 def _preload_hip_runtime():

@@ -127,7 +127,8 @@ class CommitmentKey:
         """Build the fixed-base window tables in HBM.  20-bit windows (13 x the key size): large
         commits take 13 instead of 16 bucket additions per pair.  16-bit windows (16 x): all windows
         share one bucket set -- the small commits of a fold step lose most of their latency-bound
-        tail.  Results are bit-identical either way."""
+        tail.  window_bits = _lib.TABLE_GLV: the endomorphism copy of the key (2 x), single commits then split every
+        scalar into two 128-bit halves over half the windows.  Results are bit-identical either way."""
         self.lib.check(self.lib.c.mira_msm_precompute_ex(self.handle, window_bits))
         self.precomputed = True
         return self

@@ -4,6 +4,7 @@
 // (src/fft.rs:51-196).  Kernels live in the per-curve units and ntt.hip.
 #include "ctx.h"
 #include "host_field.hpp"
+#include "glv_consts.h"
 #include <cerrno>
 #include <fcntl.h>
 #include <sys/stat.h>
@@ -93,7 +94,7 @@ template <class FP> static hostf::HFe<FP> small_const(long v) {
     return v < 0 ? hostf::sub(hostf::zero<FP>(), x) : x;
 }
 static int upload_consts() {
-    uint64_t blk[24];
+    uint64_t blk[32];
     memset(blk, 0, sizeof blk);
     auto gx = small_const<FqP>(1), gy = small_const<FqP>(2);
     memcpy(blk + 0, gx.l, 32); memcpy(blk + 4, gy.l, 32);
@@ -106,6 +107,15 @@ static int upload_consts() {
     auto b0 = small_const<FqP>(3 * 32);
     auto b1 = small_const<FrP>(-17 * 32);
     memcpy(blk + 16, b0.l, 32); memcpy(blk + 20, b1.l, 32);
+    // beta * 2^261 of each curve's endomorphism (glv.cuh): (32 beta) * 2^256, beta < 2^192
+    auto beta_r261 = [](const uint64_t b[4], auto tag) {
+        using FP = decltype(tag);
+        hostf::HFe<FP> v = {{b[0] << 5, (b[1] << 5) | (b[0] >> 59), (b[2] << 5) | (b[1] >> 59), (b[3] << 5) | (b[2] >> 59)}};
+        return hostf::to_mont(v);
+    };
+    auto be0 = beta_r261(Glv<FrP>::BETA, FqP{});
+    auto be1 = beta_r261(Glv<FqP>::BETA, FrP{});
+    memcpy(blk + 24, be0.l, 32); memcpy(blk + 28, be1.l, 32);
     int rc = g.consts.ensure(sizeof blk);
     if (rc) return rc;
     RT_CHECK(rt_h2d(g.consts.p, blk, sizeof blk, g.stream));
@@ -199,19 +209,69 @@ static double plan_cost_us(uint32_t c, double n, uint32_t count, const double *b
     return plan_table_us(c, n_eff * count) + heavy + W * (count - 1) * B / 5800.0;
 }
 
-static MsmPlan make_plan(size_t n, int32_t forced_c, uint32_t count = 1, uint64_t stride = 0, const uint32_t *bitlen_hist = nullptr) {
+// The GLV split (glv.cuh) has a table of its own: wall time in microseconds of one commit of 2^glv_log_n[r] uniform pairs -- twice
+// as many half-length scalars -- under width c (tools/glv_probe.py --calibrate, profiles/r03_k_glv.txt).  The widths that cut
+// 128 bits evenly stand out (9 at 2^17, 13 at 2^18 - 2^19, 16 beyond): a last window that holds only a few bits of every half is a
+// handful of very heavy buckets.
+static const int glv_log_n[11] = {10, 12, 14, 15, 16, 17, 18, 19, 20, 21, 22};
+static const double glv_wall_us[11][17] = {
+    //                c = 5      6      7      8      9     10     11     12     13     14     15     16
+    {0, 0, 0, 0, 0,   256,   248,   245,   210,   246,   240,   310,   293,   332,   437,   530,   592},
+    {0, 0, 0, 0, 0,   239,   237,   264,   256,   275,   277,   295,   322,   311,   397,   566,   597},
+    {0, 0, 0, 0, 0,   297,   296,   301,   290,   349,   337,   347,   351,   369,   410,   533,   532},
+    {0, 0, 0, 0, 0,   361,   363,   347,   322,   339,   397,   427,   414,   404,   452,   579,   600},
+    {0, 0, 0, 0, 0,   479,   447,   436,   448,   392,   444,   516,   516,   456,   514,   625,   639},
+    {0, 0, 0, 0, 0,   705,   631,   605,   595,   529,   560,   575,   668,   535,   589,   692,   721},
+    {0, 0, 0, 0, 0,  1133,  1007,   934,   881,   857,   833,   815,   862,   715,   774,   850,   852},
+    {0, 0, 0, 0, 0,  2045,  1788,  1616,  1461,  1450,  1332,  1283,  1283,  1090,  1138,  1201,  1181},
+    {0, 0, 0, 0, 0,  4100,  3600,  3200,  2900,  2662,  2358,  2220,  2145,  1867,  1886,  1899,  1828},   // (c < 9: not measured, extrapolated)
+    {0, 0, 0, 0, 0,  8200,  7200,  6400,  5800,  5158,  4529,  4155,  3929,  3462,  3391,  3369,  3123},
+    {0, 0, 0, 0, 0, 16400, 14400, 12800, 11600, 10785,  9327,  8571,  7828,  7044,  6795,  6666,  6074},
+};
+static double glv_table_us(uint32_t c, double pairs) {
+    const double x = std::log2(std::max(pairs, 1.0));
+    if (x <= glv_log_n[0]) return glv_wall_us[0][c];
+    for (int r = 1; r < 11; r++)
+        if (x <= glv_log_n[r]) {
+            const double t = (x - glv_log_n[r - 1]) / (glv_log_n[r] - glv_log_n[r - 1]);
+            return glv_wall_us[r - 1][c] * (1.0 - t) + glv_wall_us[r][c] * t;
+        }
+    return glv_wall_us[10][c] * pairs / std::exp2((double)glv_log_n[10]);
+}
+// n halves (2 x the pairs); with the bit lengths of the previous commit's halves: the dense commit with as many bucket additions,
+// plus what its heavy buckets cost beyond a uniform vector's (as plan_cost_us and pick_shared do)
+static double glv_cost_us(uint32_t c, double n_halves, const double *hist) {
+    const uint32_t W = (GLV_BITS + c - 1) / c;
+    double pairs = n_halves / 2, heavy = 0;
+    if (hist) {
+        double adds, load;
+        plan_len_stats(c, hist, &adds, &load);
+        const double dense_halves = std::max(1.0, adds / W);
+        pairs = dense_halves / 2;
+        static double uniform[256];                          // bit lengths of a magnitude uniform below 2^126 (what the table was measured on)
+        if (uniform[126] == 0)
+            for (int len = 1; len <= 126; len++) uniform[len] = std::exp2((double)len - 127.0);
+        double u_adds, u_load;
+        plan_len_stats(c, uniform, &u_adds, &u_load);
+        heavy = std::max(0.0, plan_heavy_us(adds, load, 1) - plan_heavy_us(u_adds * dense_halves, u_load * dense_halves, 1));
+    }
+    return glv_table_us(c, pairs) + heavy;
+}
+
+static MsmPlan make_plan(size_t n, int32_t forced_c, uint32_t count = 1, uint64_t stride = 0, const uint32_t *bitlen_hist = nullptr, uint32_t bits = 256) {
     MsmPlan p;
     uint32_t best_c = 13;
     double best = 1e300;
     double per_msm[256];
     if (bitlen_hist)
         for (int len = 0; len < 256; len++) per_msm[len] = (double)bitlen_hist[len] / count;
-    for (uint32_t c = 4; c <= 16 && !forced_c; c++) {
-        const double cost = plan_cost_us(c, (double)n, count, bitlen_hist ? per_msm : nullptr);
+    for (uint32_t c = (bits == 256 ? 4 : 5); c <= 16 && !forced_c; c++) {
+        const double cost = bits == 256 ? plan_cost_us(c, (double)n, count, bitlen_hist ? per_msm : nullptr)
+                                        : glv_cost_us(c, (double)n, bitlen_hist ? per_msm : nullptr);   // the halves of the GLV split: their own table
         if (cost < best * 0.99) { best = cost; best_c = c; }    // ties go to the narrower window (fewer buckets: less that skewed data can upset)
     }
     p.c = forced_c ? (uint32_t)forced_c : best_c;
-    p.W = (256 + p.c - 1) / p.c;
+    p.W = (bits + p.c - 1) / p.c;
     p.B = 1u << (p.c - 1);
     p.count = count; p.stride = stride; p.Wt = p.W * count;
     p.NB = p.Wt * p.B;
@@ -443,8 +503,12 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
     // a rank of a sharded MSM that was not given a width takes 16, whatever its chunk length: partials
     // of different widths cannot be combined, and chunk lengths differ between ranks
     const int32_t width = requested_c ? requested_c : (sharded && forced_c == 0) ? 16 : forced_c;
-    MsmPlan p = make_plan(n, width, 1, 0, use_hist ? stat : nullptr);
-    if (n >= (1ull << 31) || (uint64_t)n * p.W >= (1ull << 32)) { set_error("n too large for 32-bit entry offsets"); return MIRA_E_UNSUPPORTED; }
+    // the GLV split (glv.cuh): 2 n half-length scalars over the interleaved key; not for ranks of a sharded MSM (their partials
+    // must have one shape whatever each rank's key holds) nor beside a table set
+    const bool glv = bs.glv && !set && !table_mode && !sharded && n < (1ull << 30) && tuned(MIRA_TUNE_GLV, 1) != 0;
+    MsmPlan p = glv ? make_plan(2 * n, width, 1, 0, use_hist ? stat : nullptr, GLV_BITS) : make_plan(n, width, 1, 0, use_hist ? stat : nullptr);
+    p.glv = glv; p.glv_bases = glv ? bs.glv : nullptr;
+    if (n >= (1ull << 31) || (uint64_t)n * (glv ? 2 : 1) * p.W >= (1ull << 32)) { set_error("n too large for 32-bit entry offsets"); return MIRA_E_UNSUPPORTED; }
     if (p.W > MIRA_MAX_WINDOWS) { set_error("window configuration exceeds MIRA_MAX_WINDOWS"); return MIRA_E_UNSUPPORTED; }
     *c_out = p.c; *W_out = p.W;
     g.last_c = (int32_t)p.c; g.last_w = (int32_t)p.W; g.last_table_c = 0;
@@ -769,6 +833,7 @@ int mira_msm_unregister(uint64_t handle) {
     if (it->second.owned && it->second.d) (void)rt_free(it->second.d);
     if (it->second.tables) (void)rt_free(it->second.tables);
     for (auto &set : it->second.shared) (void)rt_free(set.p);
+    if (it->second.glv) (void)rt_free(it->second.glv);
     g_bases.erase(it);
     return MIRA_OK;
 }
@@ -788,6 +853,11 @@ static int precompute_locked(uint64_t handle, int32_t window_bits) {
         if (rc) return rc;
         if (tmp.tables) bs.shared.push_back({tmp.tables, (uint32_t)window_bits, W});
         return MIRA_OK;
+    }
+    if (window_bits == MIRA_TABLE_GLV) {                       // the interleaved key [P_i, phi(P_i)] of the GLV split
+        if (bs.glv || bs.n == 0) return MIRA_OK;
+        const unsigned char *consts = reinterpret_cast<const unsigned char *>(g.consts.p);
+        return bs.curve == MIRA_CURVE_BN256 ? build_glv_bn256(bs, consts + 192) : build_glv_grumpkin(bs, consts + 224);
     }
     if (window_bits != 20 && window_bits != 22) { set_error("window tables are built for 8- to 16-bit (shared buckets), 20- or 22-bit windows"); return MIRA_E_BAD_ARG; }
     if (bs.tables && bs.table_c != (uint32_t)window_bits) { set_error("this key already has wide tables of another width"); return MIRA_E_BAD_ARG; }
@@ -889,7 +959,7 @@ int mira_msm_combine(int curve, const uint64_t *partials, size_t nparts, int32_t
 }
 int mira_set_tuning(int knob, int64_t value) {
     std::lock_guard<std::mutex> lk(g_lock);
-    if (knob < 0 || knob > MIRA_TUNE_MIN_SEGMENT) { set_error("unknown tuning knob"); return MIRA_E_BAD_ARG; }
+    if (knob < 0 || knob > MIRA_TUNE_GLV) { set_error("unknown tuning knob"); return MIRA_E_BAD_ARG; }
     g.tune[knob] = value;
     return MIRA_OK;
 }

@@ -129,6 +129,7 @@ struct Bases {
     // shared-bucket table sets (8 .. 16 bits, msm_host.cuh): any number of widths beside each other, each W x the key
     struct SharedSet { void *p; uint32_t c, W; };
     std::vector<SharedSet> shared;
+    void *glv = nullptr;      // the interleaved key of the GLV split, 2 n points (mira_msm_precompute_ex(handle, MIRA_TABLE_GLV)), or null
     // bit-length histogram of the scalars of the previous commit of stat_n elements over this key
     // (planning input for the next one of the same length; never affects a result)
     mutable uint32_t stat_hist[256] = {0};
@@ -154,6 +155,9 @@ struct MsmPlan {
     const void *shared_tables = nullptr;   // the W tables of this width, table_n points each
     uint64_t table_n = 0;
     uint32_t sums = 0;
+    // GLV (glv.cuh): the n scalars become 2 n half-length ones over the interleaved key [P_i, phi(P_i)]; W = ceil(129 / c)
+    bool glv = false;
+    const void *glv_bases = nullptr;
     bool stats = false;   // also histogram the bit lengths of the scalars (planning input of the next commit of this shape)
 };
 
@@ -165,6 +169,8 @@ int msm_launch_table_bn256(const Bases &bs, size_t first, const void *d_scalars,
 int msm_launch_table_grumpkin(const Bases &bs, size_t first, const void *d_scalars, size_t n, uint64_t *host_sums);
 int build_tables_bn256(Bases &bs, uint32_t c, uint32_t W);
 int build_tables_grumpkin(Bases &bs, uint32_t c, uint32_t W);
+int build_glv_bn256(Bases &bs, const void *d_beta_r261);
+int build_glv_grumpkin(Bases &bs, const void *d_beta_r261);
 int curve_init_bn256();
 int convert_bases_bn256(const void *d_src, void *d_dst, size_t n);
 int convert_bases_grumpkin(const void *d_src, void *d_dst, size_t n);

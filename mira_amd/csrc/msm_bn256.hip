@@ -18,6 +18,7 @@ int msm_launch_table_bn256(const Bases &bs, size_t first, const void *d_scalars,
     return msm_launch_table<Fq29, FrP>(bs, first, d_scalars, n, host_sums);
 }
 int build_tables_bn256(Bases &bs, uint32_t c, uint32_t W) { return build_tables<Fq29>(bs, c, W); }
+int build_glv_bn256(Bases &bs, const void *d_beta_r261) { return build_glv<Fq29>(bs, d_beta_r261); }
 int load_bases_file_bn256(Bases &b, int fd, bool validate, uint32_t *d_bad) {
     return load_bases_file<Fq29>(b, fd, validate, reinterpret_cast<const unsigned char *>(g.consts.p) + 128, d_bad);
 }

@@ -18,6 +18,7 @@ int msm_launch_table_grumpkin(const Bases &bs, size_t first, const void *d_scala
     return msm_launch_table<Fr29, FqP>(bs, first, d_scalars, n, host_sums);
 }
 int build_tables_grumpkin(Bases &bs, uint32_t c, uint32_t W) { return build_tables<Fr29>(bs, c, W); }
+int build_glv_grumpkin(Bases &bs, const void *d_beta_r261) { return build_glv<Fr29>(bs, d_beta_r261); }
 int load_bases_file_grumpkin(Bases &b, int fd, bool validate, uint32_t *d_bad) {
     return load_bases_file<Fr29>(b, fd, validate, reinterpret_cast<const unsigned char *>(g.consts.p) + 160, d_bad);
 }

@@ -71,6 +71,8 @@ static int msm_launch_body(const Bases &bs, size_t first, const void *d_scalars,
     const std::vector<size_t> ends = (h_scalars && p.count == 1) ? host_chunks(n, tuned(MIRA_TUNE_HOST_CHUNK_MIN_N, (size_t)1 << 19)) : std::vector<size_t>{n};
     size_t nmax = 0;
     for (size_t k = 0, lo = 0; k < ends.size(); lo = ends[k++]) nmax = std::max(nmax, ends[k] - lo);
+    const size_t mult = p.glv ? 2 : 1;                        // columns of the digit matrix per scalar
+    nmax *= mult;
     const size_t entries_max = nmax * p.Wt;
     if ((rc = g.digits.ensure(entries_max * 2))) return rc;
     if ((rc = g.counts.ensure(((size_t)p.NB + 1) * 4))) return rc;
@@ -131,21 +133,27 @@ static int msm_launch_body(const Bases &bs, size_t first, const void *d_scalars,
         g.hist_sel ^= 1u;
     }
     for (size_t k = 0, lo = 0; k < ends.size(); lo = ends[k++]) {
-        const size_t nc = ends[k] - lo, entries = nc * p.Wt;
+        const size_t ns = ends[k] - lo, nc = ns * mult, entries = nc * p.Wt;   // ns scalars, nc columns of digits
         const unsigned char *sc = reinterpret_cast<const unsigned char *>(d_scalars) + lo * 32;
         // per-window buckets: entries are chunk-local point indices; shared buckets: entries name table points
-        const unsigned char *bases = p.shared ? reinterpret_cast<const unsigned char *>(p.shared_tables) : reinterpret_cast<const unsigned char *>(bs.d) + (first + lo) * 64;
+        const unsigned char *bases = p.shared ? reinterpret_cast<const unsigned char *>(p.shared_tables)
+                                   : p.glv  ? reinterpret_cast<const unsigned char *>(p.glv_bases) + (first + lo) * 128
+                                            : reinterpret_cast<const unsigned char *>(bs.d) + (first + lo) * 64;
         const uint32_t wgroup = p.shared ? p.W : 1u, idx_stride = p.shared ? (uint32_t)p.table_n : 0u, idx_first = p.shared ? (uint32_t)(first + lo) : 0u;
         const uint32_t add = k ? 1u : 0u;
         if (h_scalars) {
             // pageable or pinned, the copy engine moves it beside the kernels of the previous chunk
             hipStream_t cs = g.copy_stream ? g.copy_stream : st;
-            RT_CHECK(rt_h2d(const_cast<unsigned char *>(sc), reinterpret_cast<const unsigned char *>(h_scalars) + lo * 32, nc * 32, cs));
+            RT_CHECK(rt_h2d(const_cast<unsigned char *>(sc), reinterpret_cast<const unsigned char *>(h_scalars) + lo * 32, ns * 32, cs));
             if (cs != st) RT_CHECK(rt_stream_wait(st, cs, g.copy_events[k]));
         }
         // histogram / scatter tiling of this chunk: about two workgroups per CU, at least 1024 points per tile
         const uint32_t tile = (std::max<uint32_t>(1024, ceil_div(nc, std::max<uint32_t>(1, 512 / p.Wt))) + 1023) / 1024 * 1024, ntiles = ceil_div(nc, tile);
         const bool staged = nc * p.count >= staged_min_n && p.c >= 9;   // a batch is count MSMs' worth of entries
+        if (p.glv)
+            LAUNCH((k_digits<FS, true>), dim3(ceil_div(ns, 256), p.count), 256, 0, st, sc, (uint32_t)ns, (uint64_t)p.stride, p.c, p.W,
+                   reinterpret_cast<int16_t *>(g.digits.p), reinterpret_cast<uint32_t *>(g.counts.p), p.NB + 1, hist, hist_clear);
+        else
         LAUNCH(k_digits<FS>, dim3(ceil_div(nc, 256), p.count), 256, 0, st, sc, (uint32_t)nc, (uint64_t)p.stride, p.c, p.W,
                reinterpret_cast<int16_t *>(g.digits.p), reinterpret_cast<uint32_t *>(g.counts.p), p.NB + 1, hist, hist_clear);
         tm_mark("digits");
@@ -311,6 +319,21 @@ template <class F> static int export_bases(const Bases &bs, size_t first, size_t
            reinterpret_cast<unsigned char *>(d_out), (uint64_t)n);
     RT_CHECK(rt_last());
     RT_CHECK(rt_sync(g.stream));
+    return MIRA_OK;
+}
+
+// ---- the interleaved key of the GLV split (glv.cuh) -----------------------------------------------
+template <class F> static int build_glv(Bases &bs, const void *d_beta_r261) {
+    const size_t bytes = (size_t)bs.n * 128;
+    void *t = nullptr;
+    if (rt_malloc(&t, bytes) != hipSuccess || !t) {
+        set_error("device allocation of " + std::to_string(bytes) + " bytes for the endomorphism copy of the key failed");
+        return MIRA_E_ALLOC;
+    }
+    LAUNCH(k_glv_bases<F>, ceil_div(bs.n, 256), 256, 0, g.stream, reinterpret_cast<const unsigned char *>(bs.d), reinterpret_cast<unsigned char *>(t), (uint64_t)bs.n,
+           reinterpret_cast<const unsigned char *>(d_beta_r261));
+    if (rt_last() != hipSuccess || rt_sync(g.stream) != hipSuccess) { (void)rt_free(t); set_error("building the endomorphism copy of the key failed"); return MIRA_E_NO_DEVICE; }
+    bs.glv = t;
     return MIRA_OK;
 }
 

@@ -22,6 +22,7 @@
 #include "curve.cuh"
 #include "curve29.cuh"
 #include "quad29.cuh"
+#include "glv.cuh"
 
 static constexpr uint32_t KEY_NONE = 0xFFFFFFFFu;
 // Chains longer than this go to k_fixup_heavy (a quad adds a link in ~2.2 us plus the load of the partial).  Raising it
@@ -39,7 +40,8 @@ static constexpr int WSUM_BLOCK = 512;       // k_window_sum: 128 quads
 // the data.  Counted here, where every scalar is already canonical in registers (a pre-pass of its
 // own read the scalars a second time and cost a launch, a memset and a copy: 30-50 us per commit).
 // hist_clear = the OTHER of the two histogram buffers, zeroed for the next commit.
-template <class FS>
+// GLV (glv.cuh): every scalar becomes TWO half-length ones, columns 2 i and 2 i + 1 of a digit matrix of 2 n columns.
+template <class FS, bool GLV = false>
 KERNEL void k_digits(const unsigned char *__restrict__ scalars, uint32_t n, uint64_t stride, uint32_t c, uint32_t W,
                      int16_t *__restrict__ digits, uint32_t *__restrict__ counts, uint32_t ncounts,
                      uint32_t *__restrict__ hist, uint32_t *__restrict__ hist_clear) {
@@ -59,6 +61,37 @@ KERNEL void k_digits(const unsigned char *__restrict__ scalars, uint32_t n, uint
     if (i < n) {
         const uint32_t b = blockIdx.y;                   // MSM of the batch: its windows are b*W .. b*W + W-1
         Fe<FS> s = fe_from_mont(fe_load<FS>(scalars + ((size_t)b * stride + i) * 32));
+        if constexpr (GLV) {
+            uint32_t h[2][5];
+            bool neg[2];
+            glv_split<FS>(s.l, h[0], h[1], neg[0], neg[1]);
+            int16_t *dg = digits + (size_t)b * W * (2 * (size_t)n);
+            const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                if (sampled) {
+                    uint32_t len = 0;
+#pragma unroll
+                    for (int k = 0; k < 5; k++)
+                        if (h[e][k]) len = 32u * k + (32u - (uint32_t)__builtin_clz(h[e][k]));
+                    atomicAdd(&bins[len], 1u);
+                }
+                uint32_t carry = 0;
+                for (uint32_t w = 0; w < W; w++) {
+                    const uint32_t raw = (h[e][0] & mask) + carry;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) h[e][k] = (h[e][k] >> c) | (h[e][k + 1] << (32 - c));
+                    h[e][4] >>= c;
+                    int32_t d;
+                    // raw = 2^(c-1) may be written as -2^(c-1) with a carry or as +2^(c-1) without: whichever leaves the STORED digit
+                    // (negated for a negative half) at -2^(c-1), the one of the two an int16 holds at c = 16.  The last window keeps
+                    // what it holds (glv.cuh: magnitudes < 2^126.13 leave it below 2^(c-1) even under c W = 128).
+                    if ((raw > half || (raw == half && !neg[e])) && w + 1 < W) { d = (int32_t)raw - (int32_t)(1u << c); carry = 1; }
+                    else { d = (int32_t)raw; carry = 0; }
+                    dg[(size_t)w * (2 * (size_t)n) + 2 * (size_t)i + e] = (int16_t)(neg[e] ? -d : d);
+                }
+            }
+        } else {
         if (sampled) {
             uint32_t len = 0;
 #pragma unroll
@@ -78,6 +111,7 @@ KERNEL void k_digits(const unsigned char *__restrict__ scalars, uint32_t n, uint
             if (raw >= half) { d = (int32_t)raw - (int32_t)(1u << c); carry = 1; }
             else { d = (int32_t)raw; carry = 0; }
             dg[(size_t)w * n + i] = (int16_t)d;
+        }
         }
     }
     if (sampled) {                                       // uniform across the block

@@ -6,7 +6,7 @@ import ctypes
 import numpy as np
 import pytest
 
-from helpers import golden_msm_case, load_golden, mont_to_ints
+from helpers import golden_msm_case, ints_to_mont, load_golden, mont_to_ints
 from mira_amd import commitment as cm
 from mira_amd import fft as F
 from mira_amd import _lib
@@ -293,6 +293,59 @@ def test_emu_shared_bucket_tables_other_widths(emu_lib, tune):
     tune(_lib.TUNE_PLAN_HIST_MIN_N, 1)
     for v, w in ((sc, want), (dense, want_dense), (sc, want)):
         assert (key.commit(v) == w).all() and last_table() in (8, 13)
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_emu_glv_split(emu_lib, tune, cid):
+    """mira_msm_precompute_ex(handle, MIRA_TABLE_GLV): every scalar split into two signed 127-bit halves over the interleaved key
+    [P_i, phi(P_i)] (glv.cuh).  Same points as the oracle for scalars around the decomposition's edges (0, 1, 2^127 -+ 1, 2^128,
+    r - 1, r - 2, 2^253), an identity base, dense and witness-like vectors, planned and forced widths (5 .. 16: ceil(128 / c)
+    windows), a prefix, host scalars in point chunks, and with the statistics of the previous commit planning the next; switched
+    off by MIRA_TUNE_GLV = 0; chunk partials of a sharded MSM keep the plain shape."""
+    n = 300
+    r = P.CURVES[cid].r
+    bs = C.synth_bases(cid, n, seed=91)
+    bs[9] = 0
+    key = cm.CommitmentKey(cid, bs, lib=emu_lib)
+    key.precompute(_lib.TABLE_GLV)
+    key.precompute(_lib.TABLE_GLV)                            # twice: a no-op
+    edge = [0, 1, 2, (1 << 127) - 1, 1 << 127, (1 << 127) + 1, 1 << 128, r - 1, r - 2, 1 << 253, (1 << 253) + 12345]
+    cc, ww = ctypes.c_int32(), ctypes.c_int32()
+
+    def last_plan():
+        emu_lib.check(emu_lib.c.mira_msm_last_plan(ctypes.byref(cc), ctypes.byref(ww)))
+        return cc.value, ww.value
+    for kind, seed in ((0, 1), (1, 2)):
+        sc = C.synth_scalars(cid, n, seed=seed, kind=kind)
+        sc[20:20 + len(edge)] = ints_to_mont(edge, r)
+        want = C.commit(cid, bs, sc)
+        assert (key.commit(sc) == want).all()
+        c0, w0 = last_plan()
+        assert w0 == -(-128 // c0)                            # half the windows of the plain path
+        for c in (((16,) if cid == 0 else (9,)) if kind == 0 else ()):   # (every emulated commit takes seconds: the GPU suite sweeps the widths)
+            emu_lib.check(emu_lib.c.mira_msm_set_window_bits(c))
+            try:
+                assert (key.commit(sc) == want).all(), c
+                assert last_plan() == (c, -(-128 // c))
+            finally:
+                emu_lib.check(emu_lib.c.mira_msm_set_window_bits(0))
+    dense = C.synth_scalars(cid, n, seed=7)
+    want_dense = C.commit(cid, bs, dense)
+    assert (key.commit(dense[:77]) == C.commit(cid, bs[:77], dense[:77])).all()
+    tune(_lib.TUNE_GLV, 0)
+    assert (key.commit(dense) == want_dense).all() and last_plan()[1] == -(-256 // last_plan()[0])
+    tune(_lib.TUNE_GLV, 1)
+    tune(_lib.TUNE_HOST_CHUNK_MIN_N, 64)                      # host scalars in chunks of 32, 64, 128, ... points: rows 2 lo .. of the interleaved key
+    assert (key.commit(dense) == want_dense).all()
+    tune(_lib.TUNE_PLAN_HIST_MIN_N, 1)                        # the bit lengths of the halves of one commit plan the next
+    d = emu_lib.alloc(n * 32)
+    for v, w in ((sc, want), (dense, want_dense)):
+        emu_lib.upload(d, v)
+        assert (key.commit_device(d, n) == w).all()
+    pb, cb, wb = key.commit_partial_device(120, d + 120 * 32, n - 120)
+    assert wb == -(-256 // cb)
+    assert (cm.combine_partials(cid, np.stack([pb]), cb, wb, lib=emu_lib) == C.commit(cid, bs[120:], dense[120:])).all()
+    emu_lib.free(d)
 
 
 def test_emu_data_dependent_planning(emu_lib, tune):

@@ -358,3 +358,65 @@ def test_every_bucket_heavy(gpu_lib, cid, n, c):
     assert (key.commit_device(d, n) == want).all()
     assert (key.commit(sc) == want).all()                        # host scalars, same width
     gpu_lib.free(d); key.close()
+
+
+@pytest.mark.parametrize("cid,log_n", [(0, 17), (1, 20)])
+def test_glv_split_every_width(gpu_lib, cid, log_n):
+    """mira_msm_precompute_ex(handle, MIRA_TABLE_GLV): the endomorphism copy of the key, every scalar split into two signed
+    127-bit halves (glv.cuh).  The plain per-window path's point (which the oracle confirms) for a dense and a witness-like
+    vector and a vector of the decomposition's edge scalars, planned and under every width 5 .. 16 (ceil(128 / c) windows), a
+    prefix, host scalars; batches and chunk partials keep the plain shape; a table set beside it takes precedence."""
+    n = 1 << log_n
+    r = P.CURVES[cid].r
+    key = cm.CommitmentKey.synthetic(cid, n, seed=141)
+    d = cm.synth_scalars_device(cid, n, seed=142)
+    dw = cm.synth_scalars_device(cid, n, seed=143, kind=1)
+    sc = gpu_lib.download(d, (n, 4))
+    edge = [0, 1, 2, (1 << 126) - 1, 1 << 126, (1 << 127) - 1, 1 << 127, (1 << 128) + 5, r - 1, r - 2, 1 << 253, (1 << 253) + 12345]
+    se = sc.copy()
+    se[1000:1000 + 64 * len(edge)] = np.tile(ints_to_mont(edge, r), (64, 1))
+    de = gpu_lib.alloc(n * 32); gpu_lib.upload(de, se)
+    before, before_w, before_e = key.commit_device(d, n), key.commit_device(dw, n), key.commit_device(de, n)
+    if log_n <= 17:
+        assert (before == C.commit(cid, key.bases(), sc)).all() and (before_e == C.commit(cid, key.bases(), se)).all()
+    m = n // 2 + 1234
+    before_m = key.commit_device(d, m)
+    before_b = key.commit_batch_device(d, n // 8, 5, stride=n // 8 + 7)
+    cc, ww = ctypes.c_int32(), ctypes.c_int32()
+
+    def last_plan():
+        gpu_lib.check(gpu_lib.c.mira_msm_last_plan(ctypes.byref(cc), ctypes.byref(ww)))
+        return cc.value, ww.value
+    key.precompute(_lib.TABLE_GLV)
+    try:
+        assert (key.commit_device(d, n) == before).all()
+        c0, w0 = last_plan()
+        assert w0 == -(-128 // c0)
+        assert (key.commit_device(dw, n) == before_w).all() and (key.commit_device(dw, n) == before_w).all()   # the second one planned by the first one's statistics
+        assert (key.commit_device(de, n) == before_e).all()
+        assert (key.commit_device(d, m) == before_m).all()
+        assert (key.commit(sc) == before).all()                                   # host scalars, in point chunks at 2^20
+        for c in range(5, 17):
+            gpu_lib.check(gpu_lib.c.mira_msm_set_window_bits(c))
+            assert (key.commit_device(de, n) == before_e).all(), c
+            assert last_plan() == (c, -(-128 // c))
+            if c in (8, 13, 16):
+                assert (key.commit_device(dw, n) == before_w).all(), c
+        gpu_lib.check(gpu_lib.c.mira_msm_set_window_bits(0))
+        assert (key.commit_batch_device(d, n // 8, 5, stride=n // 8 + 7) == before_b).all()
+        pa, ca, wa = key.commit_partial_device(0, d, m)
+        pb, cb, wb = key.commit_partial_device(m, d + m * 32, n - m)
+        assert (ca, wa) == (cb, wb) and wa == -(-256 // ca)
+        assert (cm.combine_partials(cid, np.stack([pa, pb]), ca, wa) == before).all()
+        gpu_lib.tune(_lib.TUNE_GLV, 0)
+        assert (key.commit_device(d, n) == before).all() and last_plan()[1] == -(-256 // last_plan()[0])
+        gpu_lib.tune(_lib.TUNE_GLV, -1)
+        key.precompute(13)                                                        # a shared-bucket set beside it serves the commit
+        tb = ctypes.c_int32()
+        assert (key.commit_device(d, n) == before).all()
+        gpu_lib.check(gpu_lib.c.mira_msm_last_table_bits(ctypes.byref(tb)))
+        assert tb.value == 13
+    finally:
+        gpu_lib.check(gpu_lib.c.mira_msm_set_window_bits(0))
+        gpu_lib.tune(_lib.TUNE_GLV, -1)
+        gpu_lib.free(d); gpu_lib.free(dw); gpu_lib.free(de); key.close()

@@ -1,5 +1,5 @@
 """Development tool: randomised MSM parity on the GPU against the oracle -- sizes, curves, scalar
-distributions, forced and planned window widths, window tables, batches, chunk partials.
+distributions, forced and planned window widths, window tables, the GLV split, batches, chunk partials.
 usage: python tools/fuzz_msm.py [seconds] [seed]"""
 import os, sys, time, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -51,12 +51,13 @@ while time.time() < t_end:
     key = cm.CommitmentKey(cid, bases) if bases is not None else cm.CommitmentKey.synthetic(cid, n, seed=rng.getrandbits(16))
     if bases is None:
         bases = key.download()
-    if n > 3 and rng.random() < 0.3:
-        pass
+    glv = rng.random() < 0.35
+    if glv:
+        key.precompute(_lib.TABLE_GLV)                     # the endomorphism copy: single commits split every scalar in two
     sc = scalars(cid, n, kind)
     want = C.msm_pippenger(cid, sc, bases)
     lib.check(lib.c.mira_msm_set_window_bits(forced))
-    desc = f"curve {cid} n {n} kind {kind} c {forced} {mode} staged {staged_small} chunks {chunks_small}"
+    desc = f"curve {cid} n {n} kind {kind} c {forced} {mode} staged {staged_small} chunks {chunks_small} glv {glv}"
     try:
         if mode == "commit":
             got = key.commit(sc)

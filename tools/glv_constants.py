@@ -1,9 +1,9 @@
-"""Development: the GLV constants of the two curves (not built this round), derived and checked against the
+"""Development: the GLV constants of the two curves (mira_amd/csrc/glv.cuh, glv_consts.h), derived and checked against the
 oracle's curve arithmetic.  Both curves are y^2 = x^3 + b: phi(x, y) = (beta x, y) is an endomorphism and acts on the
 prime-order group as multiplication by a cube root of unity lambda of the scalar field.  Prints, per curve: beta, lambda (the
 pair with phi(G) = lambda G), a reduced basis (a1, b1), (a2, b2) of the lattice {(x, y): x + y lambda = 0 mod r}, the rounding
 constants g_i = round(2^256 b_i / r) of the division-free decomposition, and the largest |k1|, |k2| seen over the test scalars.
-usage: python tools/glv_constants.py"""
+usage: python tools/glv_constants.py [--cpp]      (--cpp: the constants as mira_amd/csrc/glv_consts.h holds them)"""
 import os, random, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import pyref as P
@@ -71,6 +71,16 @@ for cid, cv in P.CURVES.items():
         phiQ = (beta * Q[0] % p, Q[1])
         part = lambda s, pt: P.ec_mul(abs(s), pt if s >= 0 else P.ec_neg(pt, cv), cv)
         assert P.ec_add(part(k1, Q), part(k2, phiQ), cv) == P.ec_mul(k, Q, cv)
+    if "--cpp" in sys.argv:                          # the specialisation of Glv<> in mira_amd/csrc/glv_consts.h
+        limbs = lambda v, n: ", ".join("0x%08xu" % ((v >> (32 * i)) & 0xFFFFFFFF) for i in range(n))
+        assert v1[0] > 0 and v1[1] < 0 and v2[0] > 0 and v2[1] > 0 and g1 > 0 and g2 > 0
+        print("template <> struct Glv<%s> {                                  // curve %d: scalars in %s, lambda = 0x%x" % ("FrP" if cid == 0 else "FqP", cid, "bn256::Fr" if cid == 0 else "bn256::Fq", lam))
+        print("    static constexpr uint32_t G1[3] = {%s}, G2[5] = {%s};" % (limbs(g1, 3), limbs(g2, 5)))
+        print("    static constexpr uint32_t A1[5] = {%s}, A2[5] = {%s};" % (limbs(v1[0], 5), limbs(v2[0], 5)))
+        print("    static constexpr uint32_t NB1[5] = {%s}, B2[5] = {%s};   // -b1, b2" % (limbs(-v1[1], 5), limbs(v2[1], 5)))
+        print("    static constexpr uint64_t BETA[4] = {%s};                // beta, a plain integer of the base field" % ", ".join("0x%016xull" % ((beta >> (64 * i)) & (2 ** 64 - 1)) for i in range(4)))
+        print("};")
+        continue
     print("curve %d (%s)" % (cid, "bn256 G1" if cid == 0 else "grumpkin"))
     print("  beta   = 0x%064x" % beta)
     print("  lambda = 0x%064x" % lam)

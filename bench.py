@@ -609,7 +609,7 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
         for _ in range(9):
             t0 = time.perf_counter(); keys[cm.CURVE_BN256].commit_device(cross[cm.CURVE_BN256], n); single.append((time.perf_counter() - t0) * 1e3)
         # opt-in, 2 x the key's HBM: the endomorphism copy (mira_msm_precompute_ex(handle, MIRA_TABLE_GLV)) -- single commits split
-        # every scalar into two 127-bit halves over half the windows; the same 13 calls, one per commit
+        # every scalar into two 127-bit halves over half the windows; the same 13 calls, one per commit, and the batched form
         from mira_amd import _lib as L_
         for c in plan:
             keys[c].precompute(L_.TABLE_GLV)
@@ -619,6 +619,10 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
             t0 = time.perf_counter(); glv_pts = run(False); tglv.append((time.perf_counter() - t0) * 1e3)
         for _ in range(9):
             t0 = time.perf_counter(); keys[cm.CURVE_BN256].commit_device(cross[cm.CURVE_BN256], n); single_glv.append((time.perf_counter() - t0) * 1e3)
+        run(True)
+        tglvb = []
+        for _ in range(5):
+            t0 = time.perf_counter(); glvb_pts = run(True); tglvb.append((time.perf_counter() - t0) * 1e3)
         # opt-in: shared-bucket fixed-base tables on both keys (mira_msm_precompute_ex(handle, 15) and (handle, 13):
         # 18 + 20 x the key's HBM): all windows share one bucket set, no Horner epilogue; every commit takes the set that
         # is fastest for its length and, from the second commit of a shape on, for the bit lengths of its scalars (the
@@ -641,7 +645,8 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
                                "gpu_ms_host_scalars_one_call_per_commit": round(sorted(hs)[2], 3), "gpu_ms_host_scalars_batched": round(sorted(hb)[2], 3),
                                "one_commit_131072_pairs_ms": round(sorted(single)[4], 3),
                                "gpu_ms_one_call_per_commit_glv": round(sorted(tglv)[2], 3), "one_commit_131072_pairs_ms_glv": round(sorted(single_glv)[4], 3),
-                               "glv_same_points": bool(all((a == b).all() for a, b in zip(seq_pts, glv_pts))),
+                               "gpu_ms_glv": round(sorted(tglvb)[2], 3),
+                               "glv_same_points": bool(all((a == b).all() for a, b in zip(seq_pts, glv_pts)) and all((a == b).all() for a, b in zip(seq_pts, glvb_pts))),
                                "gpu_ms_one_call_per_commit_tables": round(sorted(t16)[2], 3), "one_commit_131072_pairs_ms_tables": round(sorted(single16)[4], 3),
                                "gpu_ms_tables": round(sorted(t16b)[2], 3), "table_widths": [13, 15],
                                "tables_same_points": bool(all((a == b).all() for a, b in zip(seq_pts, t16_pts)) and all((a == b).all() for a, b in zip(seq_pts, t16b_pts))),
@@ -846,6 +851,18 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
                                             "+ interpolation: the same vectors as the reference's grouped graphs, which the CPU leg evaluates; every evaluation point through its own run-time "
                                             "compiled kernel, built once per circuit in specialize_s -- ms_interpreted_graphs: through the graph interpreter, as in earlier rounds), "
                                             "batched cross-term commits, W / E folding and instance folding (mira_g1_fold_commitments, host threads); span names follow the reference's tracing spans"}
+        # opt-in, 2 x the keys' HBM: the same chain with the endomorphism copies of both keys (the GLV split)
+        from mira_amd import _lib as L_
+        for s_ in st.values():
+            s_["key"].precompute(L_.TABLE_GLV)
+        fold_step()
+        walls_g = []
+        for _ in range(5):
+            t0 = time.perf_counter(); spans_g, last_g = fold_step(); walls_g.append(((time.perf_counter() - t0) * 1e3, spans_g))
+        wall_g, spans_g = sorted(walls_g, key=lambda x: x[0])[2]
+        same_g = all((last_g[c]["w_commit"] == last[c]["w_commit"]).all() and (last_g[c]["t_commits"] == last[c]["t_commits"]).all()
+                     and (last_g[c]["folded_e"] == last[c]["folded_e"]).all() for c in st)
+        ex["nifs_fold_step_k17"].update({"ms_glv": round(wall_g, 3), "spans_ms_glv": {a: round(b * 1e3, 3) for a, b in spans_g.items()}, "glv_same_points": bool(same_g)})
         # opt-in: the same chain over shared-bucket fixed-base tables (mira_msm_precompute_ex(handle, 15), (handle, 13)) --
         # a commitment key is fixed for the whole IVC run, its tables are built once
         for s_ in st.values():

@@ -88,7 +88,8 @@ int mira_msm_precompute(uint64_t handle);
  * lambda of the scalar field: a single commit through the per-window path then splits every scalar into two 128-bit halves
  * (k = k1 + k2 lambda, k P = k1 P + k2 phi(P)) -- the same bucket additions over half the windows: half the bucket reduction,
  * half the chain of doublings on the host.  The same points bit for bit; mira_msm_last_plan reports ceil(129 / c) windows.
- * Commits that go through a table set, batches and ranks of a sharded MSM do not use it. */
+ * Single commits and batches through the per-window path use it; commits served by a table set and ranks of a sharded MSM
+ * (whose partials must have one shape on every rank) do not. */
 #define MIRA_TABLE_GLV 2
 int mira_msm_precompute_ex(uint64_t handle, int32_t window_bits);
 /* Validate every registered base against the curve equation on the GPU, as

@@ -240,7 +240,7 @@ static double glv_table_us(uint32_t c, double pairs) {
 }
 // n halves (2 x the pairs); with the bit lengths of the previous commit's halves: the dense commit with as many bucket additions,
 // plus what its heavy buckets cost beyond a uniform vector's (as plan_cost_us and pick_shared do)
-static double glv_cost_us(uint32_t c, double n_halves, const double *hist) {
+static double glv_cost_us(uint32_t c, double n_halves, const double *hist, uint32_t count = 1) {
     const uint32_t W = (GLV_BITS + c - 1) / c;
     double pairs = n_halves / 2, heavy = 0;
     if (hist) {
@@ -255,7 +255,8 @@ static double glv_cost_us(uint32_t c, double n_halves, const double *hist) {
         plan_len_stats(c, uniform, &u_adds, &u_load);
         heavy = std::max(0.0, plan_heavy_us(adds, load, 1) - plan_heavy_us(u_adds * dense_halves, u_load * dense_halves, 1));
     }
-    return glv_table_us(c, pairs) + heavy;
+    // a batch: the commits' additions in one launch, and W 2^(c-1) more buckets to reduce per further commit (as plan_cost_us)
+    return glv_table_us(c, pairs * count) + heavy + (double)W * (count - 1) * (double)(1u << (c - 1)) / 5800.0;
 }
 
 static MsmPlan make_plan(size_t n, int32_t forced_c, uint32_t count = 1, uint64_t stride = 0, const uint32_t *bitlen_hist = nullptr, uint32_t bits = 256) {
@@ -267,7 +268,7 @@ static MsmPlan make_plan(size_t n, int32_t forced_c, uint32_t count = 1, uint64_
         for (int len = 0; len < 256; len++) per_msm[len] = (double)bitlen_hist[len] / count;
     for (uint32_t c = (bits == 256 ? 4 : 5); c <= 16 && !forced_c; c++) {
         const double cost = bits == 256 ? plan_cost_us(c, (double)n, count, bitlen_hist ? per_msm : nullptr)
-                                        : glv_cost_us(c, (double)n, bitlen_hist ? per_msm : nullptr);   // the halves of the GLV split: their own table
+                                        : glv_cost_us(c, (double)n, bitlen_hist ? per_msm : nullptr, count);   // the halves of the GLV split: their own table
         if (cost < best * 0.99) { best = cost; best_c = c; }    // ties go to the narrower window (fewer buckets: less that skewed data can upset)
     }
     p.c = forced_c ? (uint32_t)forced_c : best_c;
@@ -596,14 +597,19 @@ static int msm_batch_device_locked(uint64_t handle, const void *d_scalars, size_
         }
         return MIRA_OK;
     }
-    MsmPlan p1 = make_plan(n, forced_c);
+    // the GLV split (glv.cuh) where the key has its endomorphism copy: 2 n half-length scalars per commitment, half the windows
+    const bool glv = bs.glv && n < (1ull << 30) && tuned(MIRA_TUNE_GLV, 1) != 0;
+    const size_t nv = glv ? 2 * n : n;
+    const uint32_t bits = glv ? GLV_BITS : 256;
+    MsmPlan p1 = make_plan(nv, forced_c, 1, 0, nullptr, bits);
     // per launch: W_total * B counters <= 2^21 (three-launch scan) and n * W_total entries < 2^32
     size_t per = std::max<size_t>(1, std::min<size_t>((size_t)((1ull << 21) / ((uint64_t)p1.W * p1.B)),
-                                                      (size_t)(((1ull << 32) - 1) / ((uint64_t)n * p1.W))));
+                                                      (size_t)(((1ull << 32) - 1) / ((uint64_t)nv * p1.W))));
     std::vector<uint64_t> win;
     for (size_t done = 0; done < count; done += per) {
         const size_t cnt = std::min(per, count - done);
-        MsmPlan p = make_plan(n, forced_c, (uint32_t)cnt, stride);
+        MsmPlan p = make_plan(nv, forced_c, (uint32_t)cnt, stride, nullptr, bits);
+        p.glv = glv; p.glv_bases = glv ? bs.glv : nullptr;
         g.last_c = (int32_t)p.c; g.last_w = (int32_t)p.W; g.last_table_c = 0;
         win.assign((size_t)p.Wt * 16, 0);
         const unsigned char *sc = reinterpret_cast<const unsigned char *>(d_scalars) + done * stride * 32;

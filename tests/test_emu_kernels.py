@@ -300,8 +300,8 @@ def test_emu_glv_split(emu_lib, tune, cid):
     """mira_msm_precompute_ex(handle, MIRA_TABLE_GLV): every scalar split into two signed 127-bit halves over the interleaved key
     [P_i, phi(P_i)] (glv.cuh).  Same points as the oracle for scalars around the decomposition's edges (0, 1, 2^127 -+ 1, 2^128,
     r - 1, r - 2, 2^253), an identity base, dense and witness-like vectors, planned and forced widths (5 .. 16: ceil(128 / c)
-    windows), a prefix, host scalars in point chunks, and with the statistics of the previous commit planning the next; switched
-    off by MIRA_TUNE_GLV = 0; chunk partials of a sharded MSM keep the plain shape."""
+    windows), a prefix, a batch, host scalars in point chunks, and with the statistics of the previous commit planning the next;
+    switched off by MIRA_TUNE_GLV = 0; chunk partials of a sharded MSM keep the plain shape."""
     n = 300
     r = P.CURVES[cid].r
     bs = C.synth_bases(cid, n, seed=91)
@@ -332,6 +332,8 @@ def test_emu_glv_split(emu_lib, tune, cid):
     dense = C.synth_scalars(cid, n, seed=7)
     want_dense = C.commit(cid, bs, dense)
     assert (key.commit(dense[:77]) == C.commit(cid, bs[:77], dense[:77])).all()
+    vs = [dense[:150], sc[:150], np.zeros((150, 4), dtype=np.uint64)]          # a batch: 2 x 150 halves per commitment
+    assert (key.commit_batch(vs) == np.stack([C.commit(cid, bs[:150], v) for v in vs])).all() and last_plan()[1] == -(-128 // last_plan()[0])
     tune(_lib.TUNE_GLV, 0)
     assert (key.commit(dense) == want_dense).all() and last_plan()[1] == -(-256 // last_plan()[0])
     tune(_lib.TUNE_GLV, 1)

@@ -365,7 +365,7 @@ def test_glv_split_every_width(gpu_lib, cid, log_n):
     """mira_msm_precompute_ex(handle, MIRA_TABLE_GLV): the endomorphism copy of the key, every scalar split into two signed
     127-bit halves (glv.cuh).  The plain per-window path's point (which the oracle confirms) for a dense and a witness-like
     vector and a vector of the decomposition's edge scalars, planned and under every width 5 .. 16 (ceil(128 / c) windows), a
-    prefix, host scalars; batches and chunk partials keep the plain shape; a table set beside it takes precedence."""
+    prefix, host scalars, a batch of five; chunk partials keep the plain shape; a table set beside it takes precedence."""
     n = 1 << log_n
     r = P.CURVES[cid].r
     key = cm.CommitmentKey.synthetic(cid, n, seed=141)
@@ -404,6 +404,11 @@ def test_glv_split_every_width(gpu_lib, cid, log_n):
                 assert (key.commit_device(dw, n) == before_w).all(), c
         gpu_lib.check(gpu_lib.c.mira_msm_set_window_bits(0))
         assert (key.commit_batch_device(d, n // 8, 5, stride=n // 8 + 7) == before_b).all()
+        assert last_plan()[1] == -(-128 // last_plan()[0])
+        for c in (8, 13, 16):
+            gpu_lib.check(gpu_lib.c.mira_msm_set_window_bits(c))
+            assert (key.commit_batch_device(d, n // 8, 5, stride=n // 8 + 7) == before_b).all(), c
+        gpu_lib.check(gpu_lib.c.mira_msm_set_window_bits(0))
         pa, ca, wa = key.commit_partial_device(0, d, m)
         pb, cb, wb = key.commit_partial_device(m, d + m * 32, n - m)
         assert (ca, wa) == (cb, wb) and wa == -(-256 // ca)

@@ -142,19 +142,19 @@ static int upload_consts() {
 // LDS trees of general additions (5 us per level here).  A batch is count * W windows of one launch
 // sequence: the additions scale, the latency does not; its W * (count - 1) * B extra counters are
 // scanned at 5 800 per microsecond.
-static const int plan_log_n[10] = {6, 10, 13, 15, 16, 17, 18, 19, 20, 21};
+static const int plan_log_n[10] = {6, 10, 13, 15, 16, 17, 18, 19, 20, 21};   // (rows 2^16 .. 2^21 re-measured at the end of round 3, one box: profiles/r03_n_plan_calibrate.txt)
 static const double plan_wall_us[10][17] = {
     //            c = 4     5     6     7     8     9    10    11    12    13    14    15    16
     {0, 0, 0, 0,   198,   201,   227,   246,   293,   300,   312,   381,   379,   479,   521,   895,   905},
     {0, 0, 0, 0,   277,   263,   267,   270,   237,   278,   325,   315,   384,   452,   542,   612,   726},
     {0, 0, 0, 0,   301,   298,   303,   314,   288,   306,   313,   331,   345,   452,   504,   577,   665},
     {0, 0, 0, 0,   377,   388,   401,   343,   344,   425,   443,   427,   440,   470,   546,   597,   707},
-    {0, 0, 0, 0,   505,   479,   488,   535,   398,   458,   521,   539,   468,   535,   598,   606,   727},
-    {0, 0, 0, 0,   769,   688,   674,   695,   545,   595,   604,   710,   559,   606,   680,   692,   791},
-    {0, 0, 0, 0,  1311,  1126,  1045,  1014,   830,   858,   841,   929,   785,   806,   876,   867,   945},
-    {0, 0, 0, 0,  2434,  2016,  1856,  1707,  1410,  1496,  1382,  1367,  1185,  1158,  1203,  1163,  1205},
-    {0, 0, 0, 0,  4812,  4027,  3504,  3120,  2645,  2733,  2427,  2347,  2046,  1950,  1928,  1811,  1837},
-    {0, 0, 0, 0,  9716,  7999,  7002,  6254,  5259,  5270,  4675,  4343,  3871,  3564,  3452,  3171,  3128},
+    {0, 0, 0, 0,   501,   472,   486,   527,   398,   452,   497,   535,   466,   532,   594,   608,   663},
+    {0, 0, 0, 0,   770,   686,   669,   685,   544,   588,   601,   704,   554,   604,   674,   687,   724},
+    {0, 0, 0, 0,  1299,  1118,  1041,  1010,   828,   851,   838,   922,   773,   798,   869,   866,   880},
+    {0, 0, 0, 0,  2441,  2004,  1840,  1718,  1412,  1501,  1377,  1355,  1171,  1146,  1198,  1152,  1141},
+    {0, 0, 0, 0,  4792,  3979,  3481,  3184,  2699,  2770,  2438,  2336,  2002,  1957,  1932,  1843,  1777},
+    {0, 0, 0, 0,  9697,  8091,  7049,  6217,  5214,  5285,  4639,  4353,  3926,  3604,  3509,  3259,  3115},
 };
 static double plan_table_us(uint32_t c, double n_eff) {
     const double x = std::log2(std::max(n_eff, 1.0));
@@ -200,10 +200,13 @@ static double plan_cost_us(uint32_t c, double n, uint32_t count, const double *b
     if (bitlen_hist) {
         double adds, load, u_adds, u_load;
         plan_len_stats(c, bitlen_hist, &adds, &load);        // scalars of each length, per MSM
-        n_eff = adds / W;
+        // the dense vector with as many additions: the table was measured on UNIFORM field elements, which have u_adds non-zero
+        // digits each -- not W (254 bits under 15-bit windows: 17 digits in 18 windows; dividing by W made a uniform 2^22-pair
+        // vector look 6 % shorter under c = 15 than the vector the table was measured on, and 15 won over the faster 16)
+        plan_len_stats(c, plan_uniform_fractions(), &u_adds, &u_load);
+        n_eff = adds / u_adds;
         // the measured table already holds what the top window of UNIFORM field elements costs: only the
         // excess over a uniform vector with as many additions counts
-        plan_len_stats(c, plan_uniform_fractions(), &u_adds, &u_load);
         heavy = std::max(0.0, plan_heavy_us(adds, load, count) - plan_heavy_us(u_adds * n_eff, u_load * n_eff, count));
     }
     return plan_table_us(c, n_eff * count) + heavy + W * (count - 1) * B / 5800.0;

@@ -682,8 +682,8 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
     # 30 fixed + 2 x 14 advice columns.  Secondary (Grumpkin scalars): one gate, degree 5, 5 cross terms
     # over 15 fixed + 2 x 7 advice columns.  2^17 rows each; outputs stay in HBM for the commits.
     try:
-        from mira_amd import graph_evaluator as G
-        from mira_amd import main_gate as MG
+        from harness import graph_evaluator as G
+        from harness import main_gate as MG
         k = 17
         n = 1 << k
         res = {}
@@ -780,8 +780,8 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
     # arithmetic does not care), fixed columns uniform, the challenges synthetic.  CPU: the oracle's
     # restatements of the same calls on the effective host cores, same inputs, every output compared.
     try:
-        from mira_amd import graph_evaluator as G
-        from mira_amd import main_gate as MG
+        from harness import graph_evaluator as G
+        from harness import main_gate as MG
         from mira_amd import fold as FD
         k = 17
         n = 1 << k

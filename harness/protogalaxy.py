@@ -1,4 +1,4 @@
-"""Host-side mirror of ProtoGalaxy's polynomial pipeline, the only caller of
+"""TEST / BENCH HARNESS (not the engine).  Host-side mirror of ProtoGalaxy's polynomial pipeline, the only caller of
 the reference's FFT: `compute_F`, `compute_G`, `compute_K` (reference
 src/nifs/protogalaxy/poly/mod.rs:66-179, 218-303, 339-382), the Lagrange helpers they use
 (src/polynomial/lagrange.rs) and `FoldedTrace` (src/nifs/protogalaxy/poly/folded_trace.rs).
@@ -15,7 +15,8 @@ import ctypes
 
 import numpy as np
 
-from . import _lib
+from mira_amd import _lib
+
 from . import graph_evaluator as G
 
 FIELD = G.FIELD_FR
@@ -225,7 +226,7 @@ def compute_K(S, f_alpha, betas_stroke, accumulator, traces, lib=None):
     g_poly = compute_G(S, betas_stroke, accumulator, traces, lib)
     points_count = 1 << (len(traces) * S.max_degree()).bit_length()
     log_n = points_count.bit_length() - 1
-    from . import fft as F
+    from mira_amd import fft as F
     g_evals = _ints(F.coset_fft(G.to_montgomery(g_poly, FIELD), lib=lib))
     k_evals = []
     for w, g_y in zip(iter_cyclic_subgroup(log_n, lib), g_evals):

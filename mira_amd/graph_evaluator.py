@@ -1,15 +1,17 @@
-"""Host-side mirror of the reference's cross-term evaluation, the step before the MSM in one fold
-(SURVEY.md §8f row N1):
+"""Bindings of the cross-term evaluator, the step before the MSM in one fold:
 
-* `Expression` (reference src/polynomial/expression.rs:112-120) and `Query` (index, rotation);
-* `GraphEvaluator.new(expr)`: the calculation graph the reference builds from an expression
-  (src/polynomial/graph_evaluator.rs:196-352) -- same constants table, rotation table, sharing of
-  repeated sub-expressions and simplifications, so graphs are comparable node for node;
-* `GraphEvaluator.evaluate_device(...)`: every row at once on the GPU (`mira_graph_eval_device`),
-  replacing the per-row `evaluate` loop of `commit_cross_terms` (src/nifs/vanilla/mod.rs:100-121);
+* `GraphEvaluator`: a calculation graph in the flattened form of `include/mira_gpu.h` (constants, rotations, the
+  calculation list of src/polynomial/graph_evaluator.rs:93-176) and its life on the device -- compiled once per
+  circuit (`mira_graph_compile`), evaluated for every row at once (`mira_graph_eval_compiled` /
+  `mira_graph_eval_batch`), optionally through a kernel of its own (`mira_graph_specialize`).  It replaces the
+  per-row `evaluate` loop of `commit_cross_terms` (src/nifs/vanilla/mod.rs:100-121).  Building the graph from an
+  `Expression` (GraphEvaluator::new, graph_evaluator.rs:196-352) is symbolic host work of the reference that this
+  engine does not replace: the test / bench harness restates it in `harness/graph_evaluator.py`.
 * `PlonkEvalDomain`: the column index space of `eval_column_var` / `eval_advice_var`
   (src/plonk/eval.rs:57-69, 136-229) resolved to device pointers;
-* `commit_cross_terms`: evaluate every cross term into HBM and commit them in one batched MSM.
+* `commit_cross_terms`: evaluate every cross term into HBM and commit them in one batched MSM;
+* `CrossTermPlan`: the device side of "d cross terms from d + 1 evaluations" (graphs and interpolation coefficients
+  are handed in; `harness/graph_evaluator.py` derives them from the gate polynomial).
 
 Constants and challenges are plain Python integers below the field modulus on this side; device
 data is in the reference's Montgomery layout like everywhere else in this package."""
@@ -41,10 +43,6 @@ def to_montgomery(values, field):
     return out
 
 
-# Expression, Query and their transformations live in expression.py (re-exported here: the graph is built from them)
-from .expression import Challenge, Constant, Expression, Negated, Polynomial, Product, Scaled, Sum   # noqa: E402,F401
-
-
 # ---------------------------------------------------------------- GraphEvaluator
 # value sources are tuples ordered like the reference's derived PartialOrd (graph_evaluator.rs:55-68):
 # (SRC_CONSTANT, id) < (SRC_INTERMEDIATE, id); columns and challenges only appear inside Store
@@ -52,86 +50,20 @@ _ZERO, _ONE, _TWO = (SRC_CONSTANT, 0), (SRC_CONSTANT, 1), (SRC_CONSTANT, 2)
 
 
 class GraphEvaluator:
-    def __init__(self, field=FIELD_FR):
+    """constants: ints (the reference's table starts 0, 1, 2, graph_evaluator.rs:183-192); rotations: ints;
+    calculations: tuples (op, source...) with sources (SRC_*, id) or (SRC_COLUMN, index, rotation id);
+    calculation i writes intermediate i."""
+
+    def __init__(self, field=FIELD_FR, constants=(0, 1, 2), rotations=(), calculations=()):
         self.field = field
         self.mod = MODULUS[field]
-        self.constants = [0, 1, 2]            # the defaults of graph_evaluator.rs:183-192
-        self.rotations = []
-        self.calculations = []                # (op, sources...) ; calculation i writes intermediate i
-        self._known = {}                      # calculation -> intermediate that already holds it
-
-    @classmethod
-    def new(cls, expr, field=FIELD_FR):
-        """graph_evaluator.rs:196-203"""
-        ge = cls(field)
-        ge._calc((OP_STORE, ge._expr(expr)))
-        return ge
+        self.constants = list(constants)
+        self.rotations = list(rotations)
+        self.calculations = list(calculations)
 
     @property
     def num_intermediates(self):
         return len(self.calculations)
-
-    def _rotation(self, rot):                                   # add_rotation, :206-219
-        if rot not in self.rotations:
-            self.rotations.append(rot)
-        return self.rotations.index(rot)
-
-    def _constant(self, v):                                     # add_constant, :222-235
-        v %= self.mod
-        if v not in self.constants:
-            self.constants.append(v)
-        return (SRC_CONSTANT, self.constants.index(v))
-
-    def _calc(self, calc):                                      # add_calculation, :241-258
-        if calc not in self._known:
-            self._known[calc] = len(self.calculations)
-            self.calculations.append(calc)
-        return (SRC_INTERMEDIATE, self._known[calc])
-
-    def _expr(self, e):                                         # add_expression, :261-352
-        if isinstance(e, Constant):
-            return self._constant(e.value)
-        if isinstance(e, Polynomial):
-            return self._calc((OP_STORE, (SRC_COLUMN, e.index, self._rotation(e.rotation))))
-        if isinstance(e, Challenge):
-            return self._calc((OP_STORE, (SRC_CHALLENGE, e.index)))
-        if isinstance(e, Negated):
-            if isinstance(e.a, Constant):
-                return self._constant(-e.a.value)
-            a = self._expr(e.a)
-            return a if a == _ZERO else self._calc((OP_NEGATE, a))
-        if isinstance(e, Sum):
-            if isinstance(e.b, Negated):                        # a + (-b) is a subtraction
-                a, b = self._expr(e.a), self._expr(e.b.a)
-                if a == _ZERO:
-                    return self._calc((OP_NEGATE, b))
-                return a if b == _ZERO else self._calc((OP_SUB, a, b))
-            a, b = self._expr(e.a), self._expr(e.b)
-            return self._calc((OP_ADD,) + ((a, b) if a <= b else (b, a)))
-        if isinstance(e, Product):
-            a, b = self._expr(e.a), self._expr(e.b)
-            if _ZERO in (a, b):
-                return _ZERO
-            if a == _ONE:
-                return b
-            if b == _ONE:
-                return a
-            if a == _TWO:
-                return self._calc((OP_DOUBLE, b))
-            if b == _TWO:
-                return self._calc((OP_DOUBLE, a))
-            if a == b:
-                return self._calc((OP_SQUARE, a))
-            return self._calc((OP_MUL,) + ((a, b) if a <= b else (b, a)))
-        if isinstance(e, Scaled):
-            f = e.factor % self.mod
-            if f == 0:
-                return _ZERO
-            if f == 1:
-                return self._expr(e.a)
-            c = self._constant(f)
-            return self._calc((OP_MUL, self._expr(e.a), c))
-        raise TypeError(f"not an Expression: {e!r}")
 
     # ---- the flattened form of include/mira_gpu.h ------------------------------------------
     @staticmethod
@@ -373,61 +305,18 @@ class CrossTermPlan:
         p_0 = f(W1, c1) = T_0,    p_inf = f(W2, c2) = T_d,    p_x = f(W1 + x W2, c1 + x c2),  x = 1, -1, 2, -2, ... (d - 1 points)
     are evaluated row by row (d + 1 graphs over the same columns, one mira_graph_eval_batch) and
         T_k = sum_x Ainv[k][x] (p_x - T_0 - x^d T_d),  A[x][k] = x^k,  1 <= k <= d - 1
-    is one linear combination of those d + 1 vectors per cross term (mira_lincomb_device).  Field arithmetic is
+    is one linear combination of those d + 1 vectors per cross term (mira_lincomb_multi_device).  Field arithmetic is
     exact, so every T_k is the reference's value bit for bit (tests compare with the grouped graphs and the oracle);
-    the work is (d + 1) (|f| + one fold per queried column) + d - 1 streamed passes instead of sum_k |T_k|."""
+    the work is (d + 1) (|f| + one fold per queried column) + d - 1 streamed passes instead of sum_k |T_k|.
 
-    def __init__(self, homogeneous, degree, ctx, field=FIELD_FR):
-        from .expression import QueryIndexContext                         # noqa: F401  (ctx is one)
+    This class is the device side: `evaluators` are the d + 1 graphs in the order p_0, p_inf, p_x ..., `coeffs[k - 1]` the
+    integer coefficients of T_k on those vectors.  harness/graph_evaluator.py derives both from the gate polynomial."""
+
+    def __init__(self, degree, field, evaluators, coeffs):
         self.degree, self.field, self.mod = degree, field, MODULUS[field]
-        nsf, shift, nc = ctx.num_selectors + ctx.num_fixed, ctx.num_fold_vars(), ctx.num_challenges
-        d = degree
-
-        def at(x):
-            """f with every folded variable v replaced by v1 + x v2 (x = None: by v2 -- the leading coefficient)"""
-            def poly(p):
-                if p.index < nsf:
-                    return Polynomial(p.index, p.rotation)
-                second = Polynomial(p.index + shift, p.rotation)
-                if x is None:
-                    return second
-                return fold(Polynomial(p.index, p.rotation), second)
-
-            def fold(first, second):                                       # first + x * second in the cheapest calculations
-                if x == 0:
-                    return first
-                two = Product(Constant(2), second)                         # (2 * v is a DOUBLE)
-                mag = second if abs(x) == 1 else two if abs(x) == 2 else Sum(two, second) if abs(x) == 3 else Scaled(second, abs(x))   # 3 v = 2 v + v: no product
-                return Sum(first, mag if x > 0 else Negated(mag))          # a + (-b) is one SUB
-
-            def chal(i):
-                return Challenge(i + nc) if x is None else fold(Challenge(i), Challenge(i + nc))
-            return homogeneous.evaluate(lambda c: Constant(c), poly, chal, lambda a: Negated(a), lambda a, b: Sum(a, b), lambda a, b: Product(a, b),
-                                        lambda a, k: Scaled(a, k))
-        xs = [(j // 2 + 1) * (1 if j % 2 == 0 else -1) for j in range(d - 1)]     # 1, -1, 2, -2, 3, ...: the cheapest folds
-        self.points = [0, None] + xs                                       # vector order: p_0, p_inf, p_x ...
-        self.evaluators = [GraphEvaluator.new(at(x), field) for x in self.points]
-        # Ainv over the field: Gauss-Jordan on the (d - 1) x (d - 1) matrix x^k
-        m, mod = d - 1, self.mod
-        A = [[pow(x, k, mod) for k in range(1, d)] + [1 if j == r else 0 for j in range(m)] for r, x in enumerate(xs)]
-        for col in range(m):
-            piv = next(r for r in range(col, m) if A[r][col])
-            A[col], A[piv] = A[piv], A[col]
-            inv = pow(A[col][col], mod - 2, mod)
-            A[col] = [v * inv % mod for v in A[col]]
-            for r in range(m):
-                if r != col and A[r][col]:
-                    f = A[r][col]
-                    A[r] = [(a - f * b) % mod for a, b in zip(A[r], A[col])]
-        ainv = [row[m:] for row in A]                                      # ainv[k - 1][index of x]
-        # coefficients of T_k (k = 1 .. d - 1) on [p_0, p_inf, p_x ...]
-        self.coeffs = [[(-sum(ainv[k])) % mod, (-sum(ainv[k][r] * pow(x, d, mod) for r, x in enumerate(xs))) % mod] + ainv[k] for k in range(m)]
+        self.evaluators = list(evaluators)
+        self.coeffs = [list(row) for row in coeffs]
         self._coeffs_mont = {}                                             # the same in the library's form, converted once
-
-    @classmethod
-    def from_compressed_gates(cls, cg, ctx, field=FIELD_FR):
-        """cg: expression.CompressedGates (homogeneous form + degree), ctx: the QueryIndexContext after CompressedGates.new"""
-        return cls(cg.homogeneous, cg.degree, ctx, field)
 
     @property
     def num_calculations(self):

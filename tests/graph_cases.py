@@ -5,7 +5,7 @@ import random
 import numpy as np
 
 from helpers import ints_to_mont
-from mira_amd import graph_evaluator as G
+from harness import graph_evaluator as G
 from oracle import pyref as P
 
 MODS = {0: P.P_MOD, 1: P.R_MOD}

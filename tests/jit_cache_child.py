@@ -14,7 +14,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     cache_dir, field, seed = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     from graph_cases import gate_like_expression
-    from mira_amd import _lib, graph_evaluator as G
+    from mira_amd import _lib
+    from harness import graph_evaluator as G
     from test_gpu_graph import device_columns, synth_data
     lib = _lib.load()
     n = 1 << 10

@@ -17,10 +17,10 @@ import numpy as np
 import pytest
 
 from helpers import ints_to_mont, load_golden, mont_to_ints
-from mira_amd import expression as E
-from mira_amd import graph_evaluator as G
-from mira_amd import main_gate as MG
-from mira_amd.grouped_poly import GroupedPoly
+from harness import expression as E
+from harness import graph_evaluator as G
+from harness import main_gate as MG
+from harness.grouped_poly import GroupedPoly
 from oracle import cref as C
 from oracle import pyref as P
 

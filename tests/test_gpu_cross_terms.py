@@ -19,8 +19,8 @@ import pytest
 
 from helpers import ints_to_mont, mont_to_ints
 from mira_amd import commitment as cm
-from mira_amd import graph_evaluator as G
-from mira_amd import main_gate as MG
+from harness import graph_evaluator as G
+from harness import main_gate as MG
 from oracle import cref as C
 from oracle import pyref as P
 

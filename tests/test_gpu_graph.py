@@ -9,7 +9,7 @@ import pytest
 from graph_cases import MODS, gate_like_expression, oracle_columns, random_expression
 from helpers import ints_to_mont, mont_to_ints
 from mira_amd import commitment as cm
-from mira_amd import graph_evaluator as G
+from harness import graph_evaluator as G
 from oracle import cref as C
 from oracle import pyref as P
 

@@ -10,8 +10,8 @@ import pytest
 from graph_cases import MODS, gate_like_expression, oracle_columns, random_expression
 from helpers import ints_to_mont
 from mira_amd import commitment as cm
-from mira_amd import graph_evaluator as G
-from mira_amd import main_gate as MG
+from harness import graph_evaluator as G
+from harness import main_gate as MG
 from oracle import cref as C
 from test_gpu_graph import device_columns, synth_data
 

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from helpers import ints_to_mont, mont_to_ints
-from mira_amd import protogalaxy as PG
+from harness import protogalaxy as PG
 from oracle import cref as C
 from oracle import pyref as P
 from test_protogalaxy import MOD, build_case

@@ -11,8 +11,8 @@ import pytest
 
 from graph_cases import gate_like_expression
 from mira_amd import _lib
-from mira_amd import graph_evaluator as G
-from mira_amd import main_gate as MG
+from harness import graph_evaluator as G
+from harness import main_gate as MG
 
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mira_amd", "csrc")
 

@@ -10,8 +10,8 @@ import pytest
 
 from helpers import ints_to_mont, load_golden, mont_to_ints
 from mira_amd import _lib
-from mira_amd import graph_evaluator as G
-from mira_amd import protogalaxy as PG
+from harness import graph_evaluator as G
+from harness import protogalaxy as PG
 from oracle import cref as C
 from oracle import pyref as P
 

@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mira_amd import _lib
 if os.environ.get("MIRA_PROBE_LIB"):
     _lib.LIB_PATH = os.path.abspath(os.environ["MIRA_PROBE_LIB"])
-from mira_amd import commitment as cm, graph_evaluator as G, main_gate as MG
+from mira_amd import commitment as cm
+from harness import graph_evaluator as G, main_gate as MG
 lib = _lib.load()
 n = 1 << 17
 out = []

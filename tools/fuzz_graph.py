@@ -6,7 +6,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from graph_cases import MODS, gate_like_expression, mock_data, oracle_columns, random_expression
 from helpers import ints_to_mont
-from mira_amd import _lib, fft as F, graph_evaluator as G
+from mira_amd import _lib, fft as F
+from harness import graph_evaluator as G
 from oracle import cref as C
 lib = _lib.load()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0

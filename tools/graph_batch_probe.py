@@ -4,7 +4,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from graph_cases import gate_like_expression
-from mira_amd import _lib, commitment as cm, graph_evaluator as G
+from mira_amd import _lib, commitment as cm
+from harness import graph_evaluator as G
 lib = _lib.load()
 field, n = 1, 1 << 12
 rng = random.Random(1)

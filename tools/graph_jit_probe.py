@@ -1,7 +1,8 @@
 """Development probe: the evaluation points of the MainGate<5> cross terms at 2^17 rows, interpreted against specialised."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from mira_amd import _lib, commitment as cm, graph_evaluator as G, main_gate as MG
+from mira_amd import _lib, commitment as cm
+from harness import graph_evaluator as G, main_gate as MG
 lib = _lib.load()
 if len(sys.argv) > 1: lib.tune(_lib.TUNE_JIT_LOADS_AHEAD, int(sys.argv[1]))
 n = 1 << 17

@@ -2,7 +2,8 @@
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from mira_amd import _lib, commitment as cm, graph_evaluator as G
+from mira_amd import _lib, commitment as cm
+from harness import graph_evaluator as G
 if os.environ.get("MIRA_PROBE_LIB"):
     _lib.LIB_PATH = os.path.abspath(os.environ["MIRA_PROBE_LIB"])
 lib = _lib.load()

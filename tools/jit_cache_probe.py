@@ -6,7 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def child(cache_dir):
-    from mira_amd import _lib, commitment as cm, graph_evaluator as G, main_gate as MG
+    from mira_amd import _lib, commitment as cm
+    from harness import graph_evaluator as G, main_gate as MG
     lib = _lib.load()
     n = 1 << 12
     G.GraphEvaluator.set_jit_cache_dir(cache_dir, lib=lib)

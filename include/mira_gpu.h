@@ -179,6 +179,14 @@ int mira_msm_last_table_bits(int32_t *table_bits);
 #define MIRA_TUNE_MIN_SEGMENT 10
 /* 0: do not use a key's endomorphism copy (MIRA_TABLE_GLV) -- same-key A/B runs and tests; default 1 */
 #define MIRA_TUNE_GLV 11
+/* bucket reduction (csrc/reduce_kernels.cuh): results per bucket set handed to the host's chain of doublings (default: by
+ * shape; 1 = plain window sums), log2 of the buckets per running-sum chunk (default 2 by quads / 3 by lanes), and whether
+ * the running sums are taken by quads of lanes (1) or single lanes (0; default: quads while the chunks are few) */
+#define MIRA_TUNE_REDUCE_PIECES 12
+#define MIRA_TUNE_REDUCE_LAMBDA 13
+#define MIRA_TUNE_REDUCE_QUAD 14
+/* smallest commit served from a key's shared-bucket table sets (default 2^12); MIRA_TUNE_TABLE_MIN_N is the wide tables' */
+#define MIRA_TUNE_SHARED_MIN_N 15
 int mira_set_tuning(int knob, int64_t value);
 
 /* Read a range of the registered key back in the reference layout (cache file writing,

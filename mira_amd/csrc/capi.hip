@@ -290,10 +290,17 @@ static MsmPlan make_plan(size_t n, int32_t forced_c, uint32_t count = 1, uint64_
     p.lanes = 256u * 4u * 3u * 64u;
     p.L = (uint32_t)tuned(MIRA_TUNE_MIN_SEGMENT, 10);   // minimum segment length: more, shorter segments keep the lanes of a small commit busy (16 -> 10: 2^15 pairs 0.40 -> 0.35 ms), below 10 the cut runs cost the fix-up more than the additions gain (tools/min_segment_probe.py)
     p.T = (uint32_t)std::min<uint64_t>(p.lanes, ceil_div(entries, p.L));   // upper bound of segments
-    // reduction chunk: the chain is 2m running-sum adds, then ceil(B/m/512) + 9 in k_window_sum
-    p.m = std::min<uint32_t>(p.B, p.B <= 4096 ? 4 : 8);    // measured (tools/window_probe.py): 4 / 8 beat 16 and 32 at every size
-    p.nchunks = p.B / p.m;
+    plan_reduction(p, 1);                                    // callers that can take several pieces per window ask again
     return p;
+}
+// Pieces per bucket set for a commit whose points the library's own epilogue combines (capi.hip: horner_pieces): the device's
+// Horner chain over the bits of a bucket index is cut into P parts and the host's chain of doublings, which passes every bit
+// position anyway, adds P points per window instead of one (0.25 us each).
+static uint32_t default_pieces(const MsmPlan &p, uint32_t max_points) {
+    uint32_t P = (uint32_t)tuned(MIRA_TUNE_REDUCE_PIECES, 3);
+    const uint32_t sets_per_result = p.shared ? 1u : p.W;
+    while (P > 1 && sets_per_result * P > max_points) P--;
+    return std::max(1u, P);
 }
 
 // Shared-bucket fixed-base tables (mira_msm_precompute_ex(handle, c), c = 8 .. 16): W = ceil(256 / c) signed c-bit
@@ -301,16 +308,11 @@ static MsmPlan make_plan(size_t n, int32_t forced_c, uint32_t count = 1, uint64_
 // sums back (no chain of doublings on the host).  A commit then pays ceil(256 / c) additions per pair and the
 // fix-up / bucket reduction of ONE window of 2^(c-1) buckets: narrow widths for the small commits of a fold
 // step (few buckets: a short tail), 16 bits for the large ones (fewest additions).
-static constexpr uint32_t SHARED_SUMS = 16;
 static MsmPlan make_plan_shared(size_t n, const Bases::SharedSet &set, uint64_t table_n, uint32_t count = 1, uint64_t stride = 0) {
     MsmPlan p = make_plan(n, (int32_t)set.c, count, stride);
     p.shared = true; p.shared_tables = set.p; p.table_n = table_n;
     p.NB = count * p.B;                                      // one bucket set per MSM
-    // the chain of the reduction is what counts here: chunks of four buckets, by quads of lanes -- of eight where four would
-    // leave more chunks than quads fit (a batch of 16-bit sets: 6 x 8192 chunks by single lanes took 0.19 ms, 6 x 4096 by quads 0.1x)
-    p.m = (uint64_t)count * p.B / 4 > 24576 ? 8 : 4;
-    p.nchunks = p.B / p.m;
-    p.sums = std::min<uint32_t>(SHARED_SUMS, p.nchunks);
+    plan_reduction(p, 1);
     return p;
 }
 // Which of a key's shared-bucket sets serves a commit of n pairs (count of them in one submission).  Measured
@@ -446,17 +448,25 @@ static void host_parallel_for(size_t count, const std::function<void(size_t)> &f
 #endif
 }
 
-// Horner over the window sums: sum_w 2^(c w) * Wsum[w], then to_affine.
+// The epilogue of a commit: sum_(w < W) sum_(p < P) 2^(c w + piece_start(cb, P, p)) pts[w P + p] by ONE chain of doublings from the
+// highest bit position down (Horner), then to_affine.  P = 1 is the plain sum over window sums; c = 0, P = 1 a plain sum of
+// partial sums (wide tables).
 template <class FB>
-static void horner_affine(const uint64_t *windows, uint32_t c, uint32_t W, uint64_t out[8]) {
+static void horner_pieces(const uint64_t *pts, const PartialShape &sh, uint64_t out[8]) {
     using namespace hostf;
     HXyzz<FB> acc = identity<FB>();
-    for (int w = (int)W - 1; w >= 0; w--) {
-        for (uint32_t k = 0; k < c; k++) acc = dbl_pt(acc);
-        HXyzz<FB> t;
-        memcpy(&t, windows + (size_t)w * 16, 128);
-        acc = add_pt(acc, t);
-    }
+    uint32_t at = 0;                                         // bit position the accumulator currently stands at
+    bool first = true;
+    for (int w = (int)sh.W - 1; w >= 0; w--)
+        for (int p = (int)sh.P - 1; p >= 0; p--) {
+            const uint32_t pos = sh.c * (uint32_t)w + piece_start(sh.cb, sh.P, (uint32_t)p);
+            if (!first) for (uint32_t k = pos; k < at; k++) acc = dbl_pt(acc);
+            HXyzz<FB> t;
+            memcpy(&t, pts + ((size_t)w * sh.P + (size_t)p) * 16, 128);
+            acc = add_pt(acc, t);
+            at = pos; first = false;
+        }
+    for (uint32_t k = 0; k < at; k++) acc = dbl_pt(acc);     // (the lowest piece of window 0 stands at bit 0: nothing to do)
     to_affine(acc, out);
 }
 template <class FB>
@@ -476,8 +486,10 @@ static void sum_partials(const uint64_t *partials, size_t nparts, uint32_t W, ui
 // sharded: the caller is one rank of a point-chunk sharded MSM.  All ranks must produce the same
 // kind of partial, so the choice between table and per-window mode then depends only on whether
 // the handle has tables (and on the forced width), never on this rank's chunk length.
+// allow_pieces: the caller combines the points itself with horner_pieces (a commit of this process); else the public partial
+// format, one point per window (*shape then has P = 1).
 static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scalars, size_t n, uint64_t *out_partial,
-                              uint32_t *c_out, uint32_t *W_out, bool sharded = false, int32_t requested_c = 0, const void *h_scalars = nullptr) {
+                              PartialShape *shape, bool sharded = false, int32_t requested_c = 0, const void *h_scalars = nullptr, bool allow_pieces = false) {
     int rc = ensure_ctx();
     if (rc) return rc;
     auto it = g_bases.find(handle);
@@ -502,7 +514,7 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
     const size_t hist_min_n = tuned(MIRA_TUNE_PLAN_HIST_MIN_N, PLAN_HIST_MIN_N);
     const bool can_hist = !table_mode && !sharded && forced_c == 0 && requested_c == 0 && n >= hist_min_n && d_scalars;
     const uint32_t *stat = (can_hist && bs.stat_n == n) ? bs.stat_hist : nullptr;
-    const Bases::SharedSet *set = (tables_ok && !table_mode && (sharded || n >= tuned(MIRA_TUNE_TABLE_MIN_N, TABLE16_MIN_N))) ? pick_shared(bs, n, 1, sharded, stat) : nullptr;
+    const Bases::SharedSet *set = (tables_ok && !table_mode && (sharded || n >= tuned(MIRA_TUNE_SHARED_MIN_N, TABLE16_MIN_N))) ? pick_shared(bs, n, 1, sharded, stat) : nullptr;
     const bool use_hist = can_hist && !set;
     // a rank of a sharded MSM that was not given a width takes 16, whatever its chunk length: partials
     // of different widths cannot be combined, and chunk lengths differ between ranks
@@ -514,7 +526,8 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
     p.glv = glv; p.glv_bases = glv ? bs.glv : nullptr;
     if (n >= (1ull << 31) || (uint64_t)n * (glv ? 2 : 1) * p.W >= (1ull << 32)) { set_error("n too large for 32-bit entry offsets"); return MIRA_E_UNSUPPORTED; }
     if (p.W > MIRA_MAX_WINDOWS) { set_error("window configuration exceeds MIRA_MAX_WINDOWS"); return MIRA_E_UNSUPPORTED; }
-    *c_out = p.c; *W_out = p.W;
+    if (allow_pieces && !g.windows_dst) plan_reduction(p, default_pieces(p, MIRA_MAX_WINDOWS));
+    *shape = PartialShape{p.c, p.W, p.cb, p.pieces};
     g.last_c = (int32_t)p.c; g.last_w = (int32_t)p.W; g.last_table_c = 0;
     memset(out_partial, 0, MIRA_PARTIAL_U64 * 8);
     if (n == 0) return MIRA_OK;
@@ -523,8 +536,9 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
     if (set) {                                               // shared buckets through the per-window launch sequence
         MsmPlan ps = make_plan_shared(n, *set, bs.n);
         if ((uint64_t)n * ps.W >= (1ull << 32)) { set_error("n too large for 32-bit entry offsets"); return MIRA_E_UNSUPPORTED; }
-        *c_out = 0; *W_out = ps.sums;                       // partial sums, combined by a plain sum
-        g.last_c = 0; g.last_w = (int32_t)ps.sums; g.last_table_c = (int32_t)set->c;
+        if (allow_pieces && !g.windows_dst) plan_reduction(ps, default_pieces(ps, MIRA_MAX_WINDOWS));
+        *shape = PartialShape{0, 1, ps.cb, ps.pieces};       // the pieces of ONE bucket set (P = 1: its sum)
+        g.last_c = 0; g.last_w = (int32_t)ps.pieces; g.last_table_c = (int32_t)set->c;
         ps.stats = can_hist;
         rc = bs.curve == MIRA_CURVE_BN256 ? msm_launch_bn256(bs, first, d_scalars, h_scalars, n, ps, out_partial)
                                           : msm_launch_grumpkin(bs, first, d_scalars, h_scalars, n, ps, out_partial);
@@ -536,7 +550,7 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
     }
     if (table_mode) {
         if (h_scalars) RT_CHECK(rt_h2d(const_cast<void *>(d_scalars), h_scalars, n * 32, g.stream));
-        *c_out = 0; *W_out = 64;                            // 64 partial sums, combined by a plain sum
+        *shape = PartialShape{0, 64, 0, 1};                 // 64 partial sums, combined by a plain sum
         g.last_c = 0; g.last_w = 64; g.last_table_c = (int32_t)bs.table_c;
         return bs.curve == MIRA_CURVE_BN256 ? msm_launch_table_bn256(bs, first, d_scalars, n, out_partial)
                                              : msm_launch_table_grumpkin(bs, first, d_scalars, n, out_partial);
@@ -554,8 +568,9 @@ static int combine_locked(int curve, const uint64_t *partials, size_t nparts, ui
     if (curve != MIRA_CURVE_BN256 && curve != MIRA_CURVE_GRUMPKIN) { set_error("unknown curve"); return MIRA_E_BAD_ARG; }
     if (!partials || !out || nparts == 0 || c > 16 || W < 1 || W > MIRA_MAX_WINDOWS) { set_error("bad combine arguments"); return MIRA_E_BAD_ARG; }
     std::vector<uint64_t> win((size_t)W * 16);
-    if (curve == MIRA_CURVE_BN256) { sum_partials<FqP>(partials, nparts, W, win.data()); horner_affine<FqP>(win.data(), c, W, out); }
-    else { sum_partials<FrP>(partials, nparts, W, win.data()); horner_affine<FrP>(win.data(), c, W, out); }
+    const PartialShape sh{c, W, c ? c - 1 : 0, 1};
+    if (curve == MIRA_CURVE_BN256) { sum_partials<FqP>(partials, nparts, W, win.data()); horner_pieces<FqP>(win.data(), sh, out); }
+    else { sum_partials<FrP>(partials, nparts, W, win.data()); horner_pieces<FrP>(win.data(), sh, out); }
     return MIRA_OK;
 }
 
@@ -579,7 +594,7 @@ static int msm_batch_device_locked(uint64_t handle, const void *d_scalars, size_
     // (ceil(256 / c) additions per pair, 2^(c-1) buckets per commitment instead of W 2^(c-1)),
     // and its partial sums come back to be added -- no chain of doublings
     const int32_t forced_c = bs.forced_c ? bs.forced_c : g.forced_c;
-    const Bases::SharedSet *set = (forced_c == 0 && n >= tuned(MIRA_TUNE_TABLE_MIN_N, TABLE16_MIN_N)) ? pick_shared(bs, n, (uint32_t)std::min<size_t>(count, 64), false) : nullptr;
+    const Bases::SharedSet *set = (forced_c == 0 && n >= tuned(MIRA_TUNE_SHARED_MIN_N, TABLE16_MIN_N)) ? pick_shared(bs, n, (uint32_t)std::min<size_t>(count, 64), false) : nullptr;
     if (set) {
         const uint32_t Ws = (256 + set->c - 1) / set->c;
         const size_t per = std::max<size_t>(1, std::min<size_t>(64, (size_t)(((1ull << 32) - 1) / ((uint64_t)n * Ws))));
@@ -587,15 +602,17 @@ static int msm_batch_device_locked(uint64_t handle, const void *d_scalars, size_
         for (size_t done = 0; done < count; done += per) {
             const size_t cnt = std::min(per, count - done);
             MsmPlan p = make_plan_shared(n, *set, bs.n, (uint32_t)cnt, stride);
-            g.last_c = 0; g.last_w = (int32_t)p.sums; g.last_table_c = (int32_t)set->c;
-            sums.assign(cnt * p.sums * 16, 0);
+            plan_reduction(p, default_pieces(p, MIRA_MAX_WINDOWS));
+            g.last_c = 0; g.last_w = (int32_t)p.pieces; g.last_table_c = (int32_t)set->c;
+            sums.assign(cnt * p.pieces * 16, 0);
             const unsigned char *sc = reinterpret_cast<const unsigned char *>(d_scalars) + done * stride * 32;
             rc = bs.curve == MIRA_CURVE_BN256 ? msm_launch_bn256(bs, 0, sc, nullptr, n, p, sums.data()) : msm_launch_grumpkin(bs, 0, sc, nullptr, n, p, sums.data());
             if (rc) return rc;
+            const PartialShape sh{0, 1, p.cb, p.pieces};
             for (size_t b = 0; b < cnt; b++) {
-                const uint64_t *w = sums.data() + b * p.sums * 16;
-                if (bs.curve == MIRA_CURVE_BN256) horner_affine<FqP>(w, 0, p.sums, out_affine + (done + b) * 8);
-                else horner_affine<FrP>(w, 0, p.sums, out_affine + (done + b) * 8);
+                const uint64_t *w = sums.data() + b * p.pieces * 16;
+                if (bs.curve == MIRA_CURVE_BN256) horner_pieces<FqP>(w, sh, out_affine + (done + b) * 8);
+                else horner_pieces<FrP>(w, sh, out_affine + (done + b) * 8);
             }
         }
         return MIRA_OK;
@@ -613,16 +630,18 @@ static int msm_batch_device_locked(uint64_t handle, const void *d_scalars, size_
         const size_t cnt = std::min(per, count - done);
         MsmPlan p = make_plan(nv, forced_c, (uint32_t)cnt, stride, nullptr, bits);
         p.glv = glv; p.glv_bases = glv ? bs.glv : nullptr;
+        plan_reduction(p, default_pieces(p, 1u << 20));
         g.last_c = (int32_t)p.c; g.last_w = (int32_t)p.W; g.last_table_c = 0;
-        win.assign((size_t)p.Wt * 16, 0);
+        win.assign((size_t)p.Wt * p.pieces * 16, 0);
         const unsigned char *sc = reinterpret_cast<const unsigned char *>(d_scalars) + done * stride * 32;
         rc = bs.curve == MIRA_CURVE_BN256 ? msm_launch_bn256(bs, 0, sc, nullptr, n, p, win.data()) : msm_launch_grumpkin(bs, 0, sc, nullptr, n, p, win.data());
         if (rc) return rc;
         // the epilogues of a batch are independent chains of ~250 doublings (60 us each): one host thread per commitment
+        const PartialShape sh{p.c, p.W, p.cb, p.pieces};
         auto epilogue = [&](size_t b) {
-            const uint64_t *w = win.data() + b * p.W * 16;
-            if (bs.curve == MIRA_CURVE_BN256) horner_affine<FqP>(w, p.c, p.W, out_affine + (done + b) * 8);
-            else horner_affine<FrP>(w, p.c, p.W, out_affine + (done + b) * 8);
+            const uint64_t *w = win.data() + b * p.W * p.pieces * 16;
+            if (bs.curve == MIRA_CURVE_BN256) horner_pieces<FqP>(w, sh, out_affine + (done + b) * 8);
+            else horner_pieces<FrP>(w, sh, out_affine + (done + b) * 8);
         };
         host_parallel_for(cnt, epilogue);
     }
@@ -904,10 +923,12 @@ int mira_msm_check_bases(uint64_t handle) {
 static int msm_device_locked(uint64_t handle, const void *d_scalars, size_t n, uint64_t out_affine[8], const void *h_scalars = nullptr) {
     if (!out_affine) { set_error("null output"); return MIRA_E_BAD_ARG; }
     uint64_t part[MIRA_PARTIAL_U64];
-    uint32_t c, W;
-    int rc = msm_partial_locked(handle, 0, d_scalars, n, part, &c, &W, false, 0, h_scalars);
+    PartialShape sh;
+    int rc = msm_partial_locked(handle, 0, d_scalars, n, part, &sh, false, 0, h_scalars, true);
     if (rc) return rc;
-    return combine_locked(g_bases[handle].curve, part, 1, c, W, out_affine);
+    if (g_bases[handle].curve == MIRA_CURVE_BN256) horner_pieces<FqP>(part, sh, out_affine);
+    else horner_pieces<FrP>(part, sh, out_affine);
+    return MIRA_OK;
 }
 int mira_msm_device(uint64_t handle, const void *d_scalars, size_t n, uint64_t out_affine[8]) {
     std::lock_guard<std::mutex> lk(g_lock);
@@ -957,10 +978,10 @@ int mira_msm_partial_device(uint64_t handle, size_t first, const void *d_scalars
     std::lock_guard<std::mutex> lk(g_lock);
     if (!out_partial || !window_bits || !num_windows) { set_error("null output"); return MIRA_E_BAD_ARG; }
     if (*window_bits != 0 && (*window_bits < 4 || *window_bits > 16)) { set_error("window_bits must be 0 or 4..16"); return MIRA_E_BAD_ARG; }
-    uint32_t c, W;
-    int rc = msm_partial_locked(handle, first, d_scalars, n, out_partial, &c, &W, true, *window_bits);
+    PartialShape sh;
+    int rc = msm_partial_locked(handle, first, d_scalars, n, out_partial, &sh, true, *window_bits);
     if (rc) return rc;
-    *window_bits = (int32_t)c; *num_windows = (int32_t)W;
+    *window_bits = (int32_t)sh.c; *num_windows = (int32_t)sh.W;
     return MIRA_OK;
 }
 int mira_msm_combine(int curve, const uint64_t *partials, size_t nparts, int32_t window_bits, int32_t num_windows, uint64_t out_affine[8]) {
@@ -968,11 +989,12 @@ int mira_msm_combine(int curve, const uint64_t *partials, size_t nparts, int32_t
 }
 int mira_set_tuning(int knob, int64_t value) {
     std::lock_guard<std::mutex> lk(g_lock);
-    if (knob < 0 || knob > MIRA_TUNE_GLV) { set_error("unknown tuning knob"); return MIRA_E_BAD_ARG; }
+    if (knob < 0 || knob > MIRA_TUNE_SHARED_MIN_N) { set_error("unknown tuning knob"); return MIRA_E_BAD_ARG; }
     g.tune[knob] = value;
     return MIRA_OK;
 }
 int mira_msm_plan_window_bits(size_t n, int32_t *window_bits) {
+    std::lock_guard<std::mutex> lk(g_lock);                  // make_plan reads the tuning knobs mira_set_tuning writes under this lock
     if (!window_bits) { set_error("null output"); return MIRA_E_BAD_ARG; }
     *window_bits = (int32_t)make_plan(std::max<size_t>(n, 1), 0).c;
     return MIRA_OK;
@@ -1014,12 +1036,12 @@ int mira_msm_partial_to_device(uint64_t handle, size_t first, const void *d_scal
     RT_CHECK(rt_memset(d_out_partial, 0, MIRA_PARTIAL_U64 * 8, g.stream));     // words beyond the partial's windows (and an empty chunk) read as the identity
     RT_CHECK(rt_sync(g.stream));
     uint64_t unused[MIRA_PARTIAL_U64];
-    uint32_t c, W;
+    PartialShape sh;
     g.windows_dst = d_out_partial;
-    rc = msm_partial_locked(handle, first, d_scalars, n, unused, &c, &W, true, *window_bits);
+    rc = msm_partial_locked(handle, first, d_scalars, n, unused, &sh, true, *window_bits);
     g.windows_dst = nullptr;
     if (rc) return rc;
-    *window_bits = (int32_t)c; *num_windows = (int32_t)W;
+    *window_bits = (int32_t)sh.c; *num_windows = (int32_t)sh.W;
     return MIRA_OK;
 }
 

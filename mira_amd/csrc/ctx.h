@@ -92,7 +92,7 @@ struct Ctx {
     hipStream_t copy_stream = nullptr;   // host scalars travel here, chunk by chunk, beside the kernels of earlier chunks
     std::vector<hipEvent_t> copy_events;
     int32_t forced_c = 0;
-    int64_t tune[16] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};   // mira_set_tuning overrides, < 0 = default
+    int64_t tune[24] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};   // mira_set_tuning overrides, < 0 = default
     Timing tm;
     // MSM workspace (grow-only, shared by all handles: calls are serialised by the ABI lock)
     DevBuf digits, counts, offsets, cursor, block_sums, sorted_idx, bucket_sums, part, coarse_offsets, fine_counts, fine_cursor;
@@ -159,7 +159,40 @@ struct MsmPlan {
     bool glv = false;
     const void *glv_bases = nullptr;
     bool stats = false;   // also histogram the bit lengths of the scalars (planning input of the next commit of this shape)
+    // bucket reduction (reduce_kernels.cuh, plan_reduction below): nsets bucket sets of 2^cb buckets each, chunks of 2^lambda
+    // buckets, 2^kappa chunks per workgroup, 2^gamma workgroup nodes per set, `pieces` results per set; rquad: phase A by quads
+    uint32_t nsets = 0, cb = 0, lambda = 0, kappa = 0, gamma = 0, pieces = 1;
+    bool rquad = false;
 };
+
+// first bit position of piece p of P over the cb bits of a bucket index (p = P: cb)
+static inline uint32_t piece_start(uint32_t cb, uint32_t P, uint32_t p) { return (uint32_t)(((uint64_t)p * cb + P - 1) / P); }
+// What a launch sequence hands back: W * P points whose weighted sum is the commitment,
+//     sum_(w < W) sum_(p < P) 2^(c w + piece_start(cb, P, p)) point[w P + p]
+// per-window buckets: c = window width, cb = c - 1; a shared-bucket table set: c = 0, W = 1, cb = its width - 1;
+// wide tables: c = 0, W = 64 plain partial sums, P = 1.  The public partial format (mira_msm_partial_*) is P = 1.
+struct PartialShape { uint32_t c = 0, W = 0, cb = 0, P = 1; };
+
+// Shape of the bucket reduction of a plan.  Quads for phase A while the chunks are few (the chain of dependent additions is
+// what takes the time: chunks of four buckets), single lanes in chunks of eight once they fill the SIMDs.
+static inline void plan_reduction(MsmPlan &p, uint32_t want_pieces) {
+    p.nsets = p.shared ? p.count : p.Wt;
+    p.cb = p.c - 1;
+    const uint64_t chunks_q = (uint64_t)p.nsets << (p.cb - std::min<uint32_t>(2, p.cb));
+    p.rquad = g.tune[MIRA_TUNE_REDUCE_QUAD] >= 0 ? g.tune[MIRA_TUNE_REDUCE_QUAD] != 0 : chunks_q * 4 <= 98304;
+    p.lambda = std::min<uint32_t>(p.rquad ? 2 : 3, p.cb);
+    if (g.tune[MIRA_TUNE_REDUCE_LAMBDA] >= 1) p.lambda = std::min<uint32_t>((uint32_t)g.tune[MIRA_TUNE_REDUCE_LAMBDA], p.cb);
+    const uint32_t eta = p.cb - p.lambda;
+#ifdef MIRA_CPU_EMU
+    p.kappa = std::min<uint32_t>(eta, 3);                                      // emulated lanes are OS threads: small workgroups, a taller second tree
+#else
+    p.kappa = std::min<uint32_t>(eta, p.rquad ? (eta > 12 ? 7 : 6) : 8);      // 64 (128) quads or 256 lanes per workgroup
+#endif
+    p.gamma = eta - p.kappa;
+    p.pieces = std::max<uint32_t>(1, std::min<uint32_t>(std::min<uint32_t>(want_pieces, 8), std::max<uint32_t>(1, p.cb / 2)));
+    p.m = 1u << p.lambda;
+    p.nchunks = p.B >> p.lambda;
+}
 
 // per-curve translation units (msm_bn256.hip / msm_grumpkin.hip)
 // h_scalars != null: the scalars are still in host memory; d_scalars is then the device staging buffer they are copied to

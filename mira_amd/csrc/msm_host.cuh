@@ -5,6 +5,7 @@
 #include "msm_kernels.cuh"
 #include "table_kernels.cuh"
 #include "sort_kernels.cuh"
+#include "reduce_kernels.cuh"
 #include "host_field.hpp"
 #include <cerrno>
 #include <thread>
@@ -20,6 +21,11 @@ static constexpr uint32_t FIXUP_HEAVY_GRID = 1024;   // waves of either heavy st
 // chain of dependent additions is what takes the time there); single lanes beyond (throughput)
 static constexpr uint32_t SCAN_SOLO_TILES = 2;      // up to 4096 bucket counters: k_scan_c<true> (measured: 14 -> 7 us for one tile, 15 -> 13 for two, 16 -> 30 for seven)
 static inline bool reduce_with_quads(uint64_t work_items) { return work_items * 4 <= 98304; }
+#ifdef MIRA_CPU_EMU
+static constexpr uint32_t SET_FINISH_BLOCK = 32;      // emulated lanes are OS threads
+#else
+static constexpr uint32_t SET_FINISH_BLOCK = 256;
+#endif
 
 // Host scalars (commit(&self, v: &[C::Scalar]) hands over host memory, src/commitment.rs:78) are
 // cut into point chunks: chunk k + 1 crosses PCIe on the copy stream while the kernels of chunk k
@@ -93,8 +99,9 @@ static int msm_launch_body(const Bases &bs, size_t first, const void *d_scalars,
     if ((rc = g.tail_key.ensure((size_t)p.T * 4))) return rc;
     if ((rc = g.heavy.ensure(64 + ((size_t)p.T / 2 + 8) * 32))) return rc;            // counters, runs, sub-job descriptors
     if ((rc = g.heavy_out.ensure(((size_t)p.T / 2 + 8) * XYZZ29_BYTES))) return rc;
-    if ((rc = g.chunks.ensure((size_t)(p.shared ? p.count : p.Wt) * p.nchunks * XYZZ29_BYTES))) return rc;
-    if ((rc = g.window_sums.ensure((size_t)std::max(p.Wt * 4, p.count * p.sums) * 128 + 1024))) return rc;   // (up to four partial sums per window) + the planning statistics
+    const size_t node_points = ((size_t)p.nsets << p.gamma) * (p.kappa + 2);               // one node of kappa + 2 points per workgroup of k_bucket_tree
+    if ((rc = g.chunks.ensure(node_points * XYZZ29_BYTES))) return rc;
+    if ((rc = g.window_sums.ensure((size_t)p.nsets * p.pieces * 128 + 1024))) return rc;   // pieces + the planning statistics
 #ifndef MIRA_CPU_EMU
     if (h_scalars) {
         if (!g.copy_stream) RT_CHECK(hipStreamCreateWithFlags(&g.copy_stream, hipStreamNonBlocking));
@@ -215,37 +222,29 @@ static int msm_launch_body(const Bases &bs, size_t first, const void *d_scalars,
                        reinterpret_cast<unsigned char *>(g.bucket_sums.p));
         tm_mark("fixup");
     }
-    // bucket sets: one per window, or one per MSM (shared: the chunk results of a set are summed by `sums` workgroups)
-    const uint64_t items = (uint64_t)(p.shared ? p.count : p.Wt) * p.nchunks;
-    // A single large per-window commit (2^22 pairs under 16-bit windows: 16 windows of 4096 chunk results) gives k_window_sum one
-    // workgroup per window -- 16 lone workgroups, 8 + 9 dependent additions each, 0.17 ms.  Four workgroups per window take a
-    // quarter of the chunks each and the host adds the four partial sums of every window (48 additions, 10 us) before its Horner
-    // chain.  Not for batches (hundreds of windows already; the host additions would cost more than the kernel) nor where the
-    // sums stay on the device.
-    const uint32_t split = (!p.shared && p.count == 1 && !g.windows_dst && !reduce_with_quads(items) && p.nchunks >= 2048 && p.Wt <= 16) ? 4u : 1u;
-    const uint32_t Wb = p.shared ? p.count : p.Wt, nsum = p.shared ? p.count * p.sums : p.Wt * split, per_sum = p.shared ? p.nchunks / p.sums : p.nchunks / split;
-    if (reduce_with_quads(items)) {
-        LAUNCH((k_reduce_chunks<F, true>), ceil_div(items * 4, 64), 64, 0, st, reinterpret_cast<const unsigned char *>(g.bucket_sums.p),
-               p.B, p.m, Wb, reinterpret_cast<unsigned char *>(g.chunks.p));
-        tm_mark("reduce_chunks");
-        LAUNCH_BARRIER((k_window_sum<F, true>), nsum, WSUM_BLOCK, (size_t)(WSUM_BLOCK / 4) * XYZZ29_BYTES, st, reinterpret_cast<const unsigned char *>(g.chunks.p), per_sum,
-                       reinterpret_cast<unsigned char *>(g.window_sums.p), (const uint32_t *)hist);
-    } else {
-        // 256-lane workgroups: with 64-lane ones the dispatcher was seen to pack the 1024 waves of a 2^22
-        // MSM onto part of the CUs (0.43 ms instead of 0.27)
-        LAUNCH((k_reduce_chunks<F, false>), ceil_div(items, 256), 256, 0, st, reinterpret_cast<const unsigned char *>(g.bucket_sums.p),
-               p.B, p.m, Wb, reinterpret_cast<unsigned char *>(g.chunks.p));
-        tm_mark("reduce_chunks");
-        LAUNCH_BARRIER((k_window_sum<F, false>), nsum, WSUM_BLOCK, (size_t)WSUM_BLOCK * XYZZ29_BYTES, st, reinterpret_cast<const unsigned char *>(g.chunks.p), per_sum,
-                       reinterpret_cast<unsigned char *>(g.window_sums.p), (const uint32_t *)hist);
-    }
+    // bucket reduction (reduce_kernels.cuh): running sums over chunks of 2^lambda buckets and the first kappa levels of the
+    // tree over the chunks in one launch, the remaining gamma levels and the pieces of every set in a second
+    PieceCfg pc;
+    pc.P = p.pieces;
+    for (uint32_t i = 0; i <= 8; i++) pc.start[i] = piece_start(p.cb, p.pieces, std::min(i, p.pieces));
+    const uint32_t tree_groups = p.nsets << p.gamma, npts = p.nsets * p.pieces;
+    const size_t lds_a = ((size_t)2 << p.kappa) * XYZZ29_BYTES, lds_b = ((size_t)(p.kappa + 2) << p.gamma) * XYZZ29_BYTES;
+    if (p.rquad)
+        LAUNCH_BARRIER((k_bucket_tree<F, true>), tree_groups, std::max(4u, 4u << p.kappa), lds_a, st, reinterpret_cast<const unsigned char *>(g.bucket_sums.p),
+                       p.lambda, p.kappa, reinterpret_cast<unsigned char *>(g.chunks.p));
+    else
+        LAUNCH_BARRIER((k_bucket_tree<F, false>), tree_groups, std::max(4u, 1u << p.kappa), lds_a, st, reinterpret_cast<const unsigned char *>(g.bucket_sums.p),
+                       p.lambda, p.kappa, reinterpret_cast<unsigned char *>(g.chunks.p));
+    tm_mark("reduce_chunks");
+    LAUNCH_BARRIER(k_set_finish<F>, p.nsets, SET_FINISH_BLOCK, lds_b, st, reinterpret_cast<const unsigned char *>(g.chunks.p), p.kappa + 2, p.gamma, p.lambda, pc,
+                   reinterpret_cast<unsigned char *>(g.window_sums.p), (const uint32_t *)hist);
     tm_mark("window_sum");
     RT_CHECK(rt_last());
     if (g.windows_dst) {                                     // mira_msm_partial_to_device: the sums stay in device memory
-        RT_CHECK(rt_d2d(g.windows_dst, g.window_sums.p, (size_t)nsum * 128, st));
+        RT_CHECK(rt_d2d(g.windows_dst, g.window_sums.p, (size_t)npts * 128, st));
         RT_CHECK(rt_sync(st));
-    } else {                                                 // sums (and statistics) in one copy, through pinned memory
-        const size_t bytes = (size_t)nsum * 128 + (p.stats ? 1024 : 0);
+    } else {                                                 // pieces (and statistics) in one copy, through pinned memory
+        const size_t bytes = (size_t)npts * 128 + (p.stats ? 1024 : 0);
         if (g.out_host_cap < bytes) {
             if (g.out_host) (void)rt_host_free(g.out_host);
             g.out_host = nullptr; g.out_host_cap = 0;
@@ -254,20 +253,8 @@ static int msm_launch_body(const Bases &bs, size_t first, const void *d_scalars,
         }
         RT_CHECK(rt_d2h(g.out_host, g.window_sums.p, bytes, st));
         RT_CHECK(rt_sync(st));
-        if (split == 1) memcpy(host_windows, g.out_host, (size_t)nsum * 128);
-        else {
-            using FB = typename F::Sat;
-            for (uint32_t w = 0; w < p.Wt; w++) {
-                hostf::HXyzz<FB> acc = hostf::identity<FB>();
-                for (uint32_t k = 0; k < split; k++) {
-                    hostf::HXyzz<FB> t;
-                    memcpy(&t, g.out_host + ((size_t)w * split + k) * 128, 128);
-                    acc = hostf::add_pt(acc, t);
-                }
-                memcpy(host_windows + (size_t)w * 16, &acc, 128);
-            }
-        }
-        if (p.stats) memcpy(g.hist_host, g.out_host + (size_t)nsum * 128, 1024);
+        memcpy(host_windows, g.out_host, (size_t)npts * 128);
+        if (p.stats) memcpy(g.hist_host, g.out_host + (size_t)npts * 128, 1024);
     }
     tm_end();
     return MIRA_OK;
@@ -277,6 +264,9 @@ static int msm_launch_body(const Bases &bs, size_t first, const void *d_scalars,
 template <class F, class FS> static int curve_init() {
 #ifndef MIRA_CPU_EMU
     RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_sum<F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bucket_tree<F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bucket_tree<F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_set_finish<F>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     // the LDS-staged histogram needs more than the 64 KiB default (128 KiB at c = 16)
     RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -74,6 +74,44 @@ def test_emu_msm_skewed_and_forced_window(emu_lib, c):
         emu_lib.check(emu_lib.c.mira_msm_set_window_bits(0))
 
 
+@pytest.mark.parametrize("cid", [0, 1])
+def test_emu_bucket_reduction_shapes(emu_lib, tune, cid):
+    """reduce_kernels.cuh: the weighted bucket sum as running sums over chunks + a tree whose nodes carry the per-bit sums,
+    delivered in P pieces to the host's chain of doublings.  Every shape gives the oracle's point: pieces 1 .. 4, chunks of
+    2 / 4 / 8 buckets, phase A by quads and by single lanes, widths whose trees have zero, one and several levels in the
+    second kernel; single commits, a batch and a shared-bucket table set."""
+    n = 220
+    bs, sc = C.synth_bases(cid, n, seed=61), C.synth_scalars(cid, n, seed=62)
+    sc[3] = 0
+    sc[5] = sc[6]
+    bs[9] = bs[8]
+    key = cm.CommitmentKey(cid, bs, lib=emu_lib)
+    want = C.msm_pippenger(cid, sc, bs)
+    d = emu_lib.alloc(2 * n * 32)
+    emu_lib.upload(d, sc); emu_lib.upload(d + n * 32, sc[::-1].copy())
+    want_b = np.stack([want, C.msm_pippenger(cid, sc[::-1].copy(), bs)])
+    try:
+        for c, shapes in ((4, [(1, 1, 1), (2, 2, 0)]), (7, [(1, 2, 1), (3, 1, 0), (2, 3, 1)]), (10, [(4, 2, 1), (1, 3, 0), (3, 2, 0)])):
+            emu_lib.check(emu_lib.c.mira_msm_set_window_bits(c))
+            for pieces, lam, quad in shapes:
+                tune(_lib.TUNE_REDUCE_PIECES, pieces); tune(_lib.TUNE_REDUCE_LAMBDA, lam); tune(_lib.TUNE_REDUCE_QUAD, quad)
+                assert (key.commit_device(d, n) == want).all(), (c, pieces, lam, quad)
+                assert (key.commit(sc) == want).all()
+            assert (key.commit_batch_device(d, n, 2) == want_b).all()
+            part, cc, ww = key.commit_partial_device(0, d, n)                  # the public partial format: one point per window
+            assert (cc, ww) == (c, -(-256 // c))
+            assert (cm.combine_partials(cid, part[None, :], cc, ww, lib=emu_lib) == want).all()
+    finally:
+        emu_lib.check(emu_lib.c.mira_msm_set_window_bits(0))
+    tune(_lib.TUNE_SHARED_MIN_N, 1)
+    key.precompute(9)
+    for pieces, lam, quad in ((1, 2, 1), (3, 3, 0), (4, 1, 1)):
+        tune(_lib.TUNE_REDUCE_PIECES, pieces); tune(_lib.TUNE_REDUCE_LAMBDA, lam); tune(_lib.TUNE_REDUCE_QUAD, quad)
+        assert (key.commit_device(d, n) == want).all(), (pieces, lam, quad)
+    assert (key.commit_batch_device(d, n, 2) == want_b).all()
+    emu_lib.free(d)
+
+
 def test_emu_partial_and_combine(emu_lib):
     cid, n = 1, 600
     bs, sc = C.synth_bases(cid, n, seed=2), C.synth_scalars(cid, n, seed=3)
@@ -222,6 +260,7 @@ def test_emu_shared_bucket_tables_16bit(emu_lib, tune):
     oracle; identity base, heavy bucket, chunk partials, a batch.  (2^15 emulated buckets are slow: the staged sort, host
     scalars in chunks and prefixes of the shared-bucket path run at narrower widths in the next test.)"""
     tune(_lib.TUNE_TABLE_MIN_N, 1)
+    tune(_lib.TUNE_SHARED_MIN_N, 1)
     cid, n = 0, 300
     bs = C.synth_bases(cid, n, seed=44)
     bs[11] = 0
@@ -235,7 +274,7 @@ def test_emu_shared_bucket_tables_16bit(emu_lib, tune):
     d = emu_lib.alloc(n * 32); emu_lib.upload(d, dense)
     pa, ca, wa = key.commit_partial_device(0, d, 130)
     pb, cb, wb = key.commit_partial_device(130, d + 130 * 32, n - 130)
-    assert (ca, wa) == (0, 16) == (cb, wb)
+    assert (ca, wa) == (0, 1) == (cb, wb)
     assert (cm.combine_partials(cid, np.stack([pa, pb]), ca, wa, lib=emu_lib) == want_dense).all()
     # a batch over the tables: one bucket set per commitment (two vectors of a prefix length, one all zeros)
     vs = [dense[:200], np.zeros((200, 4), dtype=np.uint64)]
@@ -252,6 +291,7 @@ def test_emu_shared_bucket_tables_other_widths(emu_lib, tune):
     one.  Same points as the per-window path and the oracle for single commits, prefixes, a batch, chunk partials
     (ranks of a sharded MSM all take the widest set) and host scalars in point chunks."""
     tune(_lib.TUNE_TABLE_MIN_N, 1)
+    tune(_lib.TUNE_SHARED_MIN_N, 1)
     cid, n = 1, 260
     bs = C.synth_bases(cid, n, seed=47)
     bs[5] = 0
@@ -280,7 +320,7 @@ def test_emu_shared_bucket_tables_other_widths(emu_lib, tune):
     d = emu_lib.alloc(n * 32); emu_lib.upload(d, dense)
     pa, ca, wa = key.commit_partial_device(0, d, 100)
     pb, cb, wb = key.commit_partial_device(100, d + 100 * 32, n - 100)
-    assert (ca, wa) == (0, 16) == (cb, wb) and last_table() == 8
+    assert (ca, wa) == (0, 1) == (cb, wb) and last_table() == 8
     assert (cm.combine_partials(cid, np.stack([pa, pb]), ca, wa, lib=emu_lib) == want_dense).all()
     tune(_lib.TUNE_STAGED_MIN_N, 1)                           # the LDS-staged sort with table indices, 12 fine bits at most
     tune(_lib.TUNE_TABLE_WIDTH, 13)

@@ -9,6 +9,7 @@ from oracle import cref as C
 from oracle import pyref as P
 lib = _lib.load()
 lib.tune(_lib.TUNE_TABLE_MIN_N, 1)
+lib.tune(_lib.TUNE_SHARED_MIN_N, 1)
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 MOD = {0: P.R_MOD, 1: P.P_MOD}                      # scalar field of each curve

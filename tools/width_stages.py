@@ -6,6 +6,8 @@ lib = _lib.load()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
 kind = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 widths = [int(a) for a in sys.argv[3:]] or [8, 9, 10, 11, 12, 13, 14]
+for kv in filter(None, os.environ.get("TUNE", "").split(",")):     # TUNE=12=3,13=2: mira_set_tuning(knob, value)
+    k, v = kv.split("="); lib.tune(int(k), int(v))
 key = cm.CommitmentKey.synthetic(0, n); d = cm.synth_scalars_device(0, n, kind=kind)
 for c in widths:
     lib.check(lib.c.mira_msm_set_window_bits(c))

@@ -42,6 +42,8 @@ extern "C" {
 #define MIRA_E_UNSUPPORTED (-5)   /* size not supported by this build */
 #define MIRA_E_INVALID_POINT (-6) /* a base is not on the curve */
 #define MIRA_E_IO (-7)            /* key file missing, unreadable or shorter than 2^k points */
+#define MIRA_E_JIT_UNAVAILABLE (-8) /* mira_graph_specialize: no run-time compiler on this machine (no libhiprtc.so); the graphs stay interpreted */
+#define MIRA_E_JIT_FAILED (-9)    /* mira_graph_specialize: the compiler or the module loader failed (mira_last_error has its log); the graphs stay interpreted */
 
 /* Largest number of windows any MSM configuration uses; sizes mira_msm_partial buffers. */
 #define MIRA_MAX_WINDOWS 64
@@ -304,8 +306,10 @@ int mira_graph_eval_batch(const uint64_t *handles, uint32_t count, const mira_ev
  * (src/ivc/public_params.rs: the PlonkStructure is built once), so this belongs where the GraphEvaluators are built.
  * The call blocks for the compilation but releases the library's lock meanwhile: other threads keep committing and
  * evaluating (interpreted), and a handle freed before the compiler is done is skipped.
- * MIRA_E_UNSUPPORTED (libhiprtc.so missing, a graph of more than 1536 instructions, a compilation failure):
- * nothing has changed and the graphs keep being interpreted -- on the GPU, there is no host path.
+ * Soft failures, each with its own code and the reason in mira_last_error(): MIRA_E_JIT_UNAVAILABLE (no libhiprtc.so on this
+ * machine), MIRA_E_UNSUPPORTED (a graph of more than 1536 instructions), MIRA_E_JIT_FAILED (the compiler or the module loader
+ * failed: the text carries the compiler's log).  In all three nothing has changed and the graphs keep being interpreted --
+ * on the GPU, there is no host path.  The three kernel headers the generated source includes are embedded in the library.
  * `columns`: the column table the graphs will be evaluated over -- only the KINDS are read (which columns are selector
  * bytes is a property of the circuit); an evaluation over columns of other kinds than the kernel was built for is
  * interpreted.
@@ -316,13 +320,20 @@ int mira_graph_is_specialized(uint64_t handle, int32_t *out);
 int mira_graph_jit_source(uint64_t handle, const mira_eval_column *columns, uint32_t num_columns, char *buf, size_t cap, size_t *len_out);
 /* Code objects on disk.  mira_graph_set_cache_dir(dir): every kernel mira_graph_specialize compiles from now on is also
  * written to `dir` (which must exist), and a graph whose kernel lies there is loaded instead of compiled -- the second
- * process of an IVC run over the same circuit specialises in milliseconds.  A file is taken only if the generated source,
- * the kernel headers beside libmira_gpu.so and the hiprtc version are the ones it was built from, byte for byte; writing
- * is best effort (an unwritable directory costs compilations, not errors).  NULL or "" (the default): no files.  The
- * reference keeps its commitment keys the same way (src/commitment.rs:96-167, `.cache/`).
- * mira_graph_jit_stats: how many kernels the last mira_graph_specialize compiled / read from the directory. */
+ * process of an IVC run over the same circuit specialises in milliseconds.  A file is taken only if the generated source
+ * and the build environment -- the kernel headers embedded in libmira_gpu.so, the compiler options, the GPU architecture
+ * of the bound device, the HIP runtime and hiprtc versions -- are the ones it was built from, byte for byte, and its code
+ * hashes to what its header says; writing is best effort (an unwritable directory costs compilations, not errors).  A code
+ * object is executed as found, so the directory must belong to the calling user and be writable by nobody else (else
+ * MIRA_E_BAD_ARG; not a directory: MIRA_E_IO), and a file there that is somebody else's or group / world-writable is
+ * ignored.  NULL or "" (the default): no files.  The reference keeps its commitment keys the same way
+ * (src/commitment.rs:96-167, `.cache/`).
+ * mira_graph_jit_stats: how many kernels the last mira_graph_specialize compiled / read from the directory.
+ * mira_graph_jit_compile_check: compile a source text through the library's own path (hiprtc + the embedded headers) and
+ * report the size of the code object; needs no GPU (build checks, tests). */
 int mira_graph_set_cache_dir(const char *dir);
 int mira_graph_jit_stats(uint32_t *compiled_out, uint32_t *from_disk_out);
+int mira_graph_jit_compile_check(const char *source, size_t *code_size_out);
 
 
 /* ---- ProtoGalaxy's polynomial pipeline around the NTT (src/nifs/protogalaxy/poly/mod.rs) -------

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmira_gpu.so")
 
 MIRA_OK = 0
 MIRA_E_NO_DEVICE, MIRA_E_BAD_ARG, MIRA_E_TOO_LONG, MIRA_E_ALLOC, MIRA_E_UNSUPPORTED, MIRA_E_INVALID_POINT, MIRA_E_IO = -1, -2, -3, -4, -5, -6, -7
+MIRA_E_JIT_UNAVAILABLE, MIRA_E_JIT_FAILED = -8, -9
 MIRA_MAX_WINDOWS = 64
 MIRA_PARTIAL_U64 = MIRA_MAX_WINDOWS * 16
 
@@ -29,7 +30,7 @@ SYMBOLS = [
     "mira_set_timing", "mira_get_timings", "mira_set_tuning",
     "mira_msm_register_bases_file", "mira_msm_save_bases_file", "mira_msm_partial_to_device", "mira_msm_set_handle_window_bits",
     "mira_trim", "mira_dev_mem_info", "mira_msm_plan_window_bits", "mira_lincomb_multi_device", "mira_dev_copy", "mira_msm_last_table_bits",
-    "mira_graph_specialize", "mira_graph_is_specialized", "mira_graph_jit_source",
+    "mira_graph_specialize", "mira_graph_is_specialized", "mira_graph_jit_source", "mira_graph_jit_compile_check",
 ]
 TUNE_STAGED_MIN_N, TUNE_TABLE_MIN_N, TUNE_PLAN_HIST_MIN_N, TUNE_NTT_MAX_LOG_LINE, TUNE_NTT_WAVE, TUNE_HOST_CHUNK_MIN_N, TUNE_NTT_SINGLE_TW_LOG, TUNE_NTT_FULL_TW_MAX_LOG, TUNE_TABLE_WIDTH, TUNE_JIT_LOADS_AHEAD, TUNE_MIN_SEGMENT, TUNE_GLV = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 TUNE_REDUCE_PIECES, TUNE_REDUCE_LAMBDA, TUNE_REDUCE_QUAD, TUNE_SHARED_MIN_N = 12, 13, 14, 15
@@ -96,7 +97,7 @@ class MiraLib:
             "mira_fold_witness_device": [ctypes.c_int, vp, vp, vp, u64p, sz], "mira_fold_error_device": [ctypes.c_int, vp, vp, sz, u64p, sz],
             "mira_g1_mul_add": [ctypes.c_int, u64p, u64p, u64p, u64p], "mira_g1_lincomb": [ctypes.c_int, u64p, u64p, u64p, sz, u64p],
             "mira_fold_relaxed_witness_device": [ctypes.c_int, vp, vp, vp, sz, vp, vp, vp, sz, u64p, sz],
-            "mira_graph_set_cache_dir": [ctypes.c_char_p], "mira_graph_jit_stats": [vp, vp],
+            "mira_graph_set_cache_dir": [ctypes.c_char_p], "mira_graph_jit_stats": [vp, vp], "mira_graph_jit_compile_check": [ctypes.c_char_p, vp],
             "mira_g1_fold_commitments": [ctypes.c_int, u64p, u64p, u64p, sz, u64p, u64p, sz, u64p, u64p],
             "mira_graph_eval_device": [ctypes.c_int, vp, vp, u32, u64p, u32, sz, vp],
             "mira_graph_compile": [ctypes.c_int, vp, u32, u32, vp], "mira_graph_eval_compiled": [u64, vp, u32, u64p, u32, sz, vp], "mira_graph_eval_batch": [vp, u32, vp, u32, vp, u32, sz, vp], "mira_graph_free": [u64], "mira_graph_specialize": [vp, u32, vp, u32], "mira_graph_is_specialized": [u64, vp], "mira_graph_jit_source": [u64, vp, u32, vp, sz, vp],

@@ -1288,6 +1288,9 @@ int mira_graph_set_cache_dir(const char *dir) {
     std::lock_guard<std::mutex> lk(g_lock);
     return graph_set_cache_dir(dir);
 }
+int mira_graph_jit_compile_check(const char *source, size_t *code_size_out) {
+    return graph_jit_compile_check(source, code_size_out);       // touches neither the device nor the library's state (rtc() is loaded once)
+}
 int mira_graph_jit_stats(uint32_t *compiled_out, uint32_t *from_disk_out) {
     std::lock_guard<std::mutex> lk(g_lock);
     return graph_jit_stats(compiled_out, from_disk_out);

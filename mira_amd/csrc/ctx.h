@@ -242,6 +242,7 @@ int graph_specialize(const uint64_t *handles, uint32_t count, const mira_eval_co
                      std::unique_lock<std::mutex> *library_lock);   // held on entry and on return; released while the compiler runs
 int graph_is_specialized(uint64_t handle, int32_t *out);
 int graph_set_cache_dir(const char *dir);
+int graph_jit_compile_check(const char *src, size_t *code_size_out);
 int graph_jit_stats(uint32_t *compiled_out, uint32_t *from_disk_out);
 int graph_jit_source(uint64_t handle, const mira_eval_column *columns, uint32_t num_columns, char *buf, size_t cap, size_t *len_out);
 int graph_eval_device(int field, const mira_graph *gr, const mira_eval_column *columns, uint32_t num_columns, const uint64_t *challenges,

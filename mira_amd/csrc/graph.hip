@@ -767,6 +767,9 @@ int graph_jit_source(uint64_t handle, const mira_eval_column *columns, uint32_t 
 }
 
 #ifndef MIRA_CPU_EMU
+#include "jit_headers.inc"
+#include <fcntl.h>
+#include <sys/stat.h>
 namespace graphjit {
 Rtc &rtc() {
     static Rtc r;
@@ -785,23 +788,20 @@ Rtc &rtc() {
     r.code_size = reinterpret_cast<decltype(r.code_size)>(sym("hiprtcGetCodeSize"));
     r.code = reinterpret_cast<decltype(r.code)>(sym("hiprtcGetCode"));
     r.destroy = reinterpret_cast<decltype(r.destroy)>(sym("hiprtcDestroyProgram"));
-    Dl_info info;                                            // the kernel headers lie beside this library
-    if (dladdr(reinterpret_cast<const void *>(&graph_specialize), &info) && info.dli_fname) {
-        std::string path(info.dli_fname);
-        const size_t slash = path.rfind('/');
-        r.include_dir = slash == std::string::npos ? "." : path.substr(0, slash);
-    } else if (r.error.empty()) r.error = "cannot locate libmira_gpu.so (dladdr)";
     return r;
 }
+static const char *const JIT_OPTIONS[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
 std::vector<char> compile(const std::string &src, std::string &err) {
     Rtc &r = rtc();
     std::vector<char> out;
     if (!r.error.empty()) { err = r.error; return out; }
     void *prog = nullptr;
-    if (r.create(&prog, src.c_str(), "mira_jit.hip", 0, nullptr, nullptr) != 0) { err = "hiprtcCreateProgram failed"; return out; }
-    const std::string inc = "-I" + r.include_dir;
-    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", inc.c_str()};
-    const int rc = r.compile(prog, 4, opts);
+    // the kernel headers travel inside the library: `#include "field29.cuh"` (and its own includes) resolve to these texts
+    if (r.create(&prog, src.c_str(), "mira_jit.hip", JIT_HDR_COUNT, const_cast<const char **>(JIT_HDR_TEXT), const_cast<const char **>(JIT_HDR_NAME)) != 0) {
+        err = "hiprtcCreateProgram failed";
+        return out;
+    }
+    const int rc = r.compile(prog, 3, const_cast<const char **>(JIT_OPTIONS));
     if (rc != 0) {
         size_t n = 0;
         (void)r.log_size(prog, &n);
@@ -819,9 +819,12 @@ std::vector<char> compile(const std::string &src, std::string &err) {
 }
 
 // ---- code objects on disk (mira_graph_set_cache_dir) --------------------------------------------------------------
-// A file per kernel: magic | key of the build environment | source length | source | code length | code.  The file
-// name is a hash of source and environment; a hit must match both byte for byte, so a colliding or stale file (another
-// version of the headers the source includes, another hiprtc) is a miss, never a wrong kernel.
+// A file per kernel: magic | key of the build environment | source length | source | code length | hash of the code | code.
+// The file name is a hash of source and environment; a hit must match both byte for byte and the code must hash to what the
+// header says, so a colliding, stale or damaged file (other kernel headers, another ROCm, another GPU architecture, a
+// truncated write) is a miss, never a wrong kernel.  The hash guards against damage, not against an adversary: a code object
+// is executed on the GPU as it is, so the directory must belong to the user and be writable by nobody else -- checked when it
+// is set and again for every file that is taken.
 static std::string g_cache_dir;
 static uint64_t fnv1a(const void *p, size_t n, uint64_t h = 0xcbf29ce484222325ull) {
     const unsigned char *b = static_cast<const unsigned char *>(p);
@@ -831,6 +834,8 @@ static uint64_t fnv1a(const void *p, size_t n, uint64_t h = 0xcbf29ce484222325ul
 static bool read_file(const std::string &path, std::vector<char> &out) {
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) return false;
+    struct stat sb;
+    if (fstat(fileno(f), &sb) != 0 || sb.st_uid != geteuid() || (sb.st_mode & (S_IWGRP | S_IWOTH))) { fclose(f); return false; }   // somebody else's file, or one others may write
     out.clear();
     char buf[65536];
     size_t n;
@@ -839,26 +844,31 @@ static bool read_file(const std::string &path, std::vector<char> &out) {
     fclose(f);
     return ok;
 }
-// everything besides the source text that decides the code object: the headers it includes and the compiler
+// everything besides the source text that decides the code object: the embedded headers, the compiler options, the GPU
+// architecture the process runs on, the HIP runtime and the hiprtc that compiles
 static const std::string &environment_key() {
     static std::string key;
     if (!key.empty()) return key;
     Rtc &r = rtc();
-    uint64_t h = fnv1a("gfx950 -O3 c++17", 16);
-    for (const char *name : {"field29.cuh", "field.cuh", "platform.h"}) {
-        std::vector<char> text;
-        (void)read_file(r.include_dir + "/" + name, text);       // unreadable: the compilation fails as well
-        h = fnv1a(text.data(), text.size(), h);
-        h = fnv1a(name, strlen(name), h);
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (int i = 0; i < JIT_HDR_COUNT; i++) {
+        h = fnv1a(JIT_HDR_TEXT[i], strlen(JIT_HDR_TEXT[i]), h);
+        h = fnv1a(JIT_HDR_NAME[i], strlen(JIT_HDR_NAME[i]), h);
     }
-    int major = 0, minor = 0;
+    std::string opts;
+    for (const char *o : JIT_OPTIONS) { opts += o; opts += ' '; }
+    int major = 0, minor = 0, runtime = 0;
     if (r.lib) {
         auto version = reinterpret_cast<int (*)(int *, int *)>(dlsym(r.lib, "hiprtcVersion"));
         if (version) (void)version(&major, &minor);
     }
+    (void)hipRuntimeGetVersion(&runtime);
+    hipDeviceProp_t prop;
+    std::string arch = "unknown";
+    if (hipGetDeviceProperties(&prop, g.device) == hipSuccess) arch = prop.gcnArchName;
     char buf[96];
-    snprintf(buf, sizeof buf, "mira-jit-1 %016llx hiprtc %d.%d", (unsigned long long)h, major, minor);
-    key = buf;
+    snprintf(buf, sizeof buf, "%016llx", (unsigned long long)h);
+    key = "mira-jit-2 arch " + arch + " hip " + std::to_string(runtime) + " hiprtc " + std::to_string(major) + "." + std::to_string(minor) + " headers " + buf + " options " + opts;
     return key;
 }
 static std::string cache_path(const std::string &src) {
@@ -868,7 +878,11 @@ static std::string cache_path(const std::string &src) {
     snprintf(name, sizeof name, "/mira_jit_%016llx%016llx.bin", (unsigned long long)a, (unsigned long long)b);
     return g_cache_dir + name;
 }
-static constexpr char CACHE_MAGIC[8] = {'M', 'I', 'R', 'A', 'J', 'I', 'T', '1'};
+static constexpr char CACHE_MAGIC[8] = {'M', 'I', 'R', 'A', 'J', 'I', 'T', '2'};
+static void code_hash(const std::vector<char> &code, uint64_t out[2]) {
+    out[0] = fnv1a(code.data(), code.size());
+    out[1] = fnv1a(code.data(), code.size(), 0x84222325cbf29ce4ull ^ code.size());
+}
 static std::vector<char> cache_load(const std::string &src) {
     std::vector<char> file, code;
     if (g_cache_dir.empty() || !read_file(cache_path(src), file)) return code;
@@ -876,23 +890,28 @@ static std::vector<char> cache_load(const std::string &src) {
     size_t pos = 0;
     auto take = [&](const void *want, size_t n) { const bool ok = pos + n <= file.size() && memcmp(file.data() + pos, want, n) == 0; pos += n; return ok; };
     auto take_len = [&](uint64_t &v) { if (pos + 8 > file.size()) return false; memcpy(&v, file.data() + pos, 8); pos += 8; return true; };
-    uint64_t n_env = 0, n_src = 0, n_code = 0;
+    uint64_t n_env = 0, n_src = 0, n_code = 0, want[2] = {0, 0}, have[2];
     if (!take(CACHE_MAGIC, 8) || !take_len(n_env) || n_env != env.size() || !take(env.data(), env.size())) return code;
     if (!take_len(n_src) || n_src != src.size() || !take(src.data(), src.size())) return code;
-    if (!take_len(n_code) || n_code == 0 || pos + n_code != file.size()) return code;
+    if (!take_len(n_code) || !take_len(want[0]) || !take_len(want[1]) || n_code == 0 || pos + n_code != file.size()) return code;
     code.assign(file.begin() + (long)pos, file.end());
+    code_hash(code, have);
+    if (have[0] != want[0] || have[1] != want[1]) code.clear();
     return code;
 }
 static void cache_store(const std::string &src, const std::vector<char> &code) {   // best effort: a failure costs the next process a compilation
     if (g_cache_dir.empty() || code.empty()) return;
     const std::string path = cache_path(src), tmp = path + ".tmp" + std::to_string((unsigned long long)getpid());
-    FILE *f = fopen(tmp.c_str(), "wb");
-    if (!f) return;
+    const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL, 0600);
+    FILE *f = fd >= 0 ? fdopen(fd, "wb") : nullptr;
+    if (!f) { if (fd >= 0) close(fd); return; }
     const std::string &env = environment_key();
+    uint64_t hash[2];
+    code_hash(code, hash);
     const uint64_t n_env = env.size(), n_src = src.size(), n_code = code.size();
     bool ok = fwrite(CACHE_MAGIC, 1, 8, f) == 8 && fwrite(&n_env, 8, 1, f) == 1 && fwrite(env.data(), 1, env.size(), f) == env.size();
     ok = ok && fwrite(&n_src, 8, 1, f) == 1 && fwrite(src.data(), 1, src.size(), f) == src.size();
-    ok = ok && fwrite(&n_code, 8, 1, f) == 1 && fwrite(code.data(), 1, code.size(), f) == code.size();
+    ok = ok && fwrite(&n_code, 8, 1, f) == 1 && fwrite(hash, 8, 2, f) == 2 && fwrite(code.data(), 1, code.size(), f) == code.size();
     ok = (fclose(f) == 0) && ok;
     if (!ok || rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());   // rename: readers see a whole file or none
 }
@@ -906,8 +925,34 @@ int graph_set_cache_dir(const char *dir) {
     (void)dir;
     return MIRA_OK;
 #else
-    graphjit::g_cache_dir = dir ? dir : "";
-    while (graphjit::g_cache_dir.size() > 1 && graphjit::g_cache_dir.back() == '/') graphjit::g_cache_dir.pop_back();
+    std::string d = dir ? dir : "";
+    while (d.size() > 1 && d.back() == '/') d.pop_back();
+    if (!d.empty()) {
+        // code objects found there are executed on the GPU: the directory must be the user's own, writable by nobody else
+        struct stat sb;
+        if (stat(d.c_str(), &sb) != 0 || !S_ISDIR(sb.st_mode)) { set_error(d + " is not a directory"); return MIRA_E_IO; }
+        if (sb.st_uid != geteuid() || (sb.st_mode & (S_IWGRP | S_IWOTH))) {
+            set_error(d + " must belong to the calling user and be writable by nobody else (mode 0700 or 0755): kernels found there are executed");
+            return MIRA_E_BAD_ARG;
+        }
+    }
+    graphjit::g_cache_dir = d;
+    return MIRA_OK;
+#endif
+}
+// source text -> code object size, through the library's own hiprtc path and embedded headers; needs no device
+int graph_jit_compile_check(const char *src, size_t *code_size_out) {
+#ifdef MIRA_CPU_EMU
+    (void)src; (void)code_size_out;
+    set_error("the host emulation has no run-time compiler");
+    return MIRA_E_JIT_UNAVAILABLE;
+#else
+    if (!src) { set_error("null source"); return MIRA_E_BAD_ARG; }
+    if (!graphjit::rtc().error.empty()) { set_error(graphjit::rtc().error); return MIRA_E_JIT_UNAVAILABLE; }
+    std::string err;
+    const std::vector<char> code = graphjit::compile(src, err);
+    if (code.empty()) { set_error(err); return MIRA_E_JIT_FAILED; }
+    if (code_size_out) *code_size_out = code.size();
     return MIRA_OK;
 #endif
 }
@@ -919,7 +964,7 @@ int graph_specialize(const uint64_t *handles, uint32_t count, const mira_eval_co
 #ifdef MIRA_CPU_EMU
     (void)handles; (void)count; (void)columns; (void)num_columns; (void)library_lock;
     set_error("the host emulation has no run-time compiler: graphs stay interpreted");
-    return MIRA_E_UNSUPPORTED;
+    return MIRA_E_JIT_UNAVAILABLE;
 #else
     std::vector<uint64_t> todo;                              // handles, not pointers: the lock is released while the compiler runs
     for (uint32_t k = 0; k < count; k++) {
@@ -933,7 +978,7 @@ int graph_specialize(const uint64_t *handles, uint32_t count, const mira_eval_co
     }
     g_jit_last_compiled = g_jit_last_from_disk = 0;
     if (todo.empty()) return MIRA_OK;
-    if (!graphjit::rtc().error.empty()) { set_error(graphjit::rtc().error); return MIRA_E_UNSUPPORTED; }
+    if (!graphjit::rtc().error.empty()) { set_error(graphjit::rtc().error); return MIRA_E_JIT_UNAVAILABLE; }
     std::vector<std::vector<char>> code(todo.size());
     std::vector<std::string> errs(todo.size());
     std::vector<std::thread> workers;
@@ -962,7 +1007,7 @@ int graph_specialize(const uint64_t *handles, uint32_t count, const mira_eval_co
     for (auto &t : workers) t.join();
     if (library_lock && !fresh.empty()) library_lock->lock();
     for (size_t k = 0; k < todo.size(); k++)
-        if (code[k].empty()) { set_error(errs[k]); return MIRA_E_UNSUPPORTED; }
+        if (code[k].empty()) { set_error(errs[k]); return MIRA_E_JIT_FAILED; }
     if (compiled.size() + fresh.size() > 256) compiled.clear();   // a bound on what a long-lived process keeps (a code object is ~200 KiB)
     for (size_t k : fresh) { compiled[src[k]] = code[k]; graphjit::cache_store(src[k], code[k]); }
     g_jit_last_compiled = (uint32_t)fresh.size(); g_jit_last_from_disk = (uint32_t)from_disk;
@@ -980,7 +1025,7 @@ int graph_specialize(const uint64_t *handles, uint32_t count, const mira_eval_co
         if (e != hipSuccess) {
             for (size_t q = 0; q <= k; q++) if (mods[q]) (void)hipModuleUnload(mods[q]);
             set_error(std::string("loading a specialised kernel failed: ") + hipGetErrorString(e));
-            return MIRA_E_UNSUPPORTED;
+            return MIRA_E_JIT_FAILED;
         }
     }
     for (size_t k = 0; k < todo.size(); k++)

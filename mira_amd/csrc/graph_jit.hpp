@@ -13,8 +13,9 @@
 // the same operands), so every value -- not just the canonical result -- is the one k_graph_eval computes.
 //
 // hiprtc is loaded with dlopen at first use: a machine without it keeps the interpreter (mira_graph_specialize
-// reports MIRA_E_UNSUPPORTED).  The headers the source includes (field29.cuh, field.cuh, platform.h) are read from
-// the directory libmira_gpu.so lies in.
+// reports MIRA_E_JIT_UNAVAILABLE).  The headers the source includes (field29.cuh, field.cuh, platform.h) are part of
+// the library: the build embeds their text (Makefile: jit_headers.inc) and hands it to hiprtc as named headers, so
+// nothing has to lie beside libmira_gpu.so.
 #pragma once
 #include <string>
 #include <vector>
@@ -164,7 +165,7 @@ struct Rtc {
     int (*code_size)(void *, size_t *) = nullptr;
     int (*code)(void *, char *) = nullptr;
     int (*destroy)(void **) = nullptr;
-    std::string include_dir, error;
+    std::string error;
     bool tried = false;
 };
 Rtc &rtc();                                                      // graph.hip

@@ -150,15 +150,19 @@ class GraphEvaluator:
     def specialize(evaluators, columns, num_challenges, lib=None):
         """mira_graph_specialize: every one of these graphs gets a kernel of its own, compiled for the device at run
         time from its instruction stream (once per circuit: the gate polynomial is fixed for the whole IVC run).  Only
-        the KINDS of `columns` matter here.  Returns True when the graphs are specialised, False when the library has
-        no run-time compiler at hand (they stay interpreted: same values, about half the rate)."""
+        the KINDS of `columns` matter here.  Returns True when the graphs are specialised; False -- with a warning that
+        carries the library's reason -- when this machine has no run-time compiler or a graph is too long to specialise
+        (they stay interpreted: same values, about half the rate).  A compiler or loader FAILURE raises MiraError with
+        the compiler's log."""
         lib = lib or _lib.load()
         evaluators = [ev for ev in evaluators if ev is not None]
         if not evaluators:
             return True
         handles = (ctypes.c_uint64 * len(evaluators))(*[ev.compiled(num_challenges, len(columns), lib) for ev in evaluators])
         rc = lib.c.mira_graph_specialize(handles, len(evaluators), GraphEvaluator._column_table(columns), len(columns))
-        if rc == _lib.MIRA_E_UNSUPPORTED:
+        if rc in (_lib.MIRA_E_JIT_UNAVAILABLE, _lib.MIRA_E_UNSUPPORTED):
+            import warnings
+            warnings.warn("mira_graph_specialize: " + (lib.c.mira_last_error() or b"").decode(errors="replace") + " -- graphs stay interpreted", RuntimeWarning, stacklevel=2)
             return False
         lib.check(rc)
         return True

@@ -149,6 +149,9 @@ def test_code_objects_on_disk(gpu_lib, tmp_path):
     assert (first["compiled"], first["from_disk"]) == (2, 0) and all(first["specialised"])
     files = sorted(p for p in os.listdir(tmp_path) if p.startswith("mira_jit_") and p.endswith(".bin"))
     assert len(files) == 2 and not [p for p in os.listdir(tmp_path) if ".tmp" in p]
+    head = open(os.path.join(tmp_path, files[0]), "rb").read(400)
+    assert head[:8] == b"MIRAJIT2" and b"arch gfx950" in head and b" hip " in head and b" hiprtc " in head and b" headers " in head     # keyed by GPU architecture and ROCm version
+    assert all(os.stat(os.path.join(tmp_path, f)).st_mode & 0o077 == 0 for f in files)                                                # written for the user alone
     second = run()
     assert (second["compiled"], second["from_disk"]) == (0, 2) and all(second["specialised"])
     assert second["digest"] == first["digest"]
@@ -164,6 +167,14 @@ def test_code_objects_on_disk(gpu_lib, tmp_path):
     assert open(a, "rb").read() == blob
     fourth = run()
     assert (fourth["compiled"], fourth["from_disk"]) == (0, 2) and fourth["digest"] == first["digest"]
+    # a damaged code object (one byte of the code itself): the hash in the header does not match -> compiled again;
+    # a file others may write is not taken either
+    blob_a = bytearray(blob)
+    blob_a[-100] ^= 0x40
+    open(a, "wb").write(bytes(blob_a))
+    os.chmod(b, 0o666)
+    fifth = run()
+    assert (fifth["compiled"], fifth["from_disk"]) == (2, 0) and fifth["digest"] == first["digest"]
 
 
 def test_library_stays_usable_while_the_compiler_runs(gpu_lib):

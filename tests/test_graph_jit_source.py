@@ -45,6 +45,22 @@ def _compiles(src):
     rtc.hiprtcDestroyProgram(ctypes.byref(prog))
 
 
+def _compiles_with_embedded_headers(src):
+    """The product library's own path: hiprtc + the kernel headers embedded in libmira_gpu.so (no -I, no files beside the
+    library); mira_graph_jit_compile_check needs no device."""
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libmira_gpu.so not built")
+    lib = _lib.MiraLib(_lib.LIB_PATH)
+    size = ctypes.c_size_t()
+    rc = lib.c.mira_graph_jit_compile_check(src.encode(), ctypes.byref(size))
+    if rc == _lib.MIRA_E_JIT_UNAVAILABLE:
+        pytest.skip("no libhiprtc.so in this container")
+    assert rc == 0, lib.c.mira_last_error().decode()[:2000]
+    assert size.value > 4096
+    bad = lib.c.mira_graph_jit_compile_check(b'#include "field29.cuh"\nthis is not HIP\n', ctypes.byref(size))
+    assert bad == _lib.MIRA_E_JIT_FAILED and b"error" in lib.c.mira_last_error()      # a compiler failure is loud and carries the log
+
+
 def test_generated_source_of_a_gate_like_graph(emu_lib):
     rng = random.Random(5)
     e = gate_like_expression(rng, 6, 7, 12, 3)                # 2 selectors, 3 fixed, 7 advice columns; rotations; 3 challenges
@@ -61,11 +77,13 @@ def test_generated_source_of_a_gate_like_graph(emu_lib):
         assert src.count(f"((int64_t)row + ({r})) % (int64_t)nrows") <= 1
     assert src.count("% (int64_t)nrows") <= len(used_rot)                                 # ... never per column read
     assert not ev.is_specialized(3, len(cols), lib=emu_lib)
-    assert G.GraphEvaluator.specialize([ev], cols, 3, lib=emu_lib) is False               # the emulation has no run-time compiler
+    with pytest.warns(RuntimeWarning, match="no run-time compiler"):
+        assert G.GraphEvaluator.specialize([ev], cols, 3, lib=emu_lib) is False           # the emulation has no run-time compiler, and says so
     # other column kinds, other source: a selector is read as a byte, a field column as 32 bytes
     src_f = ev.jit_source([(1, G.COL_FIELD)] * 12, 3, lib=emu_lib)
     assert "const uint32_t c" not in src_f and ("const uint32_t c" in src) == any(f"cols[{k}].p[" in src for k in (0, 1))
     _compiles(src)
+    _compiles_with_embedded_headers(src)
 
 
 def test_generated_source_of_a_main_gate_point_compiles(emu_lib):
@@ -75,3 +93,18 @@ def test_generated_source_of_a_main_gate_point_compiles(emu_lib):
     src = plan.evaluators[2].jit_source([(1, G.COL_FIELD)] * ncol, 2 * ctx.num_challenges, lib=emu_lib)
     assert src.count("__builtin_amdgcn_sched_barrier(0);") >= 40                          # one scheduling region per product
     _compiles(src)
+
+
+def test_cache_directory_must_be_private(tmp_path):
+    """mira_graph_set_cache_dir: code objects found in the directory are executed, so one that others may write (or that is
+    not a directory) is refused; "" / NULL switches the files off.  No device needed."""
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libmira_gpu.so not built")
+    lib = _lib.MiraLib(_lib.LIB_PATH)
+    good, open_dir, plain = tmp_path / "mine", tmp_path / "everyone", tmp_path / "file"
+    good.mkdir(mode=0o700); open_dir.mkdir(); os.chmod(open_dir, 0o777); plain.write_text("x")
+    assert lib.c.mira_graph_set_cache_dir(os.fsencode(good)) == 0
+    assert lib.c.mira_graph_set_cache_dir(os.fsencode(open_dir)) == _lib.MIRA_E_BAD_ARG and b"writable by nobody else" in lib.c.mira_last_error()
+    assert lib.c.mira_graph_set_cache_dir(os.fsencode(plain)) == _lib.MIRA_E_IO
+    assert lib.c.mira_graph_set_cache_dir(os.fsencode(tmp_path / "absent")) == _lib.MIRA_E_IO
+    assert lib.c.mira_graph_set_cache_dir(None) == 0 and lib.c.mira_graph_set_cache_dir(b"") == 0

@@ -2,6 +2,8 @@ set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=$PWD/gpurun_out
+python -m pytest tests/test_gpu_graph_jit.py tests/test_gpu_msm.py -x -q -m gpu > $O/r04_b_tests.txt 2>&1 || { tail -30 $O/r04_b_tests.txt; exit 1; }
+tail -2 $O/r04_b_tests.txt
 python tools/batch_probe.py > $O/r04_b_batch_probe.txt 2>&1
 python tools/witness_stage_probe.py > $O/r04_b_witness_probe.txt 2>&1
 for c in 13 12 16; do

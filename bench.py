@@ -177,11 +177,13 @@ def main():
     stage_acc = {}
     sync_all()
     t0 = time.perf_counter()
-    step_walls = []
+    step_walls, rank_diag = [], []
     for _ in range(args.steps):
         ts = time.perf_counter()
         result = step()
         step_walls.append((time.perf_counter() - ts) * 1e3)     # a commit is synchronous: this is the step's own wall time
+        if dist is not None:
+            rank_diag.append(dict(skey.last))
         for name, ms in lib.timings():
             stage_acc[name] = stage_acc.get(name, 0.0) + ms
     sync_all()
@@ -243,6 +245,21 @@ def main():
         "result_affine_u64": [hex(int(v)) for v in np.asarray(result, dtype=np.uint64).reshape(-1)],
     }
 
+    if dist is not None:
+        # Self-diagnosis of an N-rank run: what every rank saw, medians over the timed steps -- its pairs, the agreed window shape,
+        # its partial MSM, the exchange (which includes waiting for the slowest rank) and the host combine.  A rank that is slow,
+        # holds the wrong chunk or planned another width shows here, in the one line the driver keeps.
+        def med(key_):
+            vals = sorted(d[key_] for d in rank_diag)
+            return vals[len(vals) // 2] if vals else None
+        mine = {"rank": rank, "local_rank": local_rank, "pairs": n, "window_bits": med("window_bits"), "num_windows": med("num_windows"),
+                "partial_ms": med("partial_ms"), "exchange_us": med("exchange_us"), "combine_ms": med("combine_ms"),
+                "step_ms_median": round(sorted(step_walls)[len(step_walls) // 2], 4), "step_ms_max": round(max(step_walls), 4)}
+        gathered = [None] * n_gpus
+        dist.all_gather_object(gathered, mine)
+        out["ranks"] = gathered
+        out["agreed_window"] = {"window_bits": mine["window_bits"], "num_windows": mine["num_windows"],
+                                "same_on_all_ranks": len({(g_["window_bits"], g_["num_windows"]) for g_ in gathered}) == 1}
     if strong and n_gpus > 1 and dist is not None and not args.emulate and not args.no_extras:
         out["extras"] = multi_gpu_extras(lib, cm, dist, rank, n_gpus, total_log_n, args)
     if rank == 0 and n_gpus == 1 and not args.no_cpu:

@@ -142,19 +142,19 @@ static int upload_consts() {
 // LDS trees of general additions (5 us per level here).  A batch is count * W windows of one launch
 // sequence: the additions scale, the latency does not; its W * (count - 1) * B extra counters are
 // scanned at 5 800 per microsecond.
-static const int plan_log_n[10] = {6, 10, 13, 15, 16, 17, 18, 19, 20, 21};   // (rows 2^16 .. 2^21 re-measured at the end of round 3, one box: profiles/r03_n_plan_calibrate.txt)
+static const int plan_log_n[10] = {6, 10, 13, 15, 16, 17, 18, 19, 20, 21};   // (all rows re-measured in round 4 on the rebuilt bucket reduction, one box: profiles/r04_b_plan_calibrate.txt)
 static const double plan_wall_us[10][17] = {
     //            c = 4     5     6     7     8     9    10    11    12    13    14    15    16
-    {0, 0, 0, 0,   198,   201,   227,   246,   293,   300,   312,   381,   379,   479,   521,   895,   905},
-    {0, 0, 0, 0,   277,   263,   267,   270,   237,   278,   325,   315,   384,   452,   542,   612,   726},
-    {0, 0, 0, 0,   301,   298,   303,   314,   288,   306,   313,   331,   345,   452,   504,   577,   665},
-    {0, 0, 0, 0,   377,   388,   401,   343,   344,   425,   443,   427,   440,   470,   546,   597,   707},
-    {0, 0, 0, 0,   501,   472,   486,   527,   398,   452,   497,   535,   466,   532,   594,   608,   663},
-    {0, 0, 0, 0,   770,   686,   669,   685,   544,   588,   601,   704,   554,   604,   674,   687,   724},
-    {0, 0, 0, 0,  1299,  1118,  1041,  1010,   828,   851,   838,   922,   773,   798,   869,   866,   880},
-    {0, 0, 0, 0,  2441,  2004,  1840,  1718,  1412,  1501,  1377,  1355,  1171,  1146,  1198,  1152,  1141},
-    {0, 0, 0, 0,  4792,  3979,  3481,  3184,  2699,  2770,  2438,  2336,  2002,  1957,  1932,  1843,  1777},
-    {0, 0, 0, 0,  9697,  8091,  7049,  6217,  5214,  5285,  4639,  4353,  3926,  3604,  3509,  3259,  3115},
+    {0, 0, 0, 0,   194,   198,   224,   240,   288,   293,   386,   321,   291,   322,   479,   418,   419},
+    {0, 0, 0, 0,   277,   262,   268,   269,   228,   279,   319,   300,   363,   365,   565,   497,   506},
+    {0, 0, 0, 0,   297,   309,   301,   309,   278,   570,   502,   343,   357,   399,   487,   468,   500},
+    {0, 0, 0, 0,   385,   392,   407,   345,   338,   421,   438,   386,   389,   439,   547,   510,   539},
+    {0, 0, 0, 0,   501,   479,   494,   526,   393,   447,   518,   529,   447,   461,   553,   507,   560},
+    {0, 0, 0, 0,   790,   696,   762,   696,   541,   582,   621,   693,   537,   534,   639,   638,   742},
+    {0, 0, 0, 0,  1311,  1122,  1040,  1008,   821,   842,   867,   909,   751,   728,   831,   747,   775},
+    {0, 0, 0, 0,  2484,  2073,  1835,  1706,  1398,  1510,  1376,  1352,  1153,  1084,  1168,  1042,  1030},
+    {0, 0, 0, 0,  4859,  4059,  3524,  3252,  2722,  2714,  2427,  2320,  1988,  1857,  1923,  1707,  1667},
+    {0, 0, 0, 0,  9587,  7989,  7020,  6310,  5318,  5421,  4734,  4386,  3878,  3519,  3494,  3064,  2980},
 };
 static double plan_table_us(uint32_t c, double n_eff) {
     const double x = std::log2(std::max(n_eff, 1.0));
@@ -530,7 +530,13 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
     *shape = PartialShape{p.c, p.W, p.cb, p.pieces};
     g.last_c = (int32_t)p.c; g.last_w = (int32_t)p.W; g.last_table_c = 0;
     memset(out_partial, 0, MIRA_PARTIAL_U64 * 8);
-    if (n == 0) return MIRA_OK;
+    if (n == 0) {
+        // an empty chunk (a rank beyond the prefix being committed) answers with the identity in the SHAPE its mode has for any
+        // length: the ranks of a sharded MSM exchange and combine partials of one shape (mira_amd/dist.py checks it)
+        if (set) { *shape = PartialShape{0, 1, set->c - 1, 1}; g.last_c = 0; g.last_w = 1; g.last_table_c = (int32_t)set->c; }
+        else if (table_mode) { *shape = PartialShape{0, 64, 0, 1}; g.last_c = 0; g.last_w = 64; g.last_table_c = (int32_t)bs.table_c; }
+        return MIRA_OK;
+    }
     if (!d_scalars) { set_error("null scalars"); return MIRA_E_BAD_ARG; }
     // fixed-base mode: window tables present, MSM large enough to be throughput-bound, no forced width
     if (set) {                                               // shared buckets through the per-window launch sequence

@@ -211,7 +211,8 @@ static int msm_launch_body(const Bases &bs, size_t first, const void *d_scalars,
                    reinterpret_cast<unsigned char *>(g.tail_part.p), reinterpret_cast<uint32_t *>(g.tail_key.p));
         tm_mark("accumulate");
         const uint32_t fix_by_bucket = p.NB < p.T ? p.NB : 0u;   // fewer buckets than segments: index the fix-up by bucket
-        LAUNCH(k_fixup<F>, ceil_div((uint64_t)(fix_by_bucket ? fix_by_bucket : p.T) * 4, 128), 128, 0, st, (const uint32_t *)plan, reinterpret_cast<const uint32_t *>(g.offsets.p),
+        const uint32_t fix_items = fix_by_bucket ? fix_by_bucket : p.T;
+        LAUNCH((k_fixup<F, true>), ceil_div((uint64_t)fix_items * 4, 128), 128, 0, st, (const uint32_t *)plan, reinterpret_cast<const uint32_t *>(g.offsets.p),
                reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
                reinterpret_cast<const uint32_t *>(g.tail_key.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p), heavy_count, heavy_runs, heavy_subs, fix_by_bucket);
         LAUNCH_BARRIER(k_fixup_heavy_a<F>, (FIXUP_HEAVY_GRID + 3) / 4, HEAVY_BLOCK_A, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_subs, (const U4 *)heavy_runs,
@@ -425,7 +426,7 @@ static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars
            reinterpret_cast<unsigned char *>(g.bucket_sums.p), reinterpret_cast<unsigned char *>(g.head_part.p),
            reinterpret_cast<unsigned char *>(g.tail_part.p), reinterpret_cast<uint32_t *>(g.tail_key.p));
     tm_mark("accumulate");
-    LAUNCH(k_fixup<F>, ceil_div((uint64_t)T * 4, 128), 128, 0, st, (const uint32_t *)plan, reinterpret_cast<const uint32_t *>(g.offsets.p),
+    LAUNCH((k_fixup<F, true>), ceil_div((uint64_t)T * 4, 128), 128, 0, st, (const uint32_t *)plan, reinterpret_cast<const uint32_t *>(g.offsets.p),
            reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
            reinterpret_cast<const uint32_t *>(g.tail_key.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p), heavy_count, heavy_runs, heavy_subs, 0u);
     LAUNCH_BARRIER(k_fixup_heavy_a<F>, (FIXUP_HEAVY_GRID + 3) / 4, HEAVY_BLOCK_A, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_subs, (const U4 *)heavy_runs,

@@ -415,6 +415,12 @@ KERNEL void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) k_
     tail_key[t] = (!is_head && cont_next) ? cur : KEY_NONE;   // every segment of the plan writes its key: no clearing pass
 }
 
+template <bool QUAD, class F> DEV void xyzz29_add_sel(Xyzz29<F> &acc, const Xyzz29<F> &q) {
+    if constexpr (QUAD) xyzz29_add_quad(acc, q); else xyzz29_add(acc, q);
+}
+template <bool QUAD, class F> DEV Xyzz29<F> xyzz29_double_sel(const Xyzz29<F> &p) {
+    if constexpr (QUAD) return xyzz29_double_quad(p); else return xyzz29_double(p);
+}
 // The tail kernels below are chains of dependent general additions on few waves.  Every work item
 // is owned by a QUAD of lanes (quad29.cuh): the four lanes load the same operands and share the
 // multiplications of each addition, which cuts the latency of a link from ~6.8 us to ~2 us.
@@ -427,12 +433,16 @@ DEV uint32_t quad_gid() { return (blockIdx.x * blockDim.x + threadIdx.x) >> 2; }
 // heavy_ctr = {runs, sub-jobs}; runs[h] = {lane, span, bucket, first sub-job}; subs[s] = {first
 // partial, count, run, -}.
 static constexpr uint32_t HEAVY_SUB = 64;       // partials per stage-A sub-job: one wave (16 quads x 4 partials, then a 4-level tree)
-template <class F>
+// (One LANE per cut run instead of a quad, for the sizes at which the cut runs fill the SIMDs, was built and measured in round 4:
+// 2^17 pairs c = 13 fix-up 104 -> 117 us, c = 12 123 -> 151, c = 16 51 -> 48; 2^22 pairs 59 -> 54 -- the kernel is bound by its
+// dependent loads and a lane's 14 serial multiplications are no better hidden than a quad's 4.  QUAD stays a template
+// parameter of the kernel; every launch uses quads.)
+template <class F, bool QUAD = true>
 KERNEL void __launch_bounds__(128) k_fixup(const uint32_t *__restrict__ plan, const uint32_t *__restrict__ offsets,
                     const unsigned char *__restrict__ head_part, const unsigned char *__restrict__ tail_part,
                     const uint32_t *__restrict__ tail_key, unsigned char *__restrict__ bucket_sums,
                     uint32_t *__restrict__ heavy_ctr, U4 *__restrict__ runs, U4 *__restrict__ subs, uint32_t num_buckets) {
-    const uint32_t gid = quad_gid();
+    const uint32_t gid = QUAD ? quad_gid() : blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t L = plan[0], T = plan[1];
     // One quad per cut run.  Indexed by segment (the lane that holds the run's tail partial) when
     // segments are fewer than buckets; by bucket (num_buckets != 0) when buckets are fewer -- small
@@ -455,7 +465,7 @@ KERNEL void __launch_bounds__(128) k_fixup(const uint32_t *__restrict__ plan, co
     }
     const uint32_t span = (run_end - 1) / L - t;   // lanes t+1 .. t+span hold head partials of this run
     if (span > (uint32_t)HEAVY_SPAN) {
-        if (quad_lane() != 0) return;
+        if (QUAD && quad_lane() != 0) return;
         const uint32_t nsub = (span + HEAVY_SUB - 1) / HEAVY_SUB;
         const uint32_t h = atomicAdd(&heavy_ctr[0], 1u);
         const uint32_t base = atomicAdd(&heavy_ctr[1], nsub);
@@ -469,8 +479,8 @@ KERNEL void __launch_bounds__(128) k_fixup(const uint32_t *__restrict__ plan, co
         return;
     }
     Xyzz29<F> acc = xyzz29_load<F>(tail_part + (size_t)t * XYZZ29_BYTES);
-    for (uint32_t q = 1; q <= span; q++) xyzz29_add_quad(acc, xyzz29_load<F>(head_part + (size_t)(t + q) * XYZZ29_BYTES));
-    if (quad_lane() == 0) xyzz29_store(bucket_sums + (size_t)key * XYZZ29_BYTES, acc);
+    for (uint32_t q = 1; q <= span; q++) xyzz29_add_sel<QUAD>(acc, xyzz29_load<F>(head_part + (size_t)(t + q) * XYZZ29_BYTES));
+    if (!QUAD || quad_lane() == 0) xyzz29_store(bucket_sums + (size_t)key * XYZZ29_BYTES, acc);
 }
 
 // LDS tree over the values of the first `cnt` quads of the workgroup (cnt <= blockDim.x / 4);
@@ -578,12 +588,6 @@ KERNEL void __launch_bounds__(256) k_fixup_heavy_b(const uint32_t *__restrict__ 
 // Bucket reduction.  QUAD = true: every work item is a quad of lanes (latency-bound sizes: few
 // buckets, the chain of dependent additions is what takes the time); QUAD = false: one lane per work
 // item (2^19 buckets at c = 16: throughput-bound, four times fewer lanes do the same work).
-template <bool QUAD, class F> DEV void xyzz29_add_sel(Xyzz29<F> &acc, const Xyzz29<F> &q) {
-    if constexpr (QUAD) xyzz29_add_quad(acc, q); else xyzz29_add(acc, q);
-}
-template <bool QUAD, class F> DEV Xyzz29<F> xyzz29_double_sel(const Xyzz29<F> &p) {
-    if constexpr (QUAD) return xyzz29_double_quad(p); else return xyzz29_double(p);
-}
 // Work item (w, j) folds buckets [j*m, (j+1)*m) of window w:
 //   R[w][j] = sum_i (j*m + i + 1) * S[w][j*m + i]
 template <class F, bool QUAD>

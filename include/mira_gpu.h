@@ -189,6 +189,9 @@ int mira_msm_last_table_bits(int32_t *table_bits);
 #define MIRA_TUNE_REDUCE_QUAD 14
 /* smallest commit served from a key's shared-bucket table sets (default 2^12); MIRA_TUNE_TABLE_MIN_N is the wide tables' */
 #define MIRA_TUNE_SHARED_MIN_N 15
+/* log2 of the sorted entries (pairs x windows) one pass of the pipeline takes; a longer commit is cut into point chunks that
+ * add into one set of buckets (default and maximum 32: the entry offsets are 32-bit; tests cut small commits with it) */
+#define MIRA_TUNE_PASS_ENTRIES_LOG 16
 int mira_set_tuning(int knob, int64_t value);
 
 /* Read a range of the registered key back in the reference layout (cache file writing,

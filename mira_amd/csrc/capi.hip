@@ -524,7 +524,9 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
     const bool glv = bs.glv && !set && !table_mode && !sharded && n < (1ull << 30) && tuned(MIRA_TUNE_GLV, 1) != 0;
     MsmPlan p = glv ? make_plan(2 * n, width, 1, 0, use_hist ? stat : nullptr, GLV_BITS) : make_plan(n, width, 1, 0, use_hist ? stat : nullptr);
     p.glv = glv; p.glv_bases = glv ? bs.glv : nullptr;
-    if (n >= (1ull << 31) || (uint64_t)n * (glv ? 2 : 1) * p.W >= (1ull << 32)) { set_error("n too large for 32-bit entry offsets"); return MIRA_E_UNSUPPORTED; }
+    // (a commit of n W >= 2^32 entries is cut into point chunks inside the launch sequence, msm_host.cuh; the 31-bit limit is the
+    // point index of a sorted entry, the sign in bit 31)
+    if (n >= (1ull << 31)) { set_error("n too large for 31-bit point indices"); return MIRA_E_UNSUPPORTED; }
     if (p.W > MIRA_MAX_WINDOWS) { set_error("window configuration exceeds MIRA_MAX_WINDOWS"); return MIRA_E_UNSUPPORTED; }
     if (allow_pieces && !g.windows_dst) plan_reduction(p, default_pieces(p, MIRA_MAX_WINDOWS));
     *shape = PartialShape{p.c, p.W, p.cb, p.pieces};
@@ -541,7 +543,6 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
     // fixed-base mode: window tables present, MSM large enough to be throughput-bound, no forced width
     if (set) {                                               // shared buckets through the per-window launch sequence
         MsmPlan ps = make_plan_shared(n, *set, bs.n);
-        if ((uint64_t)n * ps.W >= (1ull << 32)) { set_error("n too large for 32-bit entry offsets"); return MIRA_E_UNSUPPORTED; }
         if (allow_pieces && !g.windows_dst) plan_reduction(ps, default_pieces(ps, MIRA_MAX_WINDOWS));
         *shape = PartialShape{0, 1, ps.cb, ps.pieces};       // the pieces of ONE bucket set (P = 1: its sum)
         g.last_c = 0; g.last_w = (int32_t)ps.pieces; g.last_table_c = (int32_t)set->c;
@@ -583,7 +584,8 @@ static int combine_locked(int curve, const uint64_t *partials, size_t nparts, ui
 
 // count MSMs over the prefix of one key in a single pass of the pipeline (a batch is count * W
 // windows).  Chunked so that the window-counter scan and the 32-bit entry offsets stay in range.
-static int msm_batch_device_locked(uint64_t handle, const void *d_scalars, size_t n, size_t count, size_t stride, uint64_t *out_affine) {
+static int msm_batch_device_locked(uint64_t handle, const void *d_scalars, size_t n, size_t count, size_t stride, uint64_t *out_affine,
+                                   const uint64_t *const *h_batch = nullptr /* the vectors are still in host memory: d_scalars is their staging buffer */) {
     int rc = ensure_ctx();
     if (rc) return rc;
     auto it = g_bases.find(handle);
@@ -609,6 +611,7 @@ static int msm_batch_device_locked(uint64_t handle, const void *d_scalars, size_
             const size_t cnt = std::min(per, count - done);
             MsmPlan p = make_plan_shared(n, *set, bs.n, (uint32_t)cnt, stride);
             plan_reduction(p, default_pieces(p, MIRA_MAX_WINDOWS));
+            p.h_batch = h_batch ? h_batch + done : nullptr;
             g.last_c = 0; g.last_w = (int32_t)p.pieces; g.last_table_c = (int32_t)set->c;
             sums.assign(cnt * p.pieces * 16, 0);
             const unsigned char *sc = reinterpret_cast<const unsigned char *>(d_scalars) + done * stride * 32;
@@ -636,6 +639,7 @@ static int msm_batch_device_locked(uint64_t handle, const void *d_scalars, size_
         const size_t cnt = std::min(per, count - done);
         MsmPlan p = make_plan(nv, forced_c, (uint32_t)cnt, stride, nullptr, bits);
         p.glv = glv; p.glv_bases = glv ? bs.glv : nullptr;
+        p.h_batch = h_batch ? h_batch + done : nullptr;
         plan_reduction(p, default_pieces(p, 1u << 20));
         g.last_c = (int32_t)p.c; g.last_w = (int32_t)p.W; g.last_table_c = 0;
         win.assign((size_t)p.Wt * p.pieces * 16, 0);
@@ -972,12 +976,11 @@ int mira_msm_batch(uint64_t handle, const uint64_t *const *scalars, size_t n, si
     }
     if (n && count) {
         if ((rc = g.scalars_stage.ensure(n * count * 32))) return rc;
-        for (size_t b = 0; b < count; b++) {
+        for (size_t b = 0; b < count; b++)
             if (!scalars[b]) { set_error("null scalars"); return MIRA_E_BAD_ARG; }
-            RT_CHECK(rt_h2d(reinterpret_cast<unsigned char *>(g.scalars_stage.p) + b * n * 32, scalars[b], n * 32, g.stream));
-        }
     }
-    return msm_batch_device_locked(handle, g.scalars_stage.p, n, count, n, out_affine);
+    // the vectors cross PCIe inside the launch sequence, in point chunks beside the kernels (msm_host.cuh)
+    return msm_batch_device_locked(handle, g.scalars_stage.p, n, count, n, out_affine, (n && count) ? scalars : nullptr);
 }
 int mira_msm_partial_device(uint64_t handle, size_t first, const void *d_scalars, size_t n, uint64_t out_partial[MIRA_PARTIAL_U64],
                             int32_t *window_bits, int32_t *num_windows) {
@@ -995,7 +998,7 @@ int mira_msm_combine(int curve, const uint64_t *partials, size_t nparts, int32_t
 }
 int mira_set_tuning(int knob, int64_t value) {
     std::lock_guard<std::mutex> lk(g_lock);
-    if (knob < 0 || knob > MIRA_TUNE_SHARED_MIN_N) { set_error("unknown tuning knob"); return MIRA_E_BAD_ARG; }
+    if (knob < 0 || knob > MIRA_TUNE_PASS_ENTRIES_LOG || (knob == MIRA_TUNE_PASS_ENTRIES_LOG && value > 32)) { set_error("unknown tuning knob"); return MIRA_E_BAD_ARG; }
     g.tune[knob] = value;
     return MIRA_OK;
 }

@@ -159,6 +159,9 @@ struct MsmPlan {
     bool glv = false;
     const void *glv_bases = nullptr;
     bool stats = false;   // also histogram the bit lengths of the scalars (planning input of the next commit of this shape)
+    // a batch whose vectors are still in HOST memory (mira_msm_batch): h_batch[b] = vector b; they cross PCIe in point chunks beside
+    // the kernels, chunk k staged as count consecutive slices of its length (the stride of the digit kernel is then the chunk's)
+    const uint64_t *const *h_batch = nullptr;
     // bucket reduction (reduce_kernels.cuh, plan_reduction below): nsets bucket sets of 2^cb buckets each, chunks of 2^lambda
     // buckets, 2^kappa chunks per workgroup, 2^gamma workgroup nodes per set, `pieces` results per set; rquad: phase A by quads
     uint32_t nsets = 0, cb = 0, lambda = 0, kappa = 0, gamma = 0, pieces = 1;

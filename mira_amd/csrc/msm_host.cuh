@@ -73,11 +73,28 @@ template <class F, class FS>
 static int msm_launch_body(const Bases &bs, size_t first, const void *d_scalars, const void *h_scalars, size_t n, const MsmPlan &p,
                            uint64_t *host_windows /* count * W * 16 u64 */) {
     int rc;
-    // chunks: [0, ends[0]), [ends[0], ends[1]), ...  (one chunk unless the scalars are in host memory)
-    const std::vector<size_t> ends = (h_scalars && p.count == 1) ? host_chunks(n, tuned(MIRA_TUNE_HOST_CHUNK_MIN_N, (size_t)1 << 19)) : std::vector<size_t>{n};
+    // chunks: [0, ends[0]), [ends[0], ends[1]), ...  One chunk unless the scalars are in host memory (a single vector, or the vectors
+    // of a batch: the chunking is over POINTS, a chunk of a batch holds that range of every vector) or the commit is too long for
+    // the 32-bit entry offsets of one pass (n W >= 2^32: the reference's 2^27 .. 2^28-point keys, examples/groth16/main.rs:47-75).
+    const size_t mult = p.glv ? 2 : 1;                        // columns of the digit matrix per scalar
+    const size_t host_min = tuned(MIRA_TUNE_HOST_CHUNK_MIN_N, (size_t)1 << 19);
+    std::vector<size_t> ends;
+    if (h_scalars && p.count == 1) ends = host_chunks(n, host_min);
+    else if (p.h_batch) {
+        for (size_t e : host_chunks(n * p.count, host_min)) ends.push_back(std::min(n, (e + p.count - 1) / p.count));
+        ends.back() = n;
+        ends.erase(std::unique(ends.begin(), ends.end()), ends.end());
+    } else ends = {n};
+    {
+        const uint64_t pass_entries = (1ull << tuned(MIRA_TUNE_PASS_ENTRIES_LOG, 32)) - 1;          // (tests cut small commits this way)
+        const size_t max_chunk = std::max<size_t>(64, (size_t)(pass_entries / ((uint64_t)mult * p.Wt)) / 64 * 64);
+        std::vector<size_t> cut;
+        for (size_t k = 0, lo = 0; k < ends.size(); lo = ends[k++])
+            for (size_t at = lo; at < ends[k];) { at = std::min(ends[k], at + max_chunk); cut.push_back(at); }
+        ends.swap(cut);
+    }
     size_t nmax = 0;
     for (size_t k = 0, lo = 0; k < ends.size(); lo = ends[k++]) nmax = std::max(nmax, ends[k] - lo);
-    const size_t mult = p.glv ? 2 : 1;                        // columns of the digit matrix per scalar
     nmax *= mult;
     const size_t entries_max = nmax * p.Wt;
     if ((rc = g.digits.ensure(entries_max * 2))) return rc;
@@ -103,7 +120,7 @@ static int msm_launch_body(const Bases &bs, size_t first, const void *d_scalars,
     if ((rc = g.chunks.ensure(node_points * XYZZ29_BYTES))) return rc;
     if ((rc = g.window_sums.ensure((size_t)p.nsets * p.pieces * 128 + 1024))) return rc;   // pieces + the planning statistics
 #ifndef MIRA_CPU_EMU
-    if (h_scalars) {
+    if (h_scalars || p.h_batch) {
         if (!g.copy_stream) RT_CHECK(hipStreamCreateWithFlags(&g.copy_stream, hipStreamNonBlocking));
         while (g.copy_events.size() < ends.size()) {
             hipEvent_t e;
@@ -141,27 +158,33 @@ static int msm_launch_body(const Bases &bs, size_t first, const void *d_scalars,
     }
     for (size_t k = 0, lo = 0; k < ends.size(); lo = ends[k++]) {
         const size_t ns = ends[k] - lo, nc = ns * mult, entries = nc * p.Wt;   // ns scalars, nc columns of digits
-        const unsigned char *sc = reinterpret_cast<const unsigned char *>(d_scalars) + lo * 32;
+        // a chunk of a host batch is staged as `count` consecutive slices of ns scalars, behind the chunks before it
+        const unsigned char *sc = reinterpret_cast<const unsigned char *>(d_scalars) + (p.h_batch ? lo * p.count : lo) * 32;
+        const uint64_t stride_k = p.h_batch ? (uint64_t)ns : (uint64_t)p.stride;
         // per-window buckets: entries are chunk-local point indices; shared buckets: entries name table points
         const unsigned char *bases = p.shared ? reinterpret_cast<const unsigned char *>(p.shared_tables)
                                    : p.glv  ? reinterpret_cast<const unsigned char *>(p.glv_bases) + (first + lo) * 128
                                             : reinterpret_cast<const unsigned char *>(bs.d) + (first + lo) * 64;
         const uint32_t wgroup = p.shared ? p.W : 1u, idx_stride = p.shared ? (uint32_t)p.table_n : 0u, idx_first = p.shared ? (uint32_t)(first + lo) : 0u;
         const uint32_t add = k ? 1u : 0u;
-        if (h_scalars) {
+        if (h_scalars || p.h_batch) {
             // pageable or pinned, the copy engine moves it beside the kernels of the previous chunk
             hipStream_t cs = g.copy_stream ? g.copy_stream : st;
-            RT_CHECK(rt_h2d(const_cast<unsigned char *>(sc), reinterpret_cast<const unsigned char *>(h_scalars) + lo * 32, ns * 32, cs));
+            if (p.h_batch)
+                for (uint32_t b = 0; b < p.count; b++)
+                    RT_CHECK(rt_h2d(const_cast<unsigned char *>(sc) + (size_t)b * ns * 32, reinterpret_cast<const unsigned char *>(p.h_batch[b]) + lo * 32, ns * 32, cs));
+            else
+                RT_CHECK(rt_h2d(const_cast<unsigned char *>(sc), reinterpret_cast<const unsigned char *>(h_scalars) + lo * 32, ns * 32, cs));
             if (cs != st) RT_CHECK(rt_stream_wait(st, cs, g.copy_events[k]));
         }
         // histogram / scatter tiling of this chunk: about two workgroups per CU, at least 1024 points per tile
         const uint32_t tile = (std::max<uint32_t>(1024, ceil_div(nc, std::max<uint32_t>(1, 512 / p.Wt))) + 1023) / 1024 * 1024, ntiles = ceil_div(nc, tile);
         const bool staged = nc * p.count >= staged_min_n && p.c >= 9;   // a batch is count MSMs' worth of entries
         if (p.glv)
-            LAUNCH((k_digits<FS, true>), dim3(ceil_div(ns, 256), p.count), 256, 0, st, sc, (uint32_t)ns, (uint64_t)p.stride, p.c, p.W,
+            LAUNCH((k_digits<FS, true>), dim3(ceil_div(ns, 256), p.count), 256, 0, st, sc, (uint32_t)ns, stride_k, p.c, p.W,
                    reinterpret_cast<int16_t *>(g.digits.p), reinterpret_cast<uint32_t *>(g.counts.p), p.NB + 1, hist, hist_clear);
         else
-        LAUNCH(k_digits<FS>, dim3(ceil_div(nc, 256), p.count), 256, 0, st, sc, (uint32_t)nc, (uint64_t)p.stride, p.c, p.W,
+        LAUNCH(k_digits<FS>, dim3(ceil_div(nc, 256), p.count), 256, 0, st, sc, (uint32_t)nc, stride_k, p.c, p.W,
                reinterpret_cast<int16_t *>(g.digits.p), reinterpret_cast<uint32_t *>(g.counts.p), p.NB + 1, hist, hist_clear);
         tm_mark("digits");
         LAUNCH_BARRIER_FLEX(k_hist, dim3(ntiles, p.Wt), 1024, (size_t)p.B * 4, st, reinterpret_cast<const int16_t *>(g.digits.p), (uint32_t)nc,

@@ -25,6 +25,10 @@ def test_bench_gpus2_launches_two_ranks(emu_lib):
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2
     assert out["scaling"] == "strong" and out["config"]["total_pairs"] == 256 and out["config"]["pairs_per_gpu"] == 128
     assert out["ms_per_step"] > 0 and "EMULATION" in out["data"]
+    # the line diagnoses itself: what every rank held and measured, and that all ranks combined partials of one shape
+    assert [r["rank"] for r in out["ranks"]] == [0, 1] and all(r["pairs"] == 128 for r in out["ranks"])
+    assert all(r["partial_ms"] > 0 and r["exchange_us"] > 0 and r["combine_ms"] > 0 for r in out["ranks"])
+    assert out["agreed_window"] == {"window_bits": 8, "num_windows": 32, "same_on_all_ranks": True}
 
 
 def test_bench_gpus2_weak_variant(emu_lib):

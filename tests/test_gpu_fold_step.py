@@ -77,3 +77,62 @@ def test_msm_2p26_whole_partials_oracle(gpu_lib):
         assert (cm.combine_partials(cid, parts[g][None, :], 16, 16) == C.commit(cid, bases, sc)).all()
     assert (acc == whole).all()
     gpu_lib.free(d); key.close()
+
+
+def test_reference_largest_commit_14x2p24_and_k28_key_file(gpu_lib, tmp_path):
+    """The reference's largest real sizes (examples/groth16/main.rs:47-75: k = 24 tables over keys of 2^27 .. 2^28 points):
+    a witness commit of 14 x 2^24 = 234 881 024 pairs and a 2^28-point key through its cache file.
+    * the commit under 13-bit windows has 4.7 G sorted entries -- more than the 32-bit offsets of one pass -- and is cut into
+      point chunks inside the launch sequence; under 16-bit windows it fits one pass; eight chunk partials combined are the
+      same point; two 2^22-pair chunk partials are their chunks' commitments by the oracle;
+    * 2^28 pairs under 16-bit windows are exactly 2^32 entries: two passes; whole = two half partials combined;
+    * the 2^28-point key written as the reference's raw `[C]` file (16 GiB) and read back by mira_msm_register_bases_file with
+      the curve check: same commitment, same bytes at the chunk boundaries."""
+    import time
+    cid = 0
+    n28, n = 1 << 28, 14 << 24
+    key = cm.CommitmentKey.synthetic(cid, n28, seed=0x3238)
+    d = cm.synth_scalars_device(cid, n28, seed=0x3239)
+    timings = {}
+    try:
+        gpu_lib.check(gpu_lib.c.mira_msm_set_window_bits(16))
+        key.commit_device(d, 1 << 20)
+        t0 = time.perf_counter(); whole = key.commit_device(d, n); timings["commit_14x2p24_c16_ms"] = (time.perf_counter() - t0) * 1e3
+        G, per = 8, n // 8
+        parts = []
+        for g in range(G):
+            part, c, w = key.commit_partial_device(g * per, d + g * per * 32, per)
+            assert (c, w) == (16, 16)
+            parts.append(part)
+        assert (cm.combine_partials(cid, np.stack(parts), 16, 16) == whole).all()
+        t0 = time.perf_counter(); whole28 = key.commit_device(d, n28); timings["commit_2p28_c16_ms"] = (time.perf_counter() - t0) * 1e3      # 2^32 entries: two passes
+        halves = [key.commit_partial_device(h * (n28 // 2), d + h * (n28 // 2) * 32, n28 // 2)[0] for h in range(2)]
+        assert (cm.combine_partials(cid, np.stack(halves), 16, 16) == whole28).all()
+        gpu_lib.check(gpu_lib.c.mira_msm_set_window_bits(13))    # 20 windows: 4.7 G entries, two passes
+        t0 = time.perf_counter(); w13 = key.commit_device(d, n); timings["commit_14x2p24_c13_ms"] = (time.perf_counter() - t0) * 1e3
+        assert (w13 == whole).all()
+        # the oracle on two chunks of 2^22 pairs: the first, and one that straddles the boundary of the two passes
+        m = 1 << 22
+        for first in (0, n // 2 - m // 2):
+            part, c, w = key.commit_partial_device(first, d + first * 32, m, window_bits=13)
+            want = C.commit(cid, key.download(first, m), gpu_lib.download(d + first * 32, (m, 4)))
+            assert (cm.combine_partials(cid, part[None, :], c, w) == want).all()
+    finally:
+        gpu_lib.check(gpu_lib.c.mira_msm_set_window_bits(0))
+    path = tmp_path / "28.bin"
+    t0 = time.perf_counter(); key.save_to_file(path); timings["save_2p28_s"] = time.perf_counter() - t0
+    assert path.stat().st_size == n28 * 64
+    key.close()
+    t0 = time.perf_counter(); loaded = cm.CommitmentKey.load_from_file(cid, path, 28, validate=True); timings["load_2p28_validated_s"] = time.perf_counter() - t0
+    try:
+        gpu_lib.check(gpu_lib.c.mira_msm_set_window_bits(16))
+        assert (loaded.commit_device(d, n) == whole).all()
+        ref = cm.CommitmentKey.synthetic(cid, 4096, seed=0x3238, index0=(1 << 27) - 2048)
+        assert (loaded.download((1 << 27) - 2048, 4096) == ref.download()).all()
+        ref.close()
+    finally:
+        gpu_lib.check(gpu_lib.c.mira_msm_set_window_bits(0))
+        loaded.close(); gpu_lib.free(d)
+        path.unlink()
+    gpu_lib.check(gpu_lib.c.mira_trim(0, None))
+    print("largest-size timings:", {k: round(v, 3) for k, v in timings.items()})

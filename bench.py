@@ -577,7 +577,8 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
     try:
         k = 17
         n = 1 << k
-        plan = {cm.CURVE_BN256: (14 << k, 6), cm.CURVE_GRUMPKIN: (7 << k, 5)}
+        from harness import main_gate as MG_sched
+        plan = MG_sched.fold_step_msm_schedule(k)              # {curve: (witness length, cross terms)}: (14 << k, 6) and (7 << k, 5), derived from the reference's configure functions
         keys, wit, cross = {}, {}, {}
         for c, (nw, cnt) in plan.items():
             keys[c] = cm.CommitmentKey.synthetic(c, nw, seed=0x464F4C44 + c)

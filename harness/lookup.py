@@ -94,12 +94,14 @@ class LookupTrace:
     seq = (a, b, c, num): the circuit as the reference synthesises it (row 0 = a, b, c; then a XOR row and an addition row
     per further element, src/nifs/tests.rs:494-512) -- needs 2 num - 5 <= 2^k rows; seq = None: a synthetic trace of the same
     shape for large tables -- every row is, by a seeded choice, an XOR row over the table's range, an addition row over the
-    whole field, or empty (the copy constraints between rows are the permutation argument's business, not this path's)."""
+    whole field, or empty (the copy constraints between rows are the permutation argument's business, not this path's);
+    the choice is seeded by `structure_seed` (the selectors belong to the circuit), the values by `seed`."""
 
-    def __init__(self, k, mod, challenges, seq=None, seed=0):
+    def __init__(self, k, mod, challenges, seq=None, seed=0, structure_seed=0x5354):
         import random
         self.k, self.mod, self.rows = k, mod, 1 << k
         rows, rng = self.rows, random.Random(seed)
+        kinds = random.Random(structure_seed)                                # which rows carry which selector is the CIRCUIT's: the same for every trace
         r1, r2, r3 = challenges
         self.challenges = [c % mod for c in challenges]
         s_add, s_xor = [False] * rows, [False] * rows
@@ -117,7 +119,7 @@ class LookupTrace:
                 a, b, c = b, c, new_c
         else:
             for row in range(rows):
-                kind = rng.randrange(4)
+                kind = kinds.randrange(4)
                 if kind == 0:
                     x, y = rng.randrange(5), rng.randrange(5)
                     adv[0][row], adv[1][row], adv[2][row] = x, y, x ^ y; s_xor[row] = True

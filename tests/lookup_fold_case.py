@@ -80,7 +80,7 @@ def run_lookup_fold(lib, log_rows, traces, seed, sample_rows=6):
     live = [acc]
     try:
         for step, tr in enumerate(traces):
-            assert tr.selectors == t0.selectors or step == 0 or True            # the structure is the first trace's; only its fixed part matters below
+            assert tr.selectors == t0.selectors and tr.fixed == t0.fixed        # traces of ONE PlonkStructure
             tr.check_is_sat(cg.compressed) if rows <= 64 else None
             inc = DeviceTrace(lib, key, rows, tr.W, tr.challenges, 1)            # to_relax: u = 1, E = 0
             live.append(inc)

@@ -224,3 +224,20 @@ def test_cross_term_plan_equals_grouped_terms(emu_lib, field, T, count):
         assert mont_to_ints(got[k], mod) == [P.eval_expression(t.to_tuple(), both, r, rows, mod) for r in range(rows)], k
     for p in ptrs + [d]:
         emu_lib.free(p)
+
+
+def test_fold_step_schedule_is_derived():
+    """The k = 17 fold-step schedule -- 14 / 7 advice columns, 30 / 15 fixed, one combining challenge in the primary circuit,
+    6 / 5 cross terms, 13 MSM calls -- follows from the reference's `configure` functions (harness/main_gate.py:
+    ivc_circuit_shape cites them), not from a table copied by hand."""
+    primary, secondary = MG.ivc_circuit_shape(5, 1, 17), MG.ivc_circuit_shape(5, 0, 17)
+    assert (primary["num_advice"], primary["num_fixed"], primary["main_gates"]) == (14, 30, 2)
+    assert (secondary["num_advice"], secondary["num_fixed"], secondary["main_gates"]) == (7, 15, 1)
+    assert (primary["num_challenges"], secondary["num_challenges"]) == (1, 0)
+    assert (primary["eval_challenges"], secondary["eval_challenges"]) == (2, 1)                 # [y, u] and [u] per instance
+    assert (primary["folding_degree"], primary["cross_terms"]) == (7, 6) and (secondary["folding_degree"], secondary["cross_terms"]) == (6, 5)
+    assert primary["round_sizes"] == [14 << 17] and secondary["round_sizes"] == [7 << 17]
+    sched = MG.fold_step_msm_schedule(17)
+    assert sched == {0: (1835008, 6), 1: (917504, 5)}
+    assert sum(1 + terms for _, terms in sched.values()) == 13
+    assert sum(n + terms * (1 << 17) for n, terms in sched.values()) == (14 + 7 + 6 + 5) << 17   # 4.19 M scalar-point pairs per fold step

@@ -17,7 +17,9 @@ from oracle import cref as C
 pytestmark = pytest.mark.gpu
 
 K = 17
-PLAN = {cm.CURVE_BN256: (14 << K, 6), cm.CURVE_GRUMPKIN: (7 << K, 5)}   # (witness length, cross terms)
+from harness import main_gate as MG
+PLAN = MG.fold_step_msm_schedule(K)      # {curve: (witness length, cross terms)} derived from the reference's configure functions: (14 << K, 6), (7 << K, 5)
+assert PLAN == {cm.CURVE_BN256: (14 << K, 6), cm.CURVE_GRUMPKIN: (7 << K, 5)}
 
 
 def test_fold_step_k17_schedule(gpu_lib):

@@ -15,7 +15,9 @@ def test_lookup_structure_shape():
     assert len(gates) == 5 and ctx.num_challenges == 2 and ctx.num_fold_vars() == 3 + 5
     cg, ctx, _, _ = LK.compressed_fibo_lookup()
     assert cg.compressed.num_challenges() == 3 and ctx.num_challenges == 4
-    assert cg.degree == 4 and len(cg.grouped) == cg.degree + 1          # h * (l + r2) * u^.. : three variables and the lookup challenge
+    # degrees count folded variables (advice, lookup variables, challenges): the vanishing polynomial L - l has s_xor * out * r1^2 (3)
+    # and enters the combination under r3^3 -> 6, the highest of the five; six cross terms per fold
+    assert cg.degree == 6 and len(cg.grouped) == cg.degree + 1
     seq = LK.get_sequence(1, 3, 2, 7)
     assert seq == [1, 3, 2, 2, 3, 3, 2] and max(seq) < 5                # every XOR operand is in the 5 x 5 table
 
@@ -26,4 +28,4 @@ def test_three_rounds_fold_on_emulation(emu_lib):
     for a, b, c in ((1, 3, 2), (3, 2, 2)):
         seq = LK.get_sequence(a, b, c, 7)
         traces.append(LK.LookupTrace(5, MOD, [rng.randrange(MOD) for _ in range(3)], seq=(seq[0], seq[1], seq[2], 7)))
-    assert run_lookup_fold(emu_lib, 5, traces, seed=0x34) == 4
+    assert run_lookup_fold(emu_lib, 5, traces, seed=0x34) == 6

@@ -91,7 +91,9 @@ int mira_msm_precompute(uint64_t handle);
  * (k = k1 + k2 lambda, k P = k1 P + k2 phi(P)) -- the same bucket additions over half the windows: half the bucket reduction,
  * half the chain of doublings on the host.  The same points bit for bit; mira_msm_last_plan reports ceil(129 / c) windows.
  * Single commits and batches through the per-window path use it; commits served by a table set and ranks of a sharded MSM
- * (whose partials must have one shape on every rank) do not. */
+ * (whose partials must have one shape on every rank) do not.  Since round 4 the library builds the copy by itself for keys of
+ * up to 2^26 points the first time a commit of at most 2^21 pairs can use it (MIRA_TUNE_GLV_AUTO_MAX_LOG; an allocation
+ * failure just leaves the key without one): the call is only needed for longer keys or to pay the cost up front. */
 #define MIRA_TABLE_GLV 2
 int mira_msm_precompute_ex(uint64_t handle, int32_t window_bits);
 /* Validate every registered base against the curve equation on the GPU, as
@@ -192,6 +194,10 @@ int mira_msm_last_table_bits(int32_t *table_bits);
 /* log2 of the sorted entries (pairs x windows) one pass of the pipeline takes; a longer commit is cut into point chunks that
  * add into one set of buckets (default and maximum 32: the entry offsets are 32-bit; tests cut small commits with it) */
 #define MIRA_TUNE_PASS_ENTRIES_LOG 16
+/* log2 of the longest key whose endomorphism copy (MIRA_TABLE_GLV, 2 x the key's memory) the library builds BY ITSELF, at the
+ * first single commit or batch that can use it (commits of at most 2^21 pairs over keys of at least 2^12 points); default 26,
+ * 0 = only where mira_msm_precompute_ex(handle, MIRA_TABLE_GLV) was called */
+#define MIRA_TUNE_GLV_AUTO_MAX_LOG 17
 int mira_set_tuning(int knob, int64_t value);
 
 /* Read a range of the registered key back in the reference layout (cache file writing,

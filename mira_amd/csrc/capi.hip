@@ -213,23 +213,23 @@ static double plan_cost_us(uint32_t c, double n, uint32_t count, const double *b
 }
 
 // The GLV split (glv.cuh) has a table of its own: wall time in microseconds of one commit of 2^glv_log_n[r] uniform pairs -- twice
-// as many half-length scalars -- under width c (tools/glv_probe.py --calibrate, profiles/r03_k_glv.txt).  The widths that cut
+// as many half-length scalars -- under width c (tools/glv_probe.py --calibrate; re-measured in round 4 on the rebuilt bucket reduction, profiles/r04_c_glv.txt).  The widths that cut
 // 128 bits evenly stand out (9 at 2^17, 13 at 2^18 - 2^19, 16 beyond): a last window that holds only a few bits of every half is a
 // handful of very heavy buckets.
 static const int glv_log_n[11] = {10, 12, 14, 15, 16, 17, 18, 19, 20, 21, 22};
 static const double glv_wall_us[11][17] = {
     //                c = 5      6      7      8      9     10     11     12     13     14     15     16
-    {0, 0, 0, 0, 0,   256,   248,   245,   210,   246,   240,   310,   293,   332,   437,   530,   592},
-    {0, 0, 0, 0, 0,   239,   237,   264,   256,   275,   277,   295,   322,   311,   397,   566,   597},
-    {0, 0, 0, 0, 0,   297,   296,   301,   290,   349,   337,   347,   351,   369,   410,   533,   532},
-    {0, 0, 0, 0, 0,   361,   363,   347,   322,   339,   397,   427,   414,   404,   452,   579,   600},
-    {0, 0, 0, 0, 0,   479,   447,   436,   448,   392,   444,   516,   516,   456,   514,   625,   639},
-    {0, 0, 0, 0, 0,   705,   631,   605,   595,   529,   560,   575,   668,   535,   589,   692,   721},
-    {0, 0, 0, 0, 0,  1133,  1007,   934,   881,   857,   833,   815,   862,   715,   774,   850,   852},
-    {0, 0, 0, 0, 0,  2045,  1788,  1616,  1461,  1450,  1332,  1283,  1283,  1090,  1138,  1201,  1181},
-    {0, 0, 0, 0, 0,  4100,  3600,  3200,  2900,  2662,  2358,  2220,  2145,  1867,  1886,  1899,  1828},   // (c < 9: not measured, extrapolated)
-    {0, 0, 0, 0, 0,  8200,  7200,  6400,  5800,  5158,  4529,  4155,  3929,  3462,  3391,  3369,  3123},
-    {0, 0, 0, 0, 0, 16400, 14400, 12800, 11600, 10785,  9327,  8571,  7828,  7044,  6795,  6666,  6074},
+    {    0,     0,     0,     0,     0,   267,   259,   239,   219,   258,   236,   310,   272,   300,   409,   529,   495},
+    {    0,     0,     0,     0,     0,   246,   246,   257,   250,   272,   269,   282,   304,   271,   373,   532,   510},
+    {    0,     0,     0,     0,     0,   302,   309,   298,   286,   344,   327,   332,   332,   332,   393,   516,   441},
+    {    0,     0,     0,     0,     0,   369,   369,   342,   320,   336,   392,   414,   354,   360,   430,   505,   510},
+    {    0,     0,     0,     0,     0,   483,   455,   430,   439,   387,   437,   498,   496,   383,   465,   523,   568},
+    {    0,     0,     0,     0,     0,   734,   646,   593,   586,   522,   553,   561,   645,   492,   562,   615,   619},
+    {    0,     0,     0,     0,     0,  1143,   997,   918,   864,   840,   811,   807,   852,   669,   741,   778,   760},
+    {    0,     0,     0,     0,     0,  2121,  1815,  1595,  1439,  1434,  1319,  1245,  1243,  1032,  1089,  1113,  1075},
+    {    0,     0,     0,     0,     0,  3979,  3405,  2992,  2699,  2690,  2371,  2204,  2111,  1822,  1841,  1802,  1718},   // (c < 9: not measured, extrapolated)
+    {    0,     0,     0,     0,     0,  7880,  6743,  5925,  5345,  5327,  4622,  4219,  4064,  3488,  3418,  3450,  3102},
+    {    0,     0,     0,     0,     0, 16179, 13844, 12165, 10974, 10937,  9540,  8698,  8069,  7162,  6963,  6795,  6019},
 };
 static double glv_table_us(uint32_t c, double pairs) {
     const double x = std::log2(std::max(pairs, 1.0));
@@ -275,6 +275,7 @@ static MsmPlan make_plan(size_t n, int32_t forced_c, uint32_t count = 1, uint64_
         if (cost < best * 0.99) { best = cost; best_c = c; }    // ties go to the narrower window (fewer buckets: less that skewed data can upset)
     }
     p.c = forced_c ? (uint32_t)forced_c : best_c;
+    p.est_us = forced_c ? 0.0 : best;
     p.W = (bits + p.c - 1) / p.c;
     p.B = 1u << (p.c - 1);
     p.count = count; p.stride = stride; p.Wt = p.W * count;
@@ -486,6 +487,35 @@ static void sum_partials(const uint64_t *partials, size_t nparts, uint32_t W, ui
 // sharded: the caller is one rank of a point-chunk sharded MSM.  All ranks must produce the same
 // kind of partial, so the choice between table and per-window mode then depends only on whether
 // the handle has tables (and on the forced width), never on this rank's chunk length.
+// The endomorphism copy of a key, built the first time a commit takes the GLV split (MIRA_TUNE_GLV_AUTO_MAX_LOG): the split
+// halves the windows -- half the bucket reduction, half the host's chain of doublings -- for 2 x the key's memory and one
+// streaming kernel.  Keys shorter than 2^12 points are not worth a copy.  A failed allocation leaves the key as it is.
+static constexpr size_t GLV_AUTO_MIN_KEY = (size_t)1 << 12;
+static bool glv_possible(const Bases &bs) {                  // a copy exists, or the library may build one for this key
+    if (tuned(MIRA_TUNE_GLV, 1) == 0) return false;
+    if (bs.glv) return true;
+    const size_t max_log = tuned(MIRA_TUNE_GLV_AUTO_MAX_LOG, 26);
+    return !bs.glv_auto_failed && max_log != 0 && bs.n >= GLV_AUTO_MIN_KEY && bs.n <= ((size_t)1 << std::min<size_t>(max_log, 30));
+}
+static bool glv_ready(const Bases &bs) {                     // ... and it is there now
+    if (!glv_possible(bs)) return false;
+    if (bs.glv) return true;
+    Bases &mut = const_cast<Bases &>(bs);
+    const unsigned char *consts = reinterpret_cast<const unsigned char *>(g.consts.p);
+    const int rc = bs.curve == MIRA_CURVE_BN256 ? build_glv_bn256(mut, consts + 192) : build_glv_grumpkin(mut, consts + 224);
+    if (rc != MIRA_OK) { bs.glv_auto_failed = true; (void)rt_last(); return false; }
+    return bs.glv != nullptr;
+}
+// Plain path or GLV split for this commit?  With a forced width: the split wherever the key has (or may get) its copy, as
+// before.  Planned: both planners are asked -- their tables are measured walls of the two paths (tools/plan_calibrate.py,
+// tools/glv_probe.py --calibrate) -- and the split must be ahead by 2 %: it wins up to ~2^19 pairs (2^17: 0.49 against 0.53 ms)
+// and for the batches of a fold step, and loses from 2^20 on, where the decomposition in k_digits and the doubled point
+// stream cost more than the halved bucket reduction saves (profiles/r04_c_glv.txt).
+static bool choose_glv(const Bases &bs, const MsmPlan &plain, const MsmPlan &split) {
+    if (!glv_possible(bs)) return false;
+    if (plain.est_us > 0 && split.est_us > 0 && split.est_us >= 0.98 * plain.est_us) return false;
+    return glv_ready(bs);
+}
 // allow_pieces: the caller combines the points itself with horner_pieces (a commit of this process); else the public partial
 // format, one point per window (*shape then has P = 1).
 static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scalars, size_t n, uint64_t *out_partial,
@@ -513,16 +543,22 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
     // kernels and read after the synchronisation that ends it.
     const size_t hist_min_n = tuned(MIRA_TUNE_PLAN_HIST_MIN_N, PLAN_HIST_MIN_N);
     const bool can_hist = !table_mode && !sharded && forced_c == 0 && requested_c == 0 && n >= hist_min_n && d_scalars;
-    const uint32_t *stat = (can_hist && bs.stat_n == n) ? bs.stat_hist : nullptr;
-    const Bases::SharedSet *set = (tables_ok && !table_mode && (sharded || n >= tuned(MIRA_TUNE_SHARED_MIN_N, TABLE16_MIN_N))) ? pick_shared(bs, n, 1, sharded, stat) : nullptr;
+    // statistics are consumed only by the kind of path that collected them: the halves of the GLV split have other lengths than
+    // the scalars they come from
+    const uint32_t *stat_any = (can_hist && bs.stat_n == n) ? bs.stat_hist : nullptr;
+    const uint32_t *stat_full = bs.stat_kind == 0 ? stat_any : nullptr;
+    const Bases::SharedSet *set = (tables_ok && !table_mode && (sharded || n >= tuned(MIRA_TUNE_SHARED_MIN_N, TABLE16_MIN_N))) ? pick_shared(bs, n, 1, sharded, stat_full) : nullptr;
     const bool use_hist = can_hist && !set;
     // a rank of a sharded MSM that was not given a width takes 16, whatever its chunk length: partials
     // of different widths cannot be combined, and chunk lengths differ between ranks
     const int32_t width = requested_c ? requested_c : (sharded && forced_c == 0) ? 16 : forced_c;
     // the GLV split (glv.cuh): 2 n half-length scalars over the interleaved key; not for ranks of a sharded MSM (their partials
     // must have one shape whatever each rank's key holds) nor beside a table set
-    const bool glv = bs.glv && !set && !table_mode && !sharded && n < (1ull << 30) && tuned(MIRA_TUNE_GLV, 1) != 0;
-    MsmPlan p = glv ? make_plan(2 * n, width, 1, 0, use_hist ? stat : nullptr, GLV_BITS) : make_plan(n, width, 1, 0, use_hist ? stat : nullptr);
+    const bool glv_ok = !set && !table_mode && !sharded && n != 0 && n < (1ull << 30) && glv_possible(bs);
+    const MsmPlan p_plain = make_plan(n, width, 1, 0, (use_hist && bs.stat_kind == 0) ? stat_any : nullptr);
+    const MsmPlan p_split = glv_ok ? make_plan(2 * n, width, 1, 0, (use_hist && bs.stat_kind == 1) ? stat_any : nullptr, GLV_BITS) : p_plain;
+    const bool glv = glv_ok && choose_glv(bs, p_plain, p_split);
+    MsmPlan p = glv ? p_split : p_plain;
     p.glv = glv; p.glv_bases = glv ? bs.glv : nullptr;
     // (a commit of n W >= 2^32 entries is cut into point chunks inside the launch sequence, msm_host.cuh; the 31-bit limit is the
     // point index of a sorted entry, the sign in bit 31)
@@ -551,7 +587,7 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
                                           : msm_launch_grumpkin(bs, first, d_scalars, h_scalars, n, ps, out_partial);
         if (rc == MIRA_OK && can_hist) {                     // msm_launch ends with a stream synchronisation
             memcpy(bs.stat_hist, g.hist_host, sizeof bs.stat_hist);
-            bs.stat_n = n;
+            bs.stat_n = n; bs.stat_kind = 0;
         }
         return rc;
     }
@@ -566,7 +602,7 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
     rc = bs.curve == MIRA_CURVE_BN256 ? msm_launch_bn256(bs, first, d_scalars, h_scalars, n, p, out_partial) : msm_launch_grumpkin(bs, first, d_scalars, h_scalars, n, p, out_partial);
     if (rc == MIRA_OK && use_hist) {                         // msm_launch ends with a stream synchronisation
         memcpy(bs.stat_hist, g.hist_host, sizeof bs.stat_hist);
-        bs.stat_n = n;
+        bs.stat_n = n; bs.stat_kind = glv ? 1 : 0;
     }
     return rc;
 }
@@ -627,7 +663,11 @@ static int msm_batch_device_locked(uint64_t handle, const void *d_scalars, size_
         return MIRA_OK;
     }
     // the GLV split (glv.cuh) where the key has its endomorphism copy: 2 n half-length scalars per commitment, half the windows
-    const bool glv = bs.glv && n < (1ull << 30) && tuned(MIRA_TUNE_GLV, 1) != 0;
+    bool glv = n < (1ull << 30) && glv_possible(bs);
+    if (glv) {                                               // the planners' estimates for a batch of this shape decide (choose_glv)
+        const uint32_t shape = (uint32_t)std::min<size_t>(count, 8);
+        glv = choose_glv(bs, make_plan(n, forced_c, shape, stride), make_plan(2 * n, forced_c, shape, stride, nullptr, GLV_BITS));
+    }
     const size_t nv = glv ? 2 * n : n;
     const uint32_t bits = glv ? GLV_BITS : 256;
     MsmPlan p1 = make_plan(nv, forced_c, 1, 0, nullptr, bits);
@@ -998,7 +1038,7 @@ int mira_msm_combine(int curve, const uint64_t *partials, size_t nparts, int32_t
 }
 int mira_set_tuning(int knob, int64_t value) {
     std::lock_guard<std::mutex> lk(g_lock);
-    if (knob < 0 || knob > MIRA_TUNE_PASS_ENTRIES_LOG || (knob == MIRA_TUNE_PASS_ENTRIES_LOG && value > 32)) { set_error("unknown tuning knob"); return MIRA_E_BAD_ARG; }
+    if (knob < 0 || knob > MIRA_TUNE_GLV_AUTO_MAX_LOG || (knob == MIRA_TUNE_PASS_ENTRIES_LOG && value > 32)) { set_error("unknown tuning knob"); return MIRA_E_BAD_ARG; }
     g.tune[knob] = value;
     return MIRA_OK;
 }
@@ -1216,6 +1256,8 @@ int mira_lincomb_multi_device(int field, void *const *d_outs, size_t num_outs, c
         if (n && !d_vecs[k]) { set_error("null vector"); return MIRA_E_BAD_ARG; }
     for (size_t m = 0; m < num_outs; m++) {
         if (n && !d_outs[m]) { set_error("null output"); return MIRA_E_BAD_ARG; }
+        for (size_t q = 0; q < m; q++)
+            if (n && d_outs[m] == d_outs[q]) { set_error("two outputs share one buffer"); return MIRA_E_BAD_ARG; }
         for (size_t k = 0; k < num_vecs; k++)
             if (n && d_outs[m] == d_vecs[k]) { set_error("an output aliases an input vector"); return MIRA_E_BAD_ARG; }
     }

@@ -129,11 +129,13 @@ struct Bases {
     // shared-bucket table sets (8 .. 16 bits, msm_host.cuh): any number of widths beside each other, each W x the key
     struct SharedSet { void *p; uint32_t c, W; };
     std::vector<SharedSet> shared;
-    void *glv = nullptr;      // the interleaved key of the GLV split, 2 n points (mira_msm_precompute_ex(handle, MIRA_TABLE_GLV)), or null
+    mutable void *glv = nullptr;   // the interleaved key of the GLV split, 2 n points (mira_msm_precompute_ex(handle, MIRA_TABLE_GLV), or built at the first commit that can use it), or null
+    mutable bool glv_auto_failed = false;   // the automatic build could not allocate: not tried again
     // bit-length histogram of the scalars of the previous commit of stat_n elements over this key
     // (planning input for the next one of the same length; never affects a result)
     mutable uint32_t stat_hist[256] = {0};
     mutable size_t stat_n = 0;
+    mutable int stat_kind = 0;     // what was histogrammed: 0 = whole scalars (per-window path, shared-bucket sets), 1 = the halves of the GLV split
 };
 
 void tm_begin();
@@ -166,6 +168,7 @@ struct MsmPlan {
     // buckets, 2^kappa chunks per workgroup, 2^gamma workgroup nodes per set, `pieces` results per set; rquad: phase A by quads
     uint32_t nsets = 0, cb = 0, lambda = 0, kappa = 0, gamma = 0, pieces = 1;
     bool rquad = false;
+    double est_us = 0;    // the planner's estimate for this plan (0: width forced, nothing estimated)
 };
 
 // first bit position of piece p of P over the cb bits of a bucket index (p = P: cb)

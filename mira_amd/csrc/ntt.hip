@@ -108,8 +108,11 @@ static int ntt_prepare_tables(uint32_t log_n, const uint64_t omega[4], const HFr
     // an evicted set that is far larger than the new one goes back to the allocator (a 2^24 set is 0.8 GB)
     if (g.ntt_set[slot].cap > 4 * off + ((size_t)1 << 20)) g.ntt_set[slot].release();
     if ((rc = g.ntt_set[slot].ensure(off))) {
-        // the n-entry table is an optimisation: without the memory for it the two-table product still works
-        if (full0) return ntt_prepare_tables(log_n, omega, scale261, t, false);
+        // the n-entry table is an optimisation: without the memory for it the two-table product still works.  The slot that
+        // could not be grown is empty now (DevBuf::ensure released it): it goes back to the FRONT of the replacement order so that
+        // the retry takes it again instead of evicting a second cached set, and the failed attempt's message does not outlive it.
+        g.ntt_set_stamp[slot] = 0;
+        if (full0) { set_error(""); return ntt_prepare_tables(log_n, omega, scale261, t, false); }
         return rc;
     }
     if ((rc = g.ntt_consts.ensure(256))) return rc;

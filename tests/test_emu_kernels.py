@@ -471,6 +471,38 @@ def test_emu_host_scalars_in_chunks(emu_lib, tune):
             emu_lib.check(emu_lib.c.mira_msm_set_window_bits(0))
 
 
+def test_emu_endomorphism_copy_built_at_first_use(emu_lib, tune):
+    """MIRA_TUNE_GLV_AUTO_MAX_LOG: a key of at least 2^12 points gets its endomorphism copy the first time a commit can use it --
+    no precompute call; the commit then has ceil(128 / c) windows and the oracle's point.  Switched off (0), or for a key longer
+    than the limit, the plain path stays; ranks of a sharded MSM never take it."""
+    cid, n, m = 1, 1 << 12, 180
+    key = cm.CommitmentKey.synthetic(cid, n, seed=97, lib=emu_lib)
+    bs = key.download(0, m)
+    sc = C.synth_scalars(cid, m, seed=98)
+    want = C.commit(cid, bs, sc)
+    cc, ww = ctypes.c_int32(), ctypes.c_int32()
+
+    def windows():
+        emu_lib.check(emu_lib.c.mira_msm_last_plan(ctypes.byref(cc), ctypes.byref(ww)))
+        return ww.value * cc.value
+    # (a FORCED width takes the split wherever the key may have its copy; a planned commit asks both planners and takes the split
+    # only where it is estimated ahead -- from ~2^12 to ~2^19 pairs, sizes the emulation does not reach)
+    key.set_window_bits(9)
+    tune(_lib.TUNE_GLV_AUTO_MAX_LOG, 0)
+    assert (key.commit(sc) == want).all() and windows() >= 254          # no copy, no split
+    tune(_lib.TUNE_GLV_AUTO_MAX_LOG, 11)                                # the key is longer than 2^11 points: still none
+    assert (key.commit(sc) == want).all() and windows() >= 254
+    tune(_lib.TUNE_GLV_AUTO_MAX_LOG, -1)                                # default: built now, used from now on
+    assert (key.commit(sc) == want).all() and 127 <= windows() < 160
+    assert (key.commit_batch([sc, sc[::-1].copy()]) == np.stack([want, C.commit(cid, bs, sc[::-1].copy())])).all() and 127 <= windows() < 160
+    key.set_window_bits(0)
+    assert (key.commit(sc) == want).all() and windows() >= 254          # planned, 180 pairs: the plain path is estimated ahead
+    d = emu_lib.alloc(m * 32); emu_lib.upload(d, sc)
+    part, c, w = key.commit_partial_device(0, d, m, window_bits=9)      # a rank of a sharded MSM: the plain shape
+    assert (c, w) == (9, 29) and (cm.combine_partials(cid, part[None, :], c, w, lib=emu_lib) == want).all()
+    emu_lib.free(d); key.close()
+
+
 def test_emu_long_commits_and_host_batches_in_chunks(emu_lib, tune):
     """Two more users of the chunk path of msm_host.cuh: a commit of more sorted entries than one pass takes (n W >= 2^32 on
     the GPU: the reference's 2^27 .. 2^28-point keys; here the pass is shrunk by MIRA_TUNE_PASS_ENTRIES_LOG) is cut into point

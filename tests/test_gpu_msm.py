@@ -14,6 +14,16 @@ from oracle import pyref as P
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["endomorphism copy at first use", "plain keys"])
+def glv_auto(request, gpu_lib):
+    """Every test of this file runs twice: with the library's default -- a key of >= 2^12 points gets its endomorphism copy at the
+    first commit of <= 2^21 pairs, which then takes the GLV split (MIRA_TUNE_GLV_AUTO_MAX_LOG) -- and with that switched off, so
+    that the plain per-window path keeps the coverage it had before the copy became automatic."""
+    gpu_lib.tune(_lib.TUNE_GLV_AUTO_MAX_LOG, -1 if request.param.startswith("endo") else 0)
+    yield request.param
+    gpu_lib.tune(_lib.TUNE_GLV_AUTO_MAX_LOG, -1)
+
+
 @pytest.mark.parametrize("cid", [0, 1])
 def test_synth_generators(gpu_lib, cid):
     n = 3000
@@ -391,7 +401,8 @@ def test_glv_split_every_width(gpu_lib, cid, log_n):
     try:
         assert (key.commit_device(d, n) == before).all()
         c0, w0 = last_plan()
-        assert w0 == -(-128 // c0)
+        # planned widths: both planners are asked and the split is taken where it is estimated ahead (up to ~2^19 pairs)
+        assert w0 == (-(-128 // c0) if log_n <= 18 else -(-256 // c0))
         assert (key.commit_device(dw, n) == before_w).all() and (key.commit_device(dw, n) == before_w).all()   # the second one planned by the first one's statistics
         assert (key.commit_device(de, n) == before_e).all()
         assert (key.commit_device(d, m) == before_m).all()
@@ -404,7 +415,7 @@ def test_glv_split_every_width(gpu_lib, cid, log_n):
                 assert (key.commit_device(dw, n) == before_w).all(), c
         gpu_lib.check(gpu_lib.c.mira_msm_set_window_bits(0))
         assert (key.commit_batch_device(d, n // 8, 5, stride=n // 8 + 7) == before_b).all()
-        assert last_plan()[1] == -(-128 // last_plan()[0])
+        assert last_plan()[1] in (-(-128 // last_plan()[0]), -(-256 // last_plan()[0]))
         for c in (8, 13, 16):
             gpu_lib.check(gpu_lib.c.mira_msm_set_window_bits(c))
             assert (key.commit_batch_device(d, n // 8, 5, stride=n // 8 + 7) == before_b).all(), c

@@ -229,5 +229,8 @@ def test_lincomb_multi_matches_single_lincombs(emu_lib):
     bad = (ctypes.c_void_p * M)(d_v[0], d_multi[1], d_multi[2])
     assert lib.c.mira_lincomb_multi_device(field, bad, M, vp, J, coeffs.ctypes.data_as(ctypes.c_void_p), n) == _lib_mod.MIRA_E_BAD_ARG
     assert lib.c.mira_lincomb_multi_device(field, (ctypes.c_void_p * 9)(*([d_one] * 9)), 9, vp, J, coeffs.ctypes.data_as(ctypes.c_void_p), n) == _lib_mod.MIRA_E_BAD_ARG
+    twice = (ctypes.c_void_p * M)(d_multi[0], d_multi[1], d_multi[0])        # two outputs in one buffer: last writer would win
+    assert lib.c.mira_lincomb_multi_device(field, twice, M, vp, J, coeffs.ctypes.data_as(ctypes.c_void_p), n) == _lib_mod.MIRA_E_BAD_ARG
+    assert b"share one buffer" in lib.c.mira_last_error()
     for p in d_v + d_multi + [d_one]:
         lib.free(p)

@@ -469,6 +469,27 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
     finally:
         lib.check(lib.c.mira_msm_set_window_bits(0))
 
+    # ---- the reference's largest real commits (examples/groth16/main.rs:47-75: k = 24 tables over 2^27 .. 2^28-point keys):
+    # a 14 x 2^24-pair witness commit and a 2^28-pair commit -- the latter is 2^32 sorted entries under 16-bit windows, more than
+    # the 32-bit entry offsets of one pass: cut into point chunks inside the launch sequence (msm_host.cuh)
+    try:
+        big = {}
+        n28 = 1 << 28
+        key = cm.CommitmentKey.synthetic(cm.CURVE_BN256, n28, seed=0x3238)
+        d = cm.synth_scalars_device(cm.CURVE_BN256, n28, seed=0x3239)
+        for name, n in (("14x2p24", 14 << 24), ("2p28", n28)):
+            key.commit_device(d, n)
+            t0 = time.perf_counter(); key.commit_device(d, n); dt = time.perf_counter() - t0
+            c_, w_ = ctypes.c_int32(), ctypes.c_int32()
+            lib.check(lib.c.mira_msm_last_plan(ctypes.byref(c_), ctypes.byref(w_)))
+            big[name] = {"pairs": n, "ms": round(dt * 1e3, 2), "M_pairs_per_s": round(n / dt / 1e6, 1), "window_bits": c_.value,
+                         "passes": -(-(n * w_.value) // ((1 << 32) - 1))}
+        key.close(); lib.free(d)
+        lib.check(lib.c.mira_trim(0, None))
+        ex["msm_reference_largest"] = big
+    except Exception as e:
+        ex["msm_reference_largest"] = {"error": repr(e)}
+
     # ---- the boundary's real cost: commit(&self, v: &[C::Scalar]) receives HOST memory
     # (src/commitment.rs:78).  mira_msm cuts the scalars into point chunks whose PCIe copies run beside
     # the kernels of the previous chunk; beside it the same call with one up-front copy (chunking off)
@@ -596,6 +617,11 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
                 else:
                     pts.extend(keys[c].commit_device(cross[c] + i * n * 32, n) for i in range(cnt))
             return pts
+        # The figures WITHOUT suffix are the per-window path on plain keys, as in rounds 1 - 3: the library's automatic endomorphism
+        # copy (round 4: built at the first commit that takes the GLV split) is switched off for them, so that they stay comparable;
+        # the *_glv figures below are what a caller gets since round 4 WITHOUT any opt-in.
+        from mira_amd import _lib as L_
+        lib.tune(L_.TUNE_GLV_AUTO_MAX_LOG, 0)
         run(False); run(True)                                   # warm-up
         def median_ms(batched, reps=5):
             ts, pts = [], None
@@ -626,11 +652,10 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
         single = []
         for _ in range(9):
             t0 = time.perf_counter(); keys[cm.CURVE_BN256].commit_device(cross[cm.CURVE_BN256], n); single.append((time.perf_counter() - t0) * 1e3)
-        # opt-in, 2 x the key's HBM: the endomorphism copy (mira_msm_precompute_ex(handle, MIRA_TABLE_GLV)) -- single commits split
-        # every scalar into two 127-bit halves over half the windows; the same 13 calls, one per commit, and the batched form
-        from mira_amd import _lib as L_
-        for c in plan:
-            keys[c].precompute(L_.TABLE_GLV)
+        # the library's default since round 4, 2 x the key's HBM: the endomorphism copy, built by the first commit that takes the
+        # split -- every scalar as two 127-bit halves over half the windows wherever the planners estimate the split ahead; the same
+        # 13 calls, one per commit, and the batched form
+        lib.tune(L_.TUNE_GLV_AUTO_MAX_LOG, -1)                   # the default: both keys get their copies inside the first commits below
         run(False)
         tglv, single_glv = [], []
         for _ in range(5):
@@ -843,6 +868,8 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
                 spans["witness_commit"] += t1 - t0; spans["evaluation"] += t2 - t1; spans["commit"] += t3 - t2; spans["fold"] += t4 - t3
                 outs[c] = dict(w_commit=w_commit, t_commits=t_commits, d_e_new=d_e_new, folded_w=folded_w, folded_e=folded_e)
             return spans, outs
+        from mira_amd import _lib as L_
+        lib.tune(L_.TUNE_GLV_AUTO_MAX_LOG, 0)                   # `ms`: plain keys as in rounds 1 - 3 (comparable); `ms_glv` below: the library's default since round 4
         fold_step()
         walls_i = []
         for _ in range(5):
@@ -869,10 +896,9 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
                                             "+ interpolation: the same vectors as the reference's grouped graphs, which the CPU leg evaluates; every evaluation point through its own run-time "
                                             "compiled kernel, built once per circuit in specialize_s -- ms_interpreted_graphs: through the graph interpreter, as in earlier rounds), "
                                             "batched cross-term commits, W / E folding and instance folding (mira_g1_fold_commitments, host threads); span names follow the reference's tracing spans"}
-        # opt-in, 2 x the keys' HBM: the same chain with the endomorphism copies of both keys (the GLV split)
-        from mira_amd import _lib as L_
-        for s_ in st.values():
-            s_["key"].precompute(L_.TABLE_GLV)
+        # the library's default since round 4 (2 x the keys' HBM): the same chain with the endomorphism copies of both keys, built by the
+        # first commits below (the GLV split)
+        lib.tune(L_.TUNE_GLV_AUTO_MAX_LOG, -1)
         fold_step()
         walls_g = []
         for _ in range(5):
@@ -927,6 +953,26 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
     except Exception as e:
         import traceback
         ex["nifs_fold_step_k17"] = {"error": repr(e), "trace": traceback.format_exc()[-600:]}
+
+    # ---- specialised cross-term kernels, cold and cached (mira_graph_set_cache_dir): both circuits of the fold step specialised in a
+    # fresh process that compiles every kernel, then in a second fresh process that finds the code objects in the directory
+    try:
+        import subprocess
+        import tempfile
+        probe = os.path.join(ROOT, "tools", "jit_cache_probe.py")
+        legs = {}
+        with tempfile.TemporaryDirectory() as cache_dir:
+            os.chmod(cache_dir, 0o700)
+            for leg in ("cold", "cached"):
+                r = subprocess.run([sys.executable, probe, cache_dir], capture_output=True, text=True, timeout=600)
+                legs[leg] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else {"error": r.stderr[-400:]}
+            legs["files"] = len(os.listdir(cache_dir))
+        for leg in ("cold", "cached"):
+            if "error" not in legs[leg]:
+                legs[leg + "_specialize_s"] = round(sum(v["seconds"] for v in legs[leg].values()), 3)
+        ex["specialize_cold_and_cached"] = legs
+    except Exception as e:
+        ex["specialize_cold_and_cached"] = {"error": repr(e)}
 
     # ---- commitment-key cache file -> HBM -------------------------------------------
     # load_or_setup_cache (src/commitment.rs:134-166) = load_from_file + is_on_curve over every point; the only timing the

@@ -511,9 +511,11 @@ static bool glv_ready(const Bases &bs) {                     // ... and it is th
 // tools/glv_probe.py --calibrate) -- and the split must be ahead by 2 %: it wins up to ~2^19 pairs (2^17: 0.49 against 0.53 ms)
 // and for the batches of a fold step, and loses from 2^20 on, where the decomposition in k_digits and the doubled point
 // stream cost more than the halved bucket reduction saves (profiles/r04_c_glv.txt).
-static bool choose_glv(const Bases &bs, const MsmPlan &plain, const MsmPlan &split) {
+static bool choose_glv(const Bases &bs, const MsmPlan &plain, const MsmPlan &split, size_t pairs) {
     if (!glv_possible(bs)) return false;
-    if (plain.est_us > 0 && split.est_us > 0 && split.est_us >= 0.98 * plain.est_us) return false;
+    if (plain.est_us > 0 && split.est_us > 0) {
+        if (split.est_us >= 0.98 * plain.est_us) return false;
+    } else if (!bs.glv && pairs > ((size_t)1 << 19)) return false;     // forced width, no estimates: a copy the caller asked for is used; none is built for sizes the split loses at
     return glv_ready(bs);
 }
 // allow_pieces: the caller combines the points itself with horner_pieces (a commit of this process); else the public partial
@@ -557,7 +559,7 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
     const bool glv_ok = !set && !table_mode && !sharded && n != 0 && n < (1ull << 30) && glv_possible(bs);
     const MsmPlan p_plain = make_plan(n, width, 1, 0, (use_hist && bs.stat_kind == 0) ? stat_any : nullptr);
     const MsmPlan p_split = glv_ok ? make_plan(2 * n, width, 1, 0, (use_hist && bs.stat_kind == 1) ? stat_any : nullptr, GLV_BITS) : p_plain;
-    const bool glv = glv_ok && choose_glv(bs, p_plain, p_split);
+    const bool glv = glv_ok && choose_glv(bs, p_plain, p_split, n);
     MsmPlan p = glv ? p_split : p_plain;
     p.glv = glv; p.glv_bases = glv ? bs.glv : nullptr;
     // (a commit of n W >= 2^32 entries is cut into point chunks inside the launch sequence, msm_host.cuh; the 31-bit limit is the
@@ -666,7 +668,7 @@ static int msm_batch_device_locked(uint64_t handle, const void *d_scalars, size_
     bool glv = n < (1ull << 30) && glv_possible(bs);
     if (glv) {                                               // the planners' estimates for a batch of this shape decide (choose_glv)
         const uint32_t shape = (uint32_t)std::min<size_t>(count, 8);
-        glv = choose_glv(bs, make_plan(n, forced_c, shape, stride), make_plan(2 * n, forced_c, shape, stride, nullptr, GLV_BITS));
+        glv = choose_glv(bs, make_plan(n, forced_c, shape, stride), make_plan(2 * n, forced_c, shape, stride, nullptr, GLV_BITS), n * shape);
     }
     const size_t nv = glv ? 2 * n : n;
     const uint32_t bits = glv ? GLV_BITS : 256;

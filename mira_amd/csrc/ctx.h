@@ -188,6 +188,9 @@ static inline void plan_reduction(MsmPlan &p, uint32_t want_pieces) {
     p.rquad = g.tune[MIRA_TUNE_REDUCE_QUAD] >= 0 ? g.tune[MIRA_TUNE_REDUCE_QUAD] != 0 : chunks_q * 4 <= 98304;
     p.lambda = std::min<uint32_t>(p.rquad ? 2 : 3, p.cb);
     if (g.tune[MIRA_TUNE_REDUCE_LAMBDA] >= 1) p.lambda = std::min<uint32_t>((uint32_t)g.tune[MIRA_TUNE_REDUCE_LAMBDA], p.cb);
+    // k_set_finish holds the 2^gamma nodes of a set in LDS, (kappa + 2) points each: with 128 quads per workgroup (kappa = 7) that is
+    // gamma <= 6, i.e. eta <= 13 -- a 16-bit set in chunks of two buckets would need more: wider chunks there (tuning knobs included)
+    while (p.rquad && p.cb - p.lambda > 13) p.lambda++;
     const uint32_t eta = p.cb - p.lambda;
 #ifdef MIRA_CPU_EMU
     p.kappa = std::min<uint32_t>(eta, 3);                                      // emulated lanes are OS threads: small workgroups, a taller second tree

@@ -13,7 +13,9 @@
 
 #ifdef MIRA_CPU_EMU
 static constexpr uint32_t FIXUP_HEAVY_GRID = 4;     // emulated lanes are OS threads: keep the idle grid small (stage A: a quarter of it)
+static constexpr uint32_t FIXUP_HEAVY_BLOCKS = 1;
 #else
+static constexpr uint32_t FIXUP_HEAVY_BLOCKS = 256; // workgroups of k_fixup_all that take the heavy sub-jobs: one per CU (they leave at once when there are none)
 static constexpr uint32_t FIXUP_HEAVY_GRID = 1024;   // waves of either heavy stage = 256 workgroups of 256 lanes, one per CU (the sub-jobs of stage A are sized to just fill them; dispatching 1024 mostly idle workgroups alone took 15 us)
 #endif
 
@@ -226,21 +228,20 @@ static int msm_launch_body(const Bases &bs, size_t first, const void *d_scalars,
             LAUNCH((k_accumulate<F, true>), ceil_div(p.T, 128), 128, 0, st, reinterpret_cast<const uint32_t *>(g.sorted_idx.p),
                    reinterpret_cast<const uint32_t *>(g.offsets.p), p.NB, bases, (const uint32_t *)plan,
                    reinterpret_cast<unsigned char *>(g.bucket_sums.p), reinterpret_cast<unsigned char *>(g.head_part.p),
-                   reinterpret_cast<unsigned char *>(g.tail_part.p), reinterpret_cast<uint32_t *>(g.tail_key.p));
+                   reinterpret_cast<unsigned char *>(g.tail_part.p), reinterpret_cast<uint32_t *>(g.tail_key.p), heavy_count, heavy_runs, heavy_subs);
         else
             LAUNCH((k_accumulate<F, false>), ceil_div(p.T, 128), 128, 0, st, reinterpret_cast<const uint32_t *>(g.sorted_idx.p),
                    reinterpret_cast<const uint32_t *>(g.offsets.p), p.NB, bases, (const uint32_t *)plan,
                    reinterpret_cast<unsigned char *>(g.bucket_sums.p), reinterpret_cast<unsigned char *>(g.head_part.p),
-                   reinterpret_cast<unsigned char *>(g.tail_part.p), reinterpret_cast<uint32_t *>(g.tail_key.p));
+                   reinterpret_cast<unsigned char *>(g.tail_part.p), reinterpret_cast<uint32_t *>(g.tail_key.p), heavy_count, heavy_runs, heavy_subs);
         tm_mark("accumulate");
         const uint32_t fix_by_bucket = p.NB < p.T ? p.NB : 0u;   // fewer buckets than segments: index the fix-up by bucket
         const uint32_t fix_items = fix_by_bucket ? fix_by_bucket : p.T;
-        LAUNCH((k_fixup<F, true>), ceil_div((uint64_t)fix_items * 4, 128), 128, 0, st, (const uint32_t *)plan, reinterpret_cast<const uint32_t *>(g.offsets.p),
-               reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
-               reinterpret_cast<const uint32_t *>(g.tail_key.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p), heavy_count, heavy_runs, heavy_subs, fix_by_bucket);
-        LAUNCH_BARRIER(k_fixup_heavy_a<F>, (FIXUP_HEAVY_GRID + 3) / 4, HEAVY_BLOCK_A, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_subs, (const U4 *)heavy_runs,
-                       reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
-                       reinterpret_cast<unsigned char *>(g.heavy_out.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p));
+        // the short chains and the sub-jobs of the heavy runs (listed by k_accumulate) side by side in one launch
+        LAUNCH_BARRIER(k_fixup_all<F>, FIXUP_HEAVY_BLOCKS + ceil_div(fix_items, HEAVY_BLOCK_A / 4), HEAVY_BLOCK_A, 0, st, FIXUP_HEAVY_BLOCKS, (const uint32_t *)plan,
+                       reinterpret_cast<const uint32_t *>(g.offsets.p), reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
+                       reinterpret_cast<const uint32_t *>(g.tail_key.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p), fix_by_bucket,
+                       (const uint32_t *)heavy_count, (const U4 *)heavy_subs, (const U4 *)heavy_runs, reinterpret_cast<unsigned char *>(g.heavy_out.p));
         LAUNCH_BARRIER(k_fixup_heavy_b<F>, (FIXUP_HEAVY_GRID + 3) / 4, HEAVY_BLOCK_B, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_runs,
                        reinterpret_cast<const unsigned char *>(g.heavy_out.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
                        reinterpret_cast<unsigned char *>(g.bucket_sums.p));
@@ -447,14 +448,12 @@ static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars
     LAUNCH((k_accumulate<F, false>), ceil_div(T, 128), 128, 0, st, reinterpret_cast<const uint32_t *>(g.sorted_idx.p),
            reinterpret_cast<const uint32_t *>(g.offsets.p), TABLE_B, reinterpret_cast<const unsigned char *>(bs.tables), (const uint32_t *)plan,
            reinterpret_cast<unsigned char *>(g.bucket_sums.p), reinterpret_cast<unsigned char *>(g.head_part.p),
-           reinterpret_cast<unsigned char *>(g.tail_part.p), reinterpret_cast<uint32_t *>(g.tail_key.p));
+           reinterpret_cast<unsigned char *>(g.tail_part.p), reinterpret_cast<uint32_t *>(g.tail_key.p), heavy_count, heavy_runs, heavy_subs);
     tm_mark("accumulate");
-    LAUNCH((k_fixup<F, true>), ceil_div((uint64_t)T * 4, 128), 128, 0, st, (const uint32_t *)plan, reinterpret_cast<const uint32_t *>(g.offsets.p),
-           reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
-           reinterpret_cast<const uint32_t *>(g.tail_key.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p), heavy_count, heavy_runs, heavy_subs, 0u);
-    LAUNCH_BARRIER(k_fixup_heavy_a<F>, (FIXUP_HEAVY_GRID + 3) / 4, HEAVY_BLOCK_A, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_subs, (const U4 *)heavy_runs,
-                   reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
-                   reinterpret_cast<unsigned char *>(g.heavy_out.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p));
+    LAUNCH_BARRIER(k_fixup_all<F>, FIXUP_HEAVY_BLOCKS + ceil_div(T, HEAVY_BLOCK_A / 4), HEAVY_BLOCK_A, 0, st, FIXUP_HEAVY_BLOCKS, (const uint32_t *)plan,
+                   reinterpret_cast<const uint32_t *>(g.offsets.p), reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
+                   reinterpret_cast<const uint32_t *>(g.tail_key.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p), 0u,
+                   (const uint32_t *)heavy_count, (const U4 *)heavy_subs, (const U4 *)heavy_runs, reinterpret_cast<unsigned char *>(g.heavy_out.p));
     LAUNCH_BARRIER(k_fixup_heavy_b<F>, (FIXUP_HEAVY_GRID + 3) / 4, HEAVY_BLOCK_B, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_runs,
                    reinterpret_cast<const unsigned char *>(g.heavy_out.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
                    reinterpret_cast<unsigned char *>(g.bucket_sums.p));

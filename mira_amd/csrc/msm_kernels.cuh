@@ -30,6 +30,7 @@ static constexpr uint32_t KEY_NONE = 0xFFFFFFFFu;
 // medium chains then sit in k_fixup for 100 us (2^13 pairs under 5-bit windows: 57 -> 158 us) -- the threshold stays.
 static constexpr int HEAVY_SPAN = 6;
 static constexpr int WSUM_BLOCK = 512;       // k_window_sum: 128 quads
+static constexpr uint32_t HEAVY_SUB = 64;    // partials per stage-A sub-job of a heavy run: one wave (16 quads x 4 partials, then a 4-level tree)
 
 // ------------------------------------------------------------------------------------------
 // (also clears the ncounts bucket counters the histogram that follows adds into: one launch less)
@@ -355,7 +356,8 @@ template <class F, bool ADD>
 KERNEL void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) k_accumulate(const uint32_t *__restrict__ sorted, const uint32_t *__restrict__ offsets, uint32_t NB,
                          const unsigned char *__restrict__ bases,
                          const uint32_t *__restrict__ plan, unsigned char *__restrict__ bucket_sums,
-                         unsigned char *__restrict__ head_part, unsigned char *__restrict__ tail_part, uint32_t *__restrict__ tail_key) {
+                         unsigned char *__restrict__ head_part, unsigned char *__restrict__ tail_part, uint32_t *__restrict__ tail_key,
+                         uint32_t *__restrict__ heavy_ctr, U4 *__restrict__ runs, U4 *__restrict__ subs) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total = offsets[NB];
     const uint32_t L = plan[0];
@@ -412,7 +414,27 @@ KERNEL void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) k_
     if (is_head) xyzz29_store(head_part + (size_t)t * XYZZ29_BYTES, acc);
     else if (cont_next) xyzz29_store(tail_part + (size_t)t * XYZZ29_BYTES, acc);
     else xyzz29_store(bucket_sums + (size_t)cur * XYZZ29_BYTES, acc);
-    tail_key[t] = (!is_head && cont_next) ? cur : KEY_NONE;   // every segment of the plan writes its key: no clearing pass
+    const bool holds_tail = !is_head && cont_next;
+    tail_key[t] = holds_tail ? cur : KEY_NONE;               // every segment of the plan writes its key: no clearing pass
+    // A run cut into more than HEAVY_SPAN partials (a heavy bucket) is entered into the heavy list HERE, by the one lane that holds
+    // its tail partial: the list is complete when this kernel ends, so the sub-jobs of the heavy runs and the short chains of all
+    // the others are summed side by side in ONE launch (k_fixup_all) instead of one after the other (round 3: k_fixup wrote the
+    // list, k_fixup_heavy_a followed -- 49 + 42 us of a 0.54 ms commit of 2^17 pairs, both latency-bound on mostly idle SIMDs).
+    if (holds_tail) {
+        const uint32_t span = (run_end - 1) / L - t;          // lanes t + 1 .. t + span hold head partials of this run
+        if (span > (uint32_t)HEAVY_SPAN) {
+            const uint32_t nsub = (span + HEAVY_SUB - 1) / HEAVY_SUB;
+            const uint32_t h = atomicAdd(&heavy_ctr[0], 1u);
+            const uint32_t base = atomicAdd(&heavy_ctr[1], nsub);
+            if (nsub > 1) atomicAdd(&heavy_ctr[4], 1u);
+            runs[h] = U4{t, span, cur, base};
+            for (uint32_t q = 0; q < nsub; q++) {
+                const uint32_t first_p = t + 1 + q * HEAVY_SUB;
+                const uint32_t cnt = (span - q * HEAVY_SUB < HEAVY_SUB) ? span - q * HEAVY_SUB : HEAVY_SUB;
+                subs[base + q] = U4{first_p, cnt, h, 0};
+            }
+        }
+    }
 }
 
 template <bool QUAD, class F> DEV void xyzz29_add_sel(Xyzz29<F> &acc, const Xyzz29<F> &q) {
@@ -426,27 +448,22 @@ template <bool QUAD, class F> DEV Xyzz29<F> xyzz29_double_sel(const Xyzz29<F> &p
 // multiplications of each addition, which cuts the latency of a link from ~6.8 us to ~2 us.
 DEV uint32_t quad_gid() { return (blockIdx.x * blockDim.x + threadIdx.x) >> 2; }
 
-// One quad per cut run.  Short chains are summed here; a chain longer than HEAVY_SPAN partials (a
-// heavy bucket: the carry bucket of small witness values, a column of ones, the sparse top window)
-// is cut into sub-jobs of HEAVY_SUB partials for the two workgroup-parallel kernels below, so its
-// cost is two LDS trees whatever its length.
-// heavy_ctr = {runs, sub-jobs}; runs[h] = {lane, span, bucket, first sub-job}; subs[s] = {first
-// partial, count, run, -}.
-static constexpr uint32_t HEAVY_SUB = 64;       // partials per stage-A sub-job: one wave (16 quads x 4 partials, then a 4-level tree)
+// The short chains: one quad per cut run sums its tail partial and its <= HEAVY_SPAN head partials.  Longer runs (heavy buckets: the
+// carry bucket of small witness values, a column of ones, the sparse top window) were entered into the heavy list by k_accumulate
+// and are summed by the sub-jobs of the same launch (k_fixup_all below), two LDS trees whatever their length.
+// heavy_ctr = {runs, sub-jobs, -, -, runs of more than one sub-job}; runs[h] = {lane, span, bucket, first sub-job};
+// subs[s] = {first partial, count, run, -}.
 // (One LANE per cut run instead of a quad, for the sizes at which the cut runs fill the SIMDs, was built and measured in round 4:
 // 2^17 pairs c = 13 fix-up 104 -> 117 us, c = 12 123 -> 151, c = 16 51 -> 48; 2^22 pairs 59 -> 54 -- the kernel is bound by its
-// dependent loads and a lane's 14 serial multiplications are no better hidden than a quad's 4.  QUAD stays a template
-// parameter of the kernel; every launch uses quads.)
-template <class F, bool QUAD = true>
-KERNEL void __launch_bounds__(128) k_fixup(const uint32_t *__restrict__ plan, const uint32_t *__restrict__ offsets,
-                    const unsigned char *__restrict__ head_part, const unsigned char *__restrict__ tail_part,
-                    const uint32_t *__restrict__ tail_key, unsigned char *__restrict__ bucket_sums,
-                    uint32_t *__restrict__ heavy_ctr, U4 *__restrict__ runs, U4 *__restrict__ subs, uint32_t num_buckets) {
-    const uint32_t gid = QUAD ? quad_gid() : blockIdx.x * blockDim.x + threadIdx.x;
+// dependent loads and a lane's 14 serial multiplications are no better hidden than a quad's 4.)
+template <class F>
+DEV void fixup_light(uint32_t gid, const uint32_t *__restrict__ plan, const uint32_t *__restrict__ offsets,
+                     const unsigned char *__restrict__ head_part, const unsigned char *__restrict__ tail_part,
+                     const uint32_t *__restrict__ tail_key, unsigned char *__restrict__ bucket_sums, uint32_t num_buckets) {
     const uint32_t L = plan[0], T = plan[1];
-    // One quad per cut run.  Indexed by segment (the lane that holds the run's tail partial) when
-    // segments are fewer than buckets; by bucket (num_buckets != 0) when buckets are fewer -- small
-    // MSMs, where every bucket is cut several times and only one segment in four holds a tail.
+    // Indexed by segment (the lane that holds the run's tail partial) when segments are fewer than buckets; by bucket
+    // (num_buckets != 0) when buckets are fewer -- small MSMs, where every bucket is cut several times and only one segment in
+    // four holds a tail.
     uint32_t t, key, run_end;
     if (num_buckets) {
         key = gid;
@@ -464,23 +481,10 @@ KERNEL void __launch_bounds__(128) k_fixup(const uint32_t *__restrict__ plan, co
         run_end = offsets[key + 1];
     }
     const uint32_t span = (run_end - 1) / L - t;   // lanes t+1 .. t+span hold head partials of this run
-    if (span > (uint32_t)HEAVY_SPAN) {
-        if (QUAD && quad_lane() != 0) return;
-        const uint32_t nsub = (span + HEAVY_SUB - 1) / HEAVY_SUB;
-        const uint32_t h = atomicAdd(&heavy_ctr[0], 1u);
-        const uint32_t base = atomicAdd(&heavy_ctr[1], nsub);
-        if (nsub > 1) atomicAdd(&heavy_ctr[4], 1u);
-        runs[h] = U4{t, span, key, base};
-        for (uint32_t s = 0; s < nsub; s++) {
-            const uint32_t first = t + 1 + s * HEAVY_SUB;
-            const uint32_t cnt = (span - s * HEAVY_SUB < HEAVY_SUB) ? span - s * HEAVY_SUB : HEAVY_SUB;
-            subs[base + s] = U4{first, cnt, h, 0};
-        }
-        return;
-    }
+    if (span > (uint32_t)HEAVY_SPAN) return;       // a heavy run: the sub-jobs of this launch take it
     Xyzz29<F> acc = xyzz29_load<F>(tail_part + (size_t)t * XYZZ29_BYTES);
-    for (uint32_t q = 1; q <= span; q++) xyzz29_add_sel<QUAD>(acc, xyzz29_load<F>(head_part + (size_t)(t + q) * XYZZ29_BYTES));
-    if (!QUAD || quad_lane() == 0) xyzz29_store(bucket_sums + (size_t)key * XYZZ29_BYTES, acc);
+    for (uint32_t q = 1; q <= span; q++) xyzz29_add_quad(acc, xyzz29_load<F>(head_part + (size_t)(t + q) * XYZZ29_BYTES));
+    if (quad_lane() == 0) xyzz29_store(bucket_sums + (size_t)key * XYZZ29_BYTES, acc);
 }
 
 // LDS tree over the values of the first `cnt` quads of the workgroup (cnt <= blockDim.x / 4);
@@ -523,18 +527,22 @@ template <class F> DEV void group_tree_sum_quad(Xyzz29<F> &acc, unsigned char *r
 // Workgroups of 256 lanes (64 quads, four waves on the four SIMDs of a CU): 64-lane workgroups were seen packed onto a
 // fraction of the CUs, several chains sharing a SIMD while others idle.  heavy_ctr[4] counts the runs that stage B
 // still has to finish (more than one sub-job).
+#ifdef MIRA_CPU_EMU
+static constexpr uint32_t HEAVY_BLOCK_A = 32, HEAVY_BLOCK_B = 256;   // emulated lanes are OS threads, and k_fixup_all is launched for every commit: eight quads per workgroup there
+#else
 static constexpr uint32_t HEAVY_BLOCK_A = 256, HEAVY_BLOCK_B = 256;
+#endif
 // A run that is one sub-job (<= HEAVY_SUB partials: the usual case) is finished here -- tail partial
 // added, bucket written -- and stage B skips it.
 template <class F>
-KERNEL void __launch_bounds__(256) k_fixup_heavy_a(const uint32_t *__restrict__ heavy_ctr, const U4 *__restrict__ subs, const U4 *__restrict__ runs,
-                          const unsigned char *__restrict__ head_part, const unsigned char *__restrict__ tail_part,
-                          unsigned char *__restrict__ sub_out, unsigned char *__restrict__ bucket_sums) {
-    __shared__ __attribute__((aligned(16))) unsigned char red[(HEAVY_BLOCK_A / 4) * XYZZ29_BYTES];
+DEV void fixup_heavy_a(uint32_t block, uint32_t nblocks, unsigned char *red, const uint32_t *__restrict__ heavy_ctr, const U4 *__restrict__ subs, const U4 *__restrict__ runs,
+                       const unsigned char *__restrict__ head_part, const unsigned char *__restrict__ tail_part,
+                       unsigned char *__restrict__ sub_out, unsigned char *__restrict__ bucket_sums) {
     const uint32_t nsubs = heavy_ctr[1], qi = threadIdx.x >> 2;
-    const uint32_t lg = nsubs > 4096 ? 1u : nsubs > 2048 ? 2u : nsubs > 1024 ? 3u : 4u;        // quads per sub-job = 2^lg
+    uint32_t lg = nsubs > 4096 ? 1u : nsubs > 2048 ? 2u : nsubs > 1024 ? 3u : 4u;              // quads per sub-job = 2^lg
+    while ((1u << lg) > HEAVY_BLOCK_A / 4) lg--;                                                // (never more than a workgroup has)
     const uint32_t gq = 1u << lg, spb = (HEAVY_BLOCK_A / 4) >> lg, ql = qi & (gq - 1u);       // sub-jobs per workgroup
-    for (uint32_t s0 = blockIdx.x * spb; s0 < nsubs; s0 += gridDim.x * spb) {
+    for (uint32_t s0 = block * spb; s0 < nsubs; s0 += nblocks * spb) {
         const uint32_t s = s0 + (qi >> lg);
         const bool active = s < nsubs;
         const U4 d = active ? subs[s] : U4{0, 0, 0, 0};
@@ -561,6 +569,22 @@ KERNEL void __launch_bounds__(256) k_fixup_heavy_a(const uint32_t *__restrict__ 
         }
         __syncthreads();
     }
+}
+// ONE launch after k_accumulate: workgroups [0, heavy_blocks) sum the sub-jobs of the heavy runs (stage A; they come first in the
+// grid so that the long chains start first), the others the short chains, 64 quads each.  Both are latency-bound on mostly idle
+// SIMDs: side by side they take what the longer one takes.
+template <class F>
+KERNEL void __launch_bounds__(256) k_fixup_all(uint32_t heavy_blocks, const uint32_t *__restrict__ plan, const uint32_t *__restrict__ offsets,
+                        const unsigned char *__restrict__ head_part, const unsigned char *__restrict__ tail_part,
+                        const uint32_t *__restrict__ tail_key, unsigned char *__restrict__ bucket_sums, uint32_t num_buckets,
+                        const uint32_t *__restrict__ heavy_ctr, const U4 *__restrict__ subs, const U4 *__restrict__ runs,
+                        unsigned char *__restrict__ sub_out) {
+    __shared__ __attribute__((aligned(16))) unsigned char red[(HEAVY_BLOCK_A / 4) * XYZZ29_BYTES];
+    if (blockIdx.x < heavy_blocks) {                                 // block-uniform
+        fixup_heavy_a<F>(blockIdx.x, heavy_blocks, red, heavy_ctr, subs, runs, head_part, tail_part, sub_out, bucket_sums);
+        return;
+    }
+    fixup_light<F>((blockIdx.x - heavy_blocks) * (blockDim.x >> 2) + (threadIdx.x >> 2), plan, offsets, head_part, tail_part, tail_key, bucket_sums, num_buckets);
 }
 // stage B: one workgroup per heavy run: bucket = tail partial + sum of its sub-job results
 template <class F>

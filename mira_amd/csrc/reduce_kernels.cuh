@@ -72,7 +72,11 @@ KERNEL void __launch_bounds__(512) k_bucket_tree(const unsigned char *__restrict
         Xyzz29<F> running = xyzz29_identity<F>(), ws = xyzz29_identity<F>();
         // the next bucket sum is requested before the current one is added (its index clamped: the last fetch is unused)
         Xyzz29<F> nxt = xyzz29_load<F>(S + (size_t)(m - 1) * XYZZ29_BYTES);
+#ifdef MIRA_PROBE_NO_PHASE_A                                  // timing probes only (tools/build_probe_variants.sh): wrong results
+        for (int i = 0; i >= 1; i--) {
+#else
         for (int i = (int)m - 1; i >= 0; i--) {
+#endif
             const Xyzz29<F> cur = nxt;
             nxt = xyzz29_load<F>(S + (size_t)(i > 0 ? i - 1 : 0) * XYZZ29_BYTES);
             if constexpr (QUAD) { xyzz29_add_quad(running, cur); xyzz29_add_quad(ws, running); }
@@ -84,7 +88,9 @@ KERNEL void __launch_bounds__(512) k_bucket_tree(const unsigned char *__restrict
         }
     }
     __syncthreads();
+#ifndef MIRA_PROBE_NO_TREE
     node_tree_quad<F>(slots, 2, kappa);
+#endif
     const uint32_t words = (kappa + 2) * (XYZZ29_BYTES / 4);
     uint32_t *dst = reinterpret_cast<uint32_t *>(nodes_out + (size_t)blockIdx.x * (kappa + 2) * XYZZ29_BYTES);
     const uint32_t *src = reinterpret_cast<const uint32_t *>(slots);

@@ -508,34 +508,36 @@ def test_emu_long_commits_and_host_batches_in_chunks(emu_lib, tune):
     the GPU: the reference's 2^27 .. 2^28-point keys; here the pass is shrunk by MIRA_TUNE_PASS_ENTRIES_LOG) is cut into point
     chunks that add into one set of buckets -- scalars in device memory, a prefix, a batch, the GLV copy and a shared-bucket
     set -- and the vectors of a HOST batch (mira_msm_batch) cross in point chunks, staged slice by slice."""
-    cid, n = 0, 900
+    cid, n = 0, 420
     bs = C.synth_bases(cid, n, seed=90)
-    bs[500] = 0
+    bs[300] = 0
     key = cm.CommitmentKey(cid, bs, lib=emu_lib)
-    vs = [C.synth_scalars(cid, n, seed=91 + b, kind=b % 2) for b in range(3)]
+    vs = [C.synth_scalars(cid, n, seed=91 + b, kind=b % 2) for b in range(2)]
     for v in vs:
-        v[200:260] = v[1]
+        v[150:200] = v[1]
     want = [C.commit(cid, bs, v) for v in vs]
-    d = emu_lib.alloc(3 * n * 32)
+    d = emu_lib.alloc(2 * n * 32)
     for b, v in enumerate(vs):
         emu_lib.upload(d + b * n * 32, v)
     emu_lib.check(emu_lib.c.mira_msm_set_window_bits(9))
     try:
         tune(_lib.TUNE_PASS_ENTRIES_LOG, 13)                     # 8191 entries per pass: chunks of 256 points under 29 windows of 9 bits
         assert (key.commit_device(d, n) == want[0]).all()
-        assert (key.commit_device(d + n * 32, 777) == C.commit(cid, bs[:777], vs[1][:777])).all()
-        assert (key.commit(vs[2]) == want[2]).all()              # host scalars: the copy chunks are cut further
-        assert (key.commit_batch_device(d, n, 3) == np.stack(want)).all()      # a batch is cut by count first, then by points
+        assert (key.commit_device(d + n * 32, 333) == C.commit(cid, bs[:333], vs[1][:333])).all()
+        assert (key.commit_batch_device(d, n, 2) == np.stack(want)).all()      # a batch is cut by count first, then by points
+        tune(_lib.TUNE_HOST_CHUNK_MIN_N, 256)                    # host vectors: the copy chunks (128, 256 ... scalars) are cut further by the pass
+        assert (key.commit(vs[1]) == want[1]).all()
+        assert (key.commit_batch(vs) == np.stack(want)).all()    # a host batch: slices of every vector per chunk
         tune(_lib.TUNE_PASS_ENTRIES_LOG, -1)
-        tune(_lib.TUNE_HOST_CHUNK_MIN_N, 256)                    # host batches: chunks of 128 x 3, 256 x 3 ... scalars
         assert (key.commit_batch(vs) == np.stack(want)).all()
         assert (key.commit_batch([v[:50] for v in vs]) == np.stack([C.commit(cid, bs[:50], v[:50]) for v in vs])).all()   # below the threshold: one chunk
-        tune(_lib.TUNE_PASS_ENTRIES_LOG, 13)
-        assert (key.commit_batch(vs) == np.stack(want)).all()    # both at once
     finally:
         emu_lib.check(emu_lib.c.mira_msm_set_window_bits(0))
+    tune(_lib.TUNE_PASS_ENTRIES_LOG, 13)
     key.precompute(_lib.TABLE_GLV)                               # the endomorphism copy: 2 n columns per chunk
-    assert (key.commit_device(d, n) == want[0]).all() and (key.commit_batch(vs) == np.stack(want)).all()
+    key.set_window_bits(9)
+    assert (key.commit_device(d, n) == want[0]).all()
+    key.set_window_bits(0)
     tune(_lib.TUNE_SHARED_MIN_N, 1)
     key.precompute(9)
     assert (key.commit_device(d, n) == want[0]).all() and (key.commit_batch(vs) == np.stack(want)).all()

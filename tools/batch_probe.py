@@ -14,6 +14,8 @@ for cid, cnt in ((0, 6), (1, 5)):
         for _ in range(5):
             t0 = time.perf_counter(); key.commit_batch_device(d, n, cnt); ts.append((time.perf_counter() - t0) * 1e3)
         lib.check(lib.c.mira_set_timing(1)); key.commit_batch_device(d, n, cnt); st = {a: round(b, 3) for a, b in lib.timings()}; lib.check(lib.c.mira_set_timing(0))
-        print(f"curve {cid} batch {cnt} x 2^17 c={c}: {sorted(ts)[2]:.3f} ms {st}", flush=True)
+        pc, pw = ctypes.c_int32(), ctypes.c_int32()
+        lib.check(lib.c.mira_msm_last_plan(ctypes.byref(pc), ctypes.byref(pw)))
+        print(f"curve {cid} batch {cnt} x 2^17 c={c} (plan {pc.value} x {pw.value}): {sorted(ts)[2]:.3f} ms {st}", flush=True)
     lib.check(lib.c.mira_msm_set_window_bits(0))
     key.close(); lib.free(d)

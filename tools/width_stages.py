@@ -2,6 +2,8 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mira_amd import _lib, commitment as cm
+if os.environ.get("MIRA_PROBE_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["MIRA_PROBE_LIB"])
 lib = _lib.load()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
 kind = int(sys.argv[2]) if len(sys.argv) > 2 else 0

@@ -116,7 +116,7 @@ static int msm_launch_body(const Bases &bs, size_t first, const void *d_scalars,
     if ((rc = g.head_part.ensure((size_t)p.T * XYZZ29_BYTES))) return rc;
     if ((rc = g.tail_part.ensure((size_t)p.T * XYZZ29_BYTES))) return rc;
     if ((rc = g.tail_key.ensure((size_t)p.T * 4))) return rc;
-    if ((rc = g.heavy.ensure(64 + ((size_t)p.T / 2 + 8) * 32))) return rc;            // counters, runs, sub-job descriptors
+    if ((rc = g.heavy.ensure(64 + ((size_t)p.T / 2 + 8) * 32 + ((size_t)p.T / 4 + 8) * 16))) return rc;   // counters, runs, sub-job descriptors, medium runs
     if ((rc = g.heavy_out.ensure(((size_t)p.T / 2 + 8) * XYZZ29_BYTES))) return rc;
     const size_t node_points = ((size_t)p.nsets << p.gamma) * (p.kappa + 2);               // one node of kappa + 2 points per workgroup of k_bucket_tree
     if ((rc = g.chunks.ensure(node_points * XYZZ29_BYTES))) return rc;
@@ -136,6 +136,7 @@ static int msm_launch_body(const Bases &bs, size_t first, const void *d_scalars,
     uint32_t *heavy_count = reinterpret_cast<uint32_t *>(g.heavy.p);          // [0] runs, [1] sub-jobs, [2..3] plan
     U4 *heavy_runs = reinterpret_cast<U4 *>(heavy_count + 16);
     U4 *heavy_subs = heavy_runs + ((size_t)p.T / 4 + 4);
+    U4 *heavy_meds = reinterpret_cast<U4 *>(reinterpret_cast<unsigned char *>(g.heavy.p) + 64 + ((size_t)p.T / 2 + 8) * 32);
     uint32_t *plan = heavy_count + 2;
     uint32_t *no_u32 = nullptr;
     unsigned char *no_u8 = nullptr;
@@ -228,12 +229,12 @@ static int msm_launch_body(const Bases &bs, size_t first, const void *d_scalars,
             LAUNCH((k_accumulate<F, true>), ceil_div(p.T, 128), 128, 0, st, reinterpret_cast<const uint32_t *>(g.sorted_idx.p),
                    reinterpret_cast<const uint32_t *>(g.offsets.p), p.NB, bases, (const uint32_t *)plan,
                    reinterpret_cast<unsigned char *>(g.bucket_sums.p), reinterpret_cast<unsigned char *>(g.head_part.p),
-                   reinterpret_cast<unsigned char *>(g.tail_part.p), reinterpret_cast<uint32_t *>(g.tail_key.p), heavy_count, heavy_runs, heavy_subs);
+                   reinterpret_cast<unsigned char *>(g.tail_part.p), reinterpret_cast<uint32_t *>(g.tail_key.p), heavy_count, heavy_runs, heavy_subs, heavy_meds);
         else
             LAUNCH((k_accumulate<F, false>), ceil_div(p.T, 128), 128, 0, st, reinterpret_cast<const uint32_t *>(g.sorted_idx.p),
                    reinterpret_cast<const uint32_t *>(g.offsets.p), p.NB, bases, (const uint32_t *)plan,
                    reinterpret_cast<unsigned char *>(g.bucket_sums.p), reinterpret_cast<unsigned char *>(g.head_part.p),
-                   reinterpret_cast<unsigned char *>(g.tail_part.p), reinterpret_cast<uint32_t *>(g.tail_key.p), heavy_count, heavy_runs, heavy_subs);
+                   reinterpret_cast<unsigned char *>(g.tail_part.p), reinterpret_cast<uint32_t *>(g.tail_key.p), heavy_count, heavy_runs, heavy_subs, heavy_meds);
         tm_mark("accumulate");
         const uint32_t fix_by_bucket = p.NB < p.T ? p.NB : 0u;   // fewer buckets than segments: index the fix-up by bucket
         const uint32_t fix_items = fix_by_bucket ? fix_by_bucket : p.T;
@@ -241,7 +242,7 @@ static int msm_launch_body(const Bases &bs, size_t first, const void *d_scalars,
         LAUNCH_BARRIER(k_fixup_all<F>, FIXUP_HEAVY_BLOCKS + ceil_div(fix_items, HEAVY_BLOCK_A / 4), HEAVY_BLOCK_A, 0, st, FIXUP_HEAVY_BLOCKS, (const uint32_t *)plan,
                        reinterpret_cast<const uint32_t *>(g.offsets.p), reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
                        reinterpret_cast<const uint32_t *>(g.tail_key.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p), fix_by_bucket,
-                       (const uint32_t *)heavy_count, (const U4 *)heavy_subs, (const U4 *)heavy_runs, reinterpret_cast<unsigned char *>(g.heavy_out.p));
+                       (const uint32_t *)heavy_count, (const U4 *)heavy_subs, (const U4 *)heavy_runs, reinterpret_cast<unsigned char *>(g.heavy_out.p), (const U4 *)heavy_meds);
         LAUNCH_BARRIER(k_fixup_heavy_b<F>, (FIXUP_HEAVY_GRID + 3) / 4, HEAVY_BLOCK_B, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_runs,
                        reinterpret_cast<const unsigned char *>(g.heavy_out.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
                        reinterpret_cast<unsigned char *>(g.bucket_sums.p));
@@ -397,7 +398,7 @@ static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars
     if ((rc = g.head_part.ensure((size_t)T * XYZZ29_BYTES))) return rc;
     if ((rc = g.tail_part.ensure((size_t)T * XYZZ29_BYTES))) return rc;
     if ((rc = g.tail_key.ensure((size_t)T * 4))) return rc;
-    if ((rc = g.heavy.ensure(64 + ((size_t)T / 2 + 8) * 32))) return rc;
+    if ((rc = g.heavy.ensure(64 + ((size_t)T / 2 + 8) * 32 + ((size_t)T / 4 + 8) * 16))) return rc;
     if ((rc = g.heavy_out.ensure(((size_t)T / 2 + 8) * XYZZ29_BYTES))) return rc;
     if ((rc = g.chunks.ensure((size_t)nchunks * XYZZ29_BYTES))) return rc;
     if ((rc = g.window_sums.ensure((size_t)TABLE_SUMS * 128))) return rc;
@@ -407,6 +408,7 @@ static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars
     uint32_t *plan = heavy_count + 2;
     U4 *heavy_runs = reinterpret_cast<U4 *>(heavy_count + 16);
     U4 *heavy_subs = heavy_runs + ((size_t)T / 4 + 4);
+    U4 *heavy_meds = reinterpret_cast<U4 *>(reinterpret_cast<unsigned char *>(g.heavy.p) + 64 + ((size_t)T / 2 + 8) * 32);
     // level-1 tiles of 32k points: runs of ~64 entries per (workgroup, coarse bin)
     const uint32_t tile = 32768, ntiles = ceil_div(n, tile);
     tm_begin();
@@ -448,12 +450,12 @@ static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars
     LAUNCH((k_accumulate<F, false>), ceil_div(T, 128), 128, 0, st, reinterpret_cast<const uint32_t *>(g.sorted_idx.p),
            reinterpret_cast<const uint32_t *>(g.offsets.p), TABLE_B, reinterpret_cast<const unsigned char *>(bs.tables), (const uint32_t *)plan,
            reinterpret_cast<unsigned char *>(g.bucket_sums.p), reinterpret_cast<unsigned char *>(g.head_part.p),
-           reinterpret_cast<unsigned char *>(g.tail_part.p), reinterpret_cast<uint32_t *>(g.tail_key.p), heavy_count, heavy_runs, heavy_subs);
+           reinterpret_cast<unsigned char *>(g.tail_part.p), reinterpret_cast<uint32_t *>(g.tail_key.p), heavy_count, heavy_runs, heavy_subs, heavy_meds);
     tm_mark("accumulate");
     LAUNCH_BARRIER(k_fixup_all<F>, FIXUP_HEAVY_BLOCKS + ceil_div(T, HEAVY_BLOCK_A / 4), HEAVY_BLOCK_A, 0, st, FIXUP_HEAVY_BLOCKS, (const uint32_t *)plan,
                    reinterpret_cast<const uint32_t *>(g.offsets.p), reinterpret_cast<const unsigned char *>(g.head_part.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
                    reinterpret_cast<const uint32_t *>(g.tail_key.p), reinterpret_cast<unsigned char *>(g.bucket_sums.p), 0u,
-                   (const uint32_t *)heavy_count, (const U4 *)heavy_subs, (const U4 *)heavy_runs, reinterpret_cast<unsigned char *>(g.heavy_out.p));
+                   (const uint32_t *)heavy_count, (const U4 *)heavy_subs, (const U4 *)heavy_runs, reinterpret_cast<unsigned char *>(g.heavy_out.p), (const U4 *)heavy_meds);
     LAUNCH_BARRIER(k_fixup_heavy_b<F>, (FIXUP_HEAVY_GRID + 3) / 4, HEAVY_BLOCK_B, 0, st, (const uint32_t *)heavy_count, (const U4 *)heavy_runs,
                    reinterpret_cast<const unsigned char *>(g.heavy_out.p), reinterpret_cast<const unsigned char *>(g.tail_part.p),
                    reinterpret_cast<unsigned char *>(g.bucket_sums.p));

@@ -29,6 +29,17 @@ static constexpr uint32_t KEY_NONE = 0xFFFFFFFFu;
 // to 16 was measured: commits whose longest chains are 7 .. 16 links gain, but wherever the heavy stages run anyway the
 // medium chains then sit in k_fixup for 100 us (2^13 pairs under 5-bit windows: 57 -> 158 us) -- the threshold stays.
 static constexpr int HEAVY_SPAN = 6;
+// MEDIUM runs (HEAVY_SPAN < partials <= MEDIUM_SPAN) go where they are cheaper, decided on the device when their number is
+// known: a few of them are sub-jobs of the heavy section (several quads and a tree each: 0.04 against 0.07 ms for the fix-up of
+// a witness-like 2^17-pair commit), thousands of them -- the 32-bit values of a 1.8 M-scalar witness vector fill 4 096 buckets
+// with 7 - 8 partials each -- would flood it with sub-jobs that share workgroups with the really heavy ones, and are summed as
+// plain chains by the quads of the light section instead (that commit's fix-up 0.18 -> 0.10 ms; profiles/r04_f_heavy_span.txt).
+static constexpr int MEDIUM_SPAN = 12;
+#ifdef MIRA_CPU_EMU
+static constexpr uint32_t MEDIUM_AS_CHAINS_FROM = 8;     // (the emulation's sizes reach both placements with this)
+#else
+static constexpr uint32_t MEDIUM_AS_CHAINS_FROM = 1024;
+#endif
 static constexpr int WSUM_BLOCK = 512;       // k_window_sum: 128 quads
 static constexpr uint32_t HEAVY_SUB = 64;    // partials per stage-A sub-job of a heavy run: one wave (16 quads x 4 partials, then a 4-level tree)
 
@@ -241,7 +252,7 @@ KERNEL void k_scan_c(const uint32_t *__restrict__ counts, uint32_t NB, const uin
                     if (L < min_L) L = min_L;
                     plan[0] = L;
                     plan[1] = (uint32_t)(((uint64_t)run + L - 1) / L);
-                    heavy_ctr[0] = 0; heavy_ctr[1] = 0; heavy_ctr[4] = 0;
+                    heavy_ctr[0] = 0; heavy_ctr[1] = 0; heavy_ctr[4] = 0; heavy_ctr[5] = 0;
                 }
             }
         }
@@ -357,7 +368,7 @@ KERNEL void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) k_
                          const unsigned char *__restrict__ bases,
                          const uint32_t *__restrict__ plan, unsigned char *__restrict__ bucket_sums,
                          unsigned char *__restrict__ head_part, unsigned char *__restrict__ tail_part, uint32_t *__restrict__ tail_key,
-                         uint32_t *__restrict__ heavy_ctr, U4 *__restrict__ runs, U4 *__restrict__ subs) {
+                         uint32_t *__restrict__ heavy_ctr, U4 *__restrict__ runs, U4 *__restrict__ subs, U4 *__restrict__ meds) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total = offsets[NB];
     const uint32_t L = plan[0];
@@ -422,7 +433,9 @@ KERNEL void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) k_
     // list, k_fixup_heavy_a followed -- 49 + 42 us of a 0.54 ms commit of 2^17 pairs, both latency-bound on mostly idle SIMDs).
     if (holds_tail) {
         const uint32_t span = (run_end - 1) / L - t;          // lanes t + 1 .. t + span hold head partials of this run
-        if (span > (uint32_t)HEAVY_SPAN) {
+        if (span > (uint32_t)HEAVY_SPAN && span <= (uint32_t)MEDIUM_SPAN) {
+            meds[atomicAdd(&heavy_ctr[5], 1u)] = U4{t, span, cur, 0};          // a medium run: placed when their number is known (k_fixup_all)
+        } else if (span > (uint32_t)MEDIUM_SPAN) {
             const uint32_t nsub = (span + HEAVY_SUB - 1) / HEAVY_SUB;
             const uint32_t h = atomicAdd(&heavy_ctr[0], 1u);
             const uint32_t base = atomicAdd(&heavy_ctr[1], nsub);
@@ -456,10 +469,34 @@ DEV uint32_t quad_gid() { return (blockIdx.x * blockDim.x + threadIdx.x) >> 2; }
 // (One LANE per cut run instead of a quad, for the sizes at which the cut runs fill the SIMDs, was built and measured in round 4:
 // 2^17 pairs c = 13 fix-up 104 -> 117 us, c = 12 123 -> 151, c = 16 51 -> 48; 2^22 pairs 59 -> 54 -- the kernel is bound by its
 // dependent loads and a lane's 14 serial multiplications are no better hidden than a quad's 4.)
+// Many medium runs BESIDE really heavy ones are summed as chains by the light section; alone (8 192 pairs under 8-bit windows:
+// thousands of runs of seven partials and nothing heavier) they are quicker as sub-jobs of their own -- 0.040 against 0.065 ms.
+DEV bool medium_as_chains(const uint32_t *__restrict__ heavy_ctr) { return heavy_ctr[5] >= MEDIUM_AS_CHAINS_FROM && heavy_ctr[1] != 0; }
+// tail partial + its `span` head partials, by one quad; the next partial is requested before the current one is added
 template <class F>
-DEV void fixup_light(uint32_t gid, const uint32_t *__restrict__ plan, const uint32_t *__restrict__ offsets,
+DEV void fixup_chain(uint32_t t, uint32_t span, uint32_t key, const unsigned char *__restrict__ head_part, const unsigned char *__restrict__ tail_part,
+                     unsigned char *__restrict__ bucket_sums) {
+    Xyzz29<F> acc = xyzz29_load<F>(tail_part + (size_t)t * XYZZ29_BYTES);
+    Xyzz29<F> nxt = xyzz29_load<F>(head_part + (size_t)(t + 1) * XYZZ29_BYTES);
+    for (uint32_t q = 1; q <= span; q++) {
+        const Xyzz29<F> cur = nxt;
+        nxt = xyzz29_load<F>(head_part + (size_t)(t + (q < span ? q + 1 : q)) * XYZZ29_BYTES);     // (index clamped: the last fetch is unused)
+        xyzz29_add_quad(acc, cur);
+    }
+    if (quad_lane() == 0) xyzz29_store(bucket_sums + (size_t)key * XYZZ29_BYTES, acc);
+}
+template <class F>
+DEV void fixup_light(uint32_t gid, uint32_t nquads, const uint32_t *__restrict__ plan, const uint32_t *__restrict__ offsets,
                      const unsigned char *__restrict__ head_part, const unsigned char *__restrict__ tail_part,
-                     const uint32_t *__restrict__ tail_key, unsigned char *__restrict__ bucket_sums, uint32_t num_buckets) {
+                     const uint32_t *__restrict__ tail_key, unsigned char *__restrict__ bucket_sums, uint32_t num_buckets,
+                     const uint32_t *__restrict__ heavy_ctr, const U4 *__restrict__ meds) {
+    // the medium runs, when there are many: dealt to the quads of the light section
+    const uint32_t n_medium = heavy_ctr[5];
+    if (medium_as_chains(heavy_ctr))
+        for (uint32_t m = gid; m < n_medium; m += nquads) {
+            const U4 r = meds[m];                                  // {lane, span, bucket, -}
+            fixup_chain<F>(r.x, r.y, r.z, head_part, tail_part, bucket_sums);
+        }
     const uint32_t L = plan[0], T = plan[1];
     // Indexed by segment (the lane that holds the run's tail partial) when segments are fewer than buckets; by bucket
     // (num_buckets != 0) when buckets are fewer -- small MSMs, where every bucket is cut several times and only one segment in
@@ -481,10 +518,8 @@ DEV void fixup_light(uint32_t gid, const uint32_t *__restrict__ plan, const uint
         run_end = offsets[key + 1];
     }
     const uint32_t span = (run_end - 1) / L - t;   // lanes t+1 .. t+span hold head partials of this run
-    if (span > (uint32_t)HEAVY_SPAN) return;       // a heavy run: the sub-jobs of this launch take it
-    Xyzz29<F> acc = xyzz29_load<F>(tail_part + (size_t)t * XYZZ29_BYTES);
-    for (uint32_t q = 1; q <= span; q++) xyzz29_add_quad(acc, xyzz29_load<F>(head_part + (size_t)(t + q) * XYZZ29_BYTES));
-    if (quad_lane() == 0) xyzz29_store(bucket_sums + (size_t)key * XYZZ29_BYTES, acc);
+    if (span > (uint32_t)HEAVY_SPAN) return;       // a medium or heavy run: listed by k_accumulate
+    fixup_chain<F>(t, span, key, head_part, tail_part, bucket_sums);
 }
 
 // LDS tree over the values of the first `cnt` quads of the workgroup (cnt <= blockDim.x / 4);
@@ -537,15 +572,20 @@ static constexpr uint32_t HEAVY_BLOCK_A = 256, HEAVY_BLOCK_B = 256;
 template <class F>
 DEV void fixup_heavy_a(uint32_t block, uint32_t nblocks, unsigned char *red, const uint32_t *__restrict__ heavy_ctr, const U4 *__restrict__ subs, const U4 *__restrict__ runs,
                        const unsigned char *__restrict__ head_part, const unsigned char *__restrict__ tail_part,
-                       unsigned char *__restrict__ sub_out, unsigned char *__restrict__ bucket_sums) {
-    const uint32_t nsubs = heavy_ctr[1], qi = threadIdx.x >> 2;
+                       unsigned char *__restrict__ sub_out, unsigned char *__restrict__ bucket_sums, const U4 *__restrict__ meds) {
+    // sub-jobs [0, nheavy) come from the heavy runs; a FEW medium runs follow them as sub-jobs of their own (one each)
+    const uint32_t nheavy = heavy_ctr[1], n_medium = heavy_ctr[5], qi = threadIdx.x >> 2;
+    const uint32_t nsubs = nheavy + (medium_as_chains(heavy_ctr) ? 0u : n_medium);
     uint32_t lg = nsubs > 4096 ? 1u : nsubs > 2048 ? 2u : nsubs > 1024 ? 3u : 4u;              // quads per sub-job = 2^lg
     while ((1u << lg) > HEAVY_BLOCK_A / 4) lg--;                                                // (never more than a workgroup has)
     const uint32_t gq = 1u << lg, spb = (HEAVY_BLOCK_A / 4) >> lg, ql = qi & (gq - 1u);       // sub-jobs per workgroup
     for (uint32_t s0 = block * spb; s0 < nsubs; s0 += nblocks * spb) {
         const uint32_t s = s0 + (qi >> lg);
         const bool active = s < nsubs;
-        const U4 d = active ? subs[s] : U4{0, 0, 0, 0};
+        U4 d = U4{0, 0, 0, 0}, rm = U4{0, 0, 0, 0};
+        const bool medium = active && s >= nheavy;
+        if (medium) { rm = meds[s - nheavy]; d = U4{rm.x + 1, rm.y, 0, 0}; }          // {first partial, count, -, -} of run {lane, span, bucket}
+        else if (active) d = subs[s];
         Xyzz29<F> acc = xyzz29_identity<F>();
         if (ql < d.y) {
             // the next partial is fetched before the current one is added (its index clamped: the last fetch is unused)
@@ -559,7 +599,7 @@ DEV void fixup_heavy_a(uint32_t block, uint32_t nblocks, unsigned char *red, con
         }
         group_tree_sum_quad(acc, red, gq, d.y < gq ? d.y : gq);
         if (active && ql == 0) {
-            const U4 r = runs[d.z];                                // {lane, span, bucket, first sub-job}
+            const U4 r = medium ? rm : runs[d.z];                  // {lane, span, bucket, first sub-job}
             if (r.y <= HEAVY_SUB) {
                 xyzz29_add_quad(acc, xyzz29_load<F>(tail_part + (size_t)r.x * XYZZ29_BYTES));
                 if (quad_lane() == 0) xyzz29_store(bucket_sums + (size_t)r.z * XYZZ29_BYTES, acc);
@@ -578,13 +618,14 @@ KERNEL void __launch_bounds__(256) k_fixup_all(uint32_t heavy_blocks, const uint
                         const unsigned char *__restrict__ head_part, const unsigned char *__restrict__ tail_part,
                         const uint32_t *__restrict__ tail_key, unsigned char *__restrict__ bucket_sums, uint32_t num_buckets,
                         const uint32_t *__restrict__ heavy_ctr, const U4 *__restrict__ subs, const U4 *__restrict__ runs,
-                        unsigned char *__restrict__ sub_out) {
+                        unsigned char *__restrict__ sub_out, const U4 *__restrict__ meds) {
     __shared__ __attribute__((aligned(16))) unsigned char red[(HEAVY_BLOCK_A / 4) * XYZZ29_BYTES];
     if (blockIdx.x < heavy_blocks) {                                 // block-uniform
-        fixup_heavy_a<F>(blockIdx.x, heavy_blocks, red, heavy_ctr, subs, runs, head_part, tail_part, sub_out, bucket_sums);
+        fixup_heavy_a<F>(blockIdx.x, heavy_blocks, red, heavy_ctr, subs, runs, head_part, tail_part, sub_out, bucket_sums, meds);
         return;
     }
-    fixup_light<F>((blockIdx.x - heavy_blocks) * (blockDim.x >> 2) + (threadIdx.x >> 2), plan, offsets, head_part, tail_part, tail_key, bucket_sums, num_buckets);
+    fixup_light<F>((blockIdx.x - heavy_blocks) * (blockDim.x >> 2) + (threadIdx.x >> 2), (gridDim.x - heavy_blocks) * (blockDim.x >> 2), plan, offsets, head_part, tail_part,
+                   tail_key, bucket_sums, num_buckets, heavy_ctr, meds);
 }
 // stage B: one workgroup per heavy run: bucket = tail partial + sum of its sub-job results
 template <class F>

@@ -544,6 +544,24 @@ def test_emu_long_commits_and_host_batches_in_chunks(emu_lib, tune):
     emu_lib.free(d); key.close()
 
 
+def test_emu_medium_runs_both_placements(emu_lib):
+    """Runs cut into 7 .. 12 partials are placed on the device once their number is known (msm_kernels.cuh: MEDIUM_SPAN): MANY of
+    them BESIDE a really heavy run are summed as chains by the quads of the light section (6-bit windows over 3 000 dense scalars:
+    every bucket holds ~ 90 entries, nine segments of ten; 400 copies of one small value make one bucket heavy), many of them alone
+    or a FEW become sub-jobs of the heavy section (one value repeated 90 times under 9-bit windows:
+    one such run beside light ones).  The emulation build switches between the two at 8 runs."""
+    cid = 0
+    for n, c, dup in ((3000, 6, 400), (3000, 6, 0), (300, 9, 90)):     # many medium runs beside a really heavy one: chains; many alone, or a few: sub-jobs
+        bs = C.synth_bases(cid, n, seed=101 + c)
+        sc = C.synth_scalars(cid, n, seed=102 + c)
+        if dup:
+            sc[100:100 + dup] = ints_to_mont([5], P.CURVES[cid].r)[0]
+        key = cm.CommitmentKey(cid, bs, lib=emu_lib)
+        key.set_window_bits(c)
+        assert (key.commit(sc) == C.msm_pippenger(cid, sc, bs)).all(), (n, c)
+        key.close()
+
+
 @pytest.mark.parametrize("n,c", [(20000, 4)])
 def test_emu_heavy_subjob_grouping(emu_lib, n, c):
     """k_fixup_heavy_a gives a sub-job 16, 8, 4 or 2 quads by the number of sub-jobs: 4-bit windows over 20 000 dense scalars

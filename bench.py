@@ -622,7 +622,9 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
         # the *_glv figures below are what a caller gets since round 4 WITHOUT any opt-in.
         from mira_amd import _lib as L_
         lib.tune(L_.TUNE_GLV_AUTO_MAX_LOG, 0)
-        run(False); run(True)                                   # warm-up
+        SETTLE = 15           # commits of a shape before it is timed: the library checks the planner's width against its neighbours on the first ones (MIRA_TUNE_WIDTH_TRIALS)
+        for _ in range(SETTLE):
+            run(False); run(True)                               # warm-up
         def median_ms(batched, reps=5):
             ts, pts = [], None
             for _ in range(reps):
@@ -644,7 +646,8 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
                 else:
                     pts.extend(keys[c].commit(v) for v in h_cross[c])
             return pts
-        run_host(False); run_host(True)
+        for _ in range(SETTLE):
+            run_host(False); run_host(True)
         hs, hb = [], []
         for _ in range(5):
             t0 = time.perf_counter(); hseq_pts = run_host(False); hs.append((time.perf_counter() - t0) * 1e3)
@@ -656,7 +659,8 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
         # split -- every scalar as two 127-bit halves over half the windows wherever the planners estimate the split ahead; the same
         # 13 calls, one per commit, and the batched form
         lib.tune(L_.TUNE_GLV_AUTO_MAX_LOG, -1)                   # the default: both keys get their copies inside the first commits below
-        run(False)
+        for _ in range(SETTLE):
+            run(False); run(True)
         tglv, single_glv = [], []
         for _ in range(5):
             t0 = time.perf_counter(); glv_pts = run(False); tglv.append((time.perf_counter() - t0) * 1e3)
@@ -673,7 +677,8 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
         for c in plan:
             for width in (15, 13):
                 keys[c].precompute(width)
-        run(False)
+        for _ in range(3):
+            run(False); run(True)
         t16, single16 = [], []
         for _ in range(5):
             t0 = time.perf_counter(); t16_pts = run(False); t16.append((time.perf_counter() - t0) * 1e3)
@@ -870,7 +875,8 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
             return spans, outs
         from mira_amd import _lib as L_
         lib.tune(L_.TUNE_GLV_AUTO_MAX_LOG, 0)                   # `ms`: plain keys as in rounds 1 - 3 (comparable); `ms_glv` below: the library's default since round 4
-        fold_step()
+        for _ in range(15):                                     # the width trials of every shape of commit settle here (MIRA_TUNE_WIDTH_TRIALS)
+            fold_step()
         walls_i = []
         for _ in range(5):
             t0 = time.perf_counter(); spans_i, last_i = fold_step(); walls_i.append(((time.perf_counter() - t0) * 1e3, spans_i))
@@ -899,7 +905,8 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
         # the library's default since round 4 (2 x the keys' HBM): the same chain with the endomorphism copies of both keys, built by the
         # first commits below (the GLV split)
         lib.tune(L_.TUNE_GLV_AUTO_MAX_LOG, -1)
-        fold_step()
+        for _ in range(15):
+            fold_step()
         walls_g = []
         for _ in range(5):
             t0 = time.perf_counter(); spans_g, last_g = fold_step(); walls_g.append(((time.perf_counter() - t0) * 1e3, spans_g))

@@ -198,6 +198,11 @@ int mira_msm_last_table_bits(int32_t *table_bits);
  * first single commit or batch that can use it (commits of at most 2^21 pairs over keys of at least 2^12 points); default 26,
  * 0 = only where mira_msm_precompute_ex(handle, MIRA_TABLE_GLV) was called */
 #define MIRA_TUNE_GLV_AUTO_MAX_LOG 17
+/* 1 (default): the window width the planner picks for a shape of commit (pairs, commitments per submission, path) over a key is
+ * checked against its four neighbours on the first ten commits of that shape -- each candidate timed twice -- and the fastest
+ * measured is kept for the rest of the key's life (commits of >= 2^12 pairs, unforced widths, not the ranks of a sharded MSM); 0: the
+ * planner's tables alone decide */
+#define MIRA_TUNE_WIDTH_TRIALS 18
 int mira_set_tuning(int knob, int64_t value);
 
 /* Read a range of the registered key back in the reference layout (cache file writing,

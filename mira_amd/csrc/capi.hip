@@ -6,6 +6,7 @@
 #include "host_field.hpp"
 #include "glv_consts.h"
 #include <cerrno>
+#include <chrono>
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <thread>
@@ -518,6 +519,38 @@ static bool choose_glv(const Bases &bs, const MsmPlan &plain, const MsmPlan &spl
     } else if (!bs.glv && pairs > ((size_t)1 << 19)) return false;     // forced width, no estimates: a copy the caller asked for is used; none is built for sizes the split loses at
     return glv_ready(bs);
 }
+// ---- width trials (ctx.h: Bases::WidthTrial) ------------------------------------------------------------------------------------
+static constexpr size_t TRIAL_MIN_N = (size_t)1 << 12;
+static constexpr int TRIAL_RUNS = 2;
+static constexpr int TRIAL_OFFSETS[5] = {0, +1, -1, +2, -2};    // the model's width, then its neighbours: the landscape has bumps (a width that leaves a two-bit top window), so all five are measured rather than walked
+static Bases::WidthTrial *trial_for(const Bases &bs, size_t n, uint32_t count, uint32_t kind, uint32_t c_model) {
+    if (tuned(MIRA_TUNE_WIDTH_TRIALS, 1) == 0 || n * count < TRIAL_MIN_N) return nullptr;
+    for (auto &t : bs.trials)
+        if (t.n == n && t.count == count && t.kind == kind) { t.stamp = ++bs.trial_stamp; return &t; }
+    if (bs.trials.size() >= 12) {                            // a key sees a handful of shapes; the least recently used one goes
+        size_t lru = 0;
+        for (size_t i = 1; i < bs.trials.size(); i++) if (bs.trials[i].stamp < bs.trials[lru].stamp) lru = i;
+        bs.trials.erase(bs.trials.begin() + (long)lru);
+    }
+    Bases::WidthTrial t;
+    t.n = n; t.count = count; t.kind = kind; t.c0 = t.best_c = t.cur_c = c_model; t.stamp = ++bs.trial_stamp;
+    bs.trials.push_back(t);
+    return &bs.trials.back();
+}
+static uint32_t trial_width(const Bases::WidthTrial &t) { return t.done ? t.best_c : t.cur_c; }
+// the wall time of the commit that ran under trial_width(t)
+static void trial_report(Bases::WidthTrial &t, double us, uint32_t c_min, uint32_t c_max) {
+    if (t.done) return;
+    t.cur_us = t.cur_runs == 0 ? us : std::min(t.cur_us, us);
+    if (++t.cur_runs < TRIAL_RUNS) return;
+    if (t.best_us == 0 || t.cur_us < 0.98 * t.best_us) { t.best_us = t.cur_us; t.best_c = t.cur_c; }   // a neighbour must be ahead by more than the noise
+    for (t.steps++; t.steps < 5; t.steps++) {
+        const int c = (int)t.c0 + TRIAL_OFFSETS[t.steps];
+        if (c >= (int)c_min && c <= (int)c_max) { t.cur_c = (uint32_t)c; t.cur_runs = 0; return; }
+    }
+    t.done = true;
+}
+
 // allow_pieces: the caller combines the points itself with horner_pieces (a commit of this process); else the public partial
 // format, one point per window (*shape then has P = 1).
 static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scalars, size_t n, uint64_t *out_partial,
@@ -561,6 +594,13 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
     const MsmPlan p_split = glv_ok ? make_plan(2 * n, width, 1, 0, (use_hist && bs.stat_kind == 1) ? stat_any : nullptr, GLV_BITS) : p_plain;
     const bool glv = glv_ok && choose_glv(bs, p_plain, p_split, n);
     MsmPlan p = glv ? p_split : p_plain;
+    // the planner's width for this shape, checked against its neighbours on the first commits of the shape (trial_*)
+    // (not before the scalar statistics of the shape exist where they are collected: the model's width for a witness vector
+    // without them is the dense vector's, too far from the best one for its neighbourhood to hold it)
+    const bool stats_pending = use_hist && !stat_any;
+    Bases::WidthTrial *trial = (width == 0 && !sharded && !set && !table_mode && n && !stats_pending) ? trial_for(bs, n, 1, (glv ? 1u : 0u) | (h_scalars ? 2u : 0u), p.c) : nullptr;
+    if (trial && trial_width(*trial) != p.c)
+        p = glv ? make_plan(2 * n, (int32_t)trial_width(*trial), 1, 0, nullptr, GLV_BITS) : make_plan(n, (int32_t)trial_width(*trial), 1, 0, nullptr);
     p.glv = glv; p.glv_bases = glv ? bs.glv : nullptr;
     // (a commit of n W >= 2^32 entries is cut into point chunks inside the launch sequence, msm_host.cuh; the 31-bit limit is the
     // point index of a sorted entry, the sign in bit 31)
@@ -601,7 +641,10 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
                                              : msm_launch_table_grumpkin(bs, first, d_scalars, n, out_partial);
     }
     p.stats = use_hist;
+    const auto t_launch = std::chrono::steady_clock::now();
     rc = bs.curve == MIRA_CURVE_BN256 ? msm_launch_bn256(bs, first, d_scalars, h_scalars, n, p, out_partial) : msm_launch_grumpkin(bs, first, d_scalars, h_scalars, n, p, out_partial);
+    if (rc == MIRA_OK && trial)
+        trial_report(*trial, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_launch).count(), glv ? 5 : 4, 16);
     if (rc == MIRA_OK && use_hist) {                         // msm_launch ends with a stream synchronisation
         memcpy(bs.stat_hist, g.hist_host, sizeof bs.stat_hist);
         bs.stat_n = n; bs.stat_kind = glv ? 1 : 0;
@@ -680,14 +723,21 @@ static int msm_batch_device_locked(uint64_t handle, const void *d_scalars, size_
     for (size_t done = 0; done < count; done += per) {
         const size_t cnt = std::min(per, count - done);
         MsmPlan p = make_plan(nv, forced_c, (uint32_t)cnt, stride, nullptr, bits);
+        Bases::WidthTrial *trial = forced_c == 0 ? trial_for(bs, n, (uint32_t)cnt, (glv ? 1u : 0u) | (h_batch ? 2u : 0u), p.c) : nullptr;
+        if (trial && trial_width(*trial) != p.c && (uint64_t)((bits + trial_width(*trial) - 1) / trial_width(*trial)) * cnt * (1ull << (trial_width(*trial) - 1)) <= (1ull << 21))
+            p = make_plan(nv, (int32_t)trial_width(*trial), (uint32_t)cnt, stride, nullptr, bits);      // (a width whose counters one scan takes)
         p.glv = glv; p.glv_bases = glv ? bs.glv : nullptr;
         p.h_batch = h_batch ? h_batch + done : nullptr;
         plan_reduction(p, default_pieces(p, 1u << 20));
         g.last_c = (int32_t)p.c; g.last_w = (int32_t)p.W; g.last_table_c = 0;
         win.assign((size_t)p.Wt * p.pieces * 16, 0);
         const unsigned char *sc = reinterpret_cast<const unsigned char *>(d_scalars) + done * stride * 32;
+        const auto t_launch = std::chrono::steady_clock::now();
         rc = bs.curve == MIRA_CURVE_BN256 ? msm_launch_bn256(bs, 0, sc, nullptr, n, p, win.data()) : msm_launch_grumpkin(bs, 0, sc, nullptr, n, p, win.data());
         if (rc) return rc;
+        if (trial && trial_width(*trial) == p.c)
+            trial_report(*trial, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_launch).count(), glv ? 5 : 4, 16);
+        else if (trial) trial->done = true;                  // the candidate does not fit one scan: the walk ends where it is
         // the epilogues of a batch are independent chains of ~250 doublings (60 us each): one host thread per commitment
         const PartialShape sh{p.c, p.W, p.cb, p.pieces};
         auto epilogue = [&](size_t b) {
@@ -1040,7 +1090,7 @@ int mira_msm_combine(int curve, const uint64_t *partials, size_t nparts, int32_t
 }
 int mira_set_tuning(int knob, int64_t value) {
     std::lock_guard<std::mutex> lk(g_lock);
-    if (knob < 0 || knob > MIRA_TUNE_GLV_AUTO_MAX_LOG || (knob == MIRA_TUNE_PASS_ENTRIES_LOG && value > 32)) { set_error("unknown tuning knob"); return MIRA_E_BAD_ARG; }
+    if (knob < 0 || knob > MIRA_TUNE_WIDTH_TRIALS || (knob == MIRA_TUNE_PASS_ENTRIES_LOG && value > 32)) { set_error("unknown tuning knob"); return MIRA_E_BAD_ARG; }
     g.tune[knob] = value;
     return MIRA_OK;
 }

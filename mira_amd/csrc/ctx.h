@@ -136,6 +136,19 @@ struct Bases {
     mutable uint32_t stat_hist[256] = {0};
     mutable size_t stat_n = 0;
     mutable int stat_kind = 0;     // what was histogrammed: 0 = whole scalars (per-window path, shared-bucket sets), 1 = the halves of the GLV split
+    // Width trials (capi.hip: trial_*): successive fold steps commit vectors of one shape over one key thousands of times, so the
+    // planner's choice for a shape is CHECKED against its neighbours on the first few commits -- the model's width and the four
+    // around it, each timed twice -- and the fastest one measured is kept.  Never changes a result.
+    struct WidthTrial {
+        size_t n = 0; uint32_t count = 0, kind = 0;               // the shape: pairs, commitments per submission, bit 0 = GLV split, bit 1 = host scalars
+        uint32_t c0 = 0, best_c = 0, cur_c = 0;
+        double best_us = 0, cur_us = 0;
+        int cur_runs = 0, steps = 0;
+        bool done = false;
+        uint64_t stamp = 0;
+    };
+    mutable std::vector<WidthTrial> trials;
+    mutable uint64_t trial_stamp = 0;
 };
 
 void tm_begin();

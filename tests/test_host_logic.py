@@ -234,3 +234,39 @@ def test_lincomb_multi_matches_single_lincombs(emu_lib):
     assert b"share one buffer" in lib.c.mira_last_error()
     for p in d_v + d_multi + [d_one]:
         lib.free(p)
+
+
+def test_width_trials_settle_and_never_change_the_point(emu_lib):
+    """MIRA_TUNE_WIDTH_TRIALS (default on): the planner's width for a shape of commit is checked against its neighbours on the first
+    commits of that shape -- the model's width and its four neighbours, each timed twice -- and the fastest measured is kept.  Every commit returns the same point; the width settles; with the knob off the planner's width is
+    used from the first call on; a forced width is never tried against anything."""
+    import ctypes
+    lib = emu_lib
+    cid, n = 1, 1 << 12
+    key = cm.CommitmentKey.synthetic(cid, n, seed=71, lib=lib)
+    d = cm.synth_scalars_device(cid, n, seed=72, kind=1, lib=lib)
+    lib.tune(_lib_mod.TUNE_GLV_AUTO_MAX_LOG, 0)
+    c, w = ctypes.c_int32(), ctypes.c_int32()
+
+    def commit():
+        pt = key.commit_device(d, n)
+        lib.check(lib.c.mira_msm_last_plan(ctypes.byref(c), ctypes.byref(w)))
+        return pt, c.value
+    try:
+        lib.tune(_lib_mod.TUNE_WIDTH_TRIALS, 0)
+        want, c_model = commit()
+        assert commit()[1] == c_model
+        lib.tune(_lib_mod.TUNE_WIDTH_TRIALS, -1)
+        widths = []
+        for _ in range(14):                                    # 2 runs x (the model's width + four neighbours) = 10 calls, then settled
+            pt, cw = commit()
+            assert (pt == want).all()
+            widths.append(cw)
+        c_stats = widths[0]                                    # (the model's width once the statistics of the first commit exist)
+        assert widths[:10] == [c_stats, c_stats, c_stats + 1, c_stats + 1, c_stats - 1, c_stats - 1, c_stats + 2, c_stats + 2, c_stats - 2, c_stats - 2]
+        assert len(set(widths[10:])) == 1 and abs(widths[-1] - c_stats) <= 2
+        key.set_window_bits(7)
+        assert commit()[1] == 7 and commit()[1] == 7
+    finally:
+        lib.tune(_lib_mod.TUNE_WIDTH_TRIALS, -1); lib.tune(_lib_mod.TUNE_GLV_AUTO_MAX_LOG, -1)
+        lib.free(d); key.close()

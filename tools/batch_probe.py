@@ -3,13 +3,15 @@ import os, sys, time, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mira_amd import _lib, commitment as cm
 lib = _lib.load()
+for kv in filter(None, os.environ.get("TUNE", "").split(",")):     # TUNE=12=3,13=2: mira_set_tuning(knob, value)
+    k_, v_ = kv.split("="); lib.tune(int(k_), int(v_))
 n = 1 << 17
 for cid, cnt in ((0, 6), (1, 5)):
     key = cm.CommitmentKey.synthetic(cid, n)
     d = cm.synth_scalars_device(cid, cnt * n, seed=77)
     for c in (0, 12, 13, 14, 15, 16):
         lib.check(lib.c.mira_msm_set_window_bits(c))
-        key.commit_batch_device(d, n, cnt)
+        for _ in range(16 if c == 0 else 2): key.commit_batch_device(d, n, cnt)      # planned: incl. the width trials of the shape
         ts = []
         for _ in range(5):
             t0 = time.perf_counter(); key.commit_batch_device(d, n, cnt); ts.append((time.perf_counter() - t0) * 1e3)

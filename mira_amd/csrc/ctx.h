@@ -33,6 +33,25 @@ static inline hipError_t rt_sync(hipStream_t s) { return hipStreamSynchronize(s)
 static inline hipError_t rt_last() { return hipGetLastError(); }
 static inline hipError_t rt_host_alloc(void **p, size_t n) { return hipHostMalloc(p, n, hipHostMallocDefault); }
 static inline hipError_t rt_host_free(void *p) { return hipHostFree(p); }
+// pinned host memory a kernel writes directly (fine-grained, coherent): *dev is the address the device uses for *host
+static inline hipError_t rt_host_alloc_mapped(void **host, void **dev, size_t n) {
+    hipError_t e = hipHostMalloc(host, n, hipHostMallocMapped | hipHostMallocCoherent);
+    return e != hipSuccess ? e : hipHostGetDevicePointer(dev, *host, 0);
+}
+// Wait until a kernel on `s` has stored `stamp` into the mapped word `flag` (its results lie in mapped memory in front of
+// that store).  Spins on the word -- hipStreamSynchronize costs 4 - 7 us more (tools/host_epilogue_probe.hip) -- and asks
+// the stream now and then, so that a kernel that died ends the wait with the runtime's error.
+static inline hipError_t rt_wait_flag(const uint64_t *flag, uint64_t stamp, hipStream_t s) {
+    for (uint64_t spins = 1;; spins++) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == stamp) return hipSuccess;
+        if ((spins & 0xFFF) == 0) {
+            const hipError_t q = hipStreamQuery(s);
+            if (q == hipSuccess) return __atomic_load_n(flag, __ATOMIC_ACQUIRE) == stamp ? hipSuccess : hipErrorUnknown;
+            if (q != hipErrorNotReady) return q;
+        }
+        __builtin_ia32_pause();
+    }
+}
 static inline hipError_t rt_event_sync(hipEvent_t e) { return hipEventSynchronize(e); }
 // `waiter` does not start work enqueued after this call before everything enqueued on `done` so far has finished
 static inline hipError_t rt_stream_wait(hipStream_t waiter, hipStream_t done, hipEvent_t ev) {
@@ -54,6 +73,8 @@ static inline int rt_sync(hipStream_t) { return 0; }
 static inline int rt_last() { return 0; }
 static inline int rt_host_alloc(void **p, size_t n) { *p = malloc(n); return *p ? 0 : 1; }
 static inline int rt_host_free(void *p) { free(p); return 0; }
+static inline int rt_host_alloc_mapped(void **host, void **dev, size_t n) { *host = malloc(n); *dev = *host; return *host ? 0 : 1; }
+static inline int rt_wait_flag(const uint64_t *flag, uint64_t stamp, hipStream_t) { return *flag == stamp ? 0 : 1; }   // kernels have run when the launch returns
 #endif
 
 struct DevBuf {
@@ -112,7 +133,8 @@ struct Ctx {
     int32_t last_c = 0, last_w = 0;  // mira_msm_last_plan
     int32_t last_table_c = 0;        // mira_msm_last_table_bits: width of the table set the last commit went through, 0 = none
     uint32_t hist_sel = 0;           // which of the two device histograms the next commit adds into
-    unsigned char *out_host = nullptr; size_t out_host_cap = 0;   // pinned staging of window sums + statistics   // cross-term evaluator: staged program, intermediates[slot][lane]
+    unsigned char *out_host = nullptr, *out_host_dev = nullptr; size_t out_host_cap = 0;   // mapped pinned memory: k_set_finish writes the pieces + statistics + a flag word there
+    uint64_t out_stamp = 0; DevBuf finish_ctr;   // cross-term evaluator: staged program, intermediates[slot][lane]
     void *windows_dst = nullptr;     // mira_msm_partial_to_device: device destination of the window sums of the call in flight
     uint64_t next_handle = 1;
 };

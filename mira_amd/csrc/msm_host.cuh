@@ -21,7 +21,8 @@ static constexpr uint32_t FIXUP_HEAVY_GRID = 1024;   // waves of either heavy st
 
 // quads for the bucket reduction while its work items number less than ~1.5 waves per SIMD (the
 // chain of dependent additions is what takes the time there); single lanes beyond (throughput)
-static constexpr uint32_t SCAN_SOLO_TILES = 2;      // up to 4096 bucket counters: k_scan_c<true> (measured: 14 -> 7 us for one tile, 15 -> 13 for two, 16 -> 30 for seven)
+static constexpr uint32_t SCAN_OWN_PREFIX_TILES = 32;   // up to 2^16 bucket counters: k_scan_c<SCAN_OWN_PREFIX>, one launch instead of three
+static constexpr uint32_t SCAN_SOLO_TILES = 2;      // up to 4096 bucket counters: k_scan_c<SCAN_SOLO> (measured: 14 -> 7 us for one tile, 15 -> 13 for two, 16 -> 30 for seven)
 static inline bool reduce_with_quads(uint64_t work_items) { return work_items * 4 <= 98304; }
 #ifdef MIRA_CPU_EMU
 static constexpr uint32_t SET_FINISH_BLOCK = 32;      // emulated lanes are OS threads
@@ -194,7 +195,12 @@ static int msm_launch_body(const Bases &bs, size_t first, const void *d_scalars,
                        p.B, tile, reinterpret_cast<uint32_t *>(g.counts.p), wgroup);
         tm_mark("hist");
         if (scan_blocks <= SCAN_SOLO_TILES) {                 // few buckets: one workgroup scans them all, one launch instead of three
-            LAUNCH_BARRIER(k_scan_c<true>, 1, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.counts.p), p.NB,
+            LAUNCH_BARRIER(k_scan_c<SCAN_SOLO>, 1, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.counts.p), p.NB,
+                           reinterpret_cast<const uint32_t *>(g.block_sums.p), reinterpret_cast<uint32_t *>(g.offsets.p),
+                           reinterpret_cast<uint32_t *>(g.cursor.p), staged ? reinterpret_cast<uint32_t *>(g.coarse_offsets.p) : no_u32, fine_bits,
+                           plan, p.lanes, p.L, heavy_count, add ? no_u8 : reinterpret_cast<unsigned char *>(g.bucket_sums.p));
+        } else if (scan_blocks <= SCAN_OWN_PREFIX_TILES) {    // the bucket counts of the small commits: every workgroup sums what lies in front of it
+            LAUNCH_BARRIER(k_scan_c<SCAN_OWN_PREFIX>, scan_blocks, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.counts.p), p.NB,
                            reinterpret_cast<const uint32_t *>(g.block_sums.p), reinterpret_cast<uint32_t *>(g.offsets.p),
                            reinterpret_cast<uint32_t *>(g.cursor.p), staged ? reinterpret_cast<uint32_t *>(g.coarse_offsets.p) : no_u32, fine_bits,
                            plan, p.lanes, p.L, heavy_count, add ? no_u8 : reinterpret_cast<unsigned char *>(g.bucket_sums.p));
@@ -202,7 +208,7 @@ static int msm_launch_body(const Bases &bs, size_t first, const void *d_scalars,
         LAUNCH_BARRIER(k_scan_a, scan_blocks, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.counts.p), p.NB,
                        reinterpret_cast<uint32_t *>(g.block_sums.p));
         LAUNCH_BARRIER(k_scan_b, 1, 1024, 0, st, reinterpret_cast<uint32_t *>(g.block_sums.p), scan_blocks);
-        LAUNCH_BARRIER(k_scan_c<false>, scan_blocks, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.counts.p), p.NB,
+        LAUNCH_BARRIER(k_scan_c<SCAN_BLOCK_SUMS>, scan_blocks, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.counts.p), p.NB,
                        reinterpret_cast<const uint32_t *>(g.block_sums.p), reinterpret_cast<uint32_t *>(g.offsets.p),
                        reinterpret_cast<uint32_t *>(g.cursor.p), staged ? reinterpret_cast<uint32_t *>(g.coarse_offsets.p) : no_u32, fine_bits,
                        plan, p.lanes, p.L, heavy_count, add ? no_u8 : reinterpret_cast<unsigned char *>(g.bucket_sums.p));
@@ -262,23 +268,39 @@ static int msm_launch_body(const Bases &bs, size_t first, const void *d_scalars,
         LAUNCH_BARRIER((k_bucket_tree<F, false>), tree_groups, std::max(4u, 1u << p.kappa), lds_a, st, reinterpret_cast<const unsigned char *>(g.bucket_sums.p),
                        p.lambda, p.kappa, reinterpret_cast<unsigned char *>(g.chunks.p));
     tm_mark("reduce_chunks");
-    LAUNCH_BARRIER(k_set_finish<F>, p.nsets, SET_FINISH_BLOCK, lds_b, st, reinterpret_cast<const unsigned char *>(g.chunks.p), p.kappa + 2, p.gamma, p.lambda, pc,
-                   reinterpret_cast<unsigned char *>(g.window_sums.p), (const uint32_t *)hist);
-    tm_mark("window_sum");
-    RT_CHECK(rt_last());
+    uint32_t *no_ctr = nullptr;
+    uint64_t *no_flag = nullptr;
     if (g.windows_dst) {                                     // mira_msm_partial_to_device: the sums stay in device memory
+        LAUNCH_BARRIER(k_set_finish<F>, p.nsets, SET_FINISH_BLOCK, lds_b, st, reinterpret_cast<const unsigned char *>(g.chunks.p), p.kappa + 2, p.gamma, p.lambda, pc,
+                       reinterpret_cast<unsigned char *>(g.window_sums.p), (const uint32_t *)hist, no_ctr, no_flag, (uint64_t)0);
+        tm_mark("window_sum");
+        RT_CHECK(rt_last());
         RT_CHECK(rt_d2d(g.windows_dst, g.window_sums.p, (size_t)npts * 128, st));
         RT_CHECK(rt_sync(st));
-    } else {                                                 // pieces (and statistics) in one copy, through pinned memory
-        const size_t bytes = (size_t)npts * 128 + (p.stats ? 1024 : 0);
-        if (g.out_host_cap < bytes) {
+    } else {
+        // pieces (and statistics) straight into mapped pinned memory, a flag word behind them: no copy command, no
+        // hipStreamSynchronize (7 us of a commit, tools/host_epilogue_probe.hip)
+        const size_t bytes = (size_t)npts * 128 + 1024, flag_at = (bytes + 63) / 64 * 64;
+        if (g.out_host_cap < flag_at + 64) {
+            RT_CHECK(rt_sync(st));
             if (g.out_host) (void)rt_host_free(g.out_host);
-            g.out_host = nullptr; g.out_host_cap = 0;
-            RT_CHECK(rt_host_alloc(reinterpret_cast<void **>(&g.out_host), bytes + 4096));
-            g.out_host_cap = bytes + 4096;
+            g.out_host = g.out_host_dev = nullptr; g.out_host_cap = 0;
+            RT_CHECK(rt_host_alloc_mapped(reinterpret_cast<void **>(&g.out_host), reinterpret_cast<void **>(&g.out_host_dev), flag_at + 64 + 4096));
+            g.out_host_cap = flag_at + 64 + 4096;
         }
-        RT_CHECK(rt_d2h(g.out_host, g.window_sums.p, bytes, st));
-        RT_CHECK(rt_sync(st));
+        if (!g.finish_ctr.p) {
+            if ((rc = g.finish_ctr.ensure(64))) return rc;
+            RT_CHECK(rt_memset(g.finish_ctr.p, 0, 64, st));
+        }
+        uint64_t *flag_host = reinterpret_cast<uint64_t *>(g.out_host + flag_at);
+        const uint64_t stamp = ++g.out_stamp;
+        __atomic_store_n(flag_host, (uint64_t)0, __ATOMIC_RELEASE);
+        LAUNCH_BARRIER(k_set_finish<F>, p.nsets, SET_FINISH_BLOCK, lds_b, st, reinterpret_cast<const unsigned char *>(g.chunks.p), p.kappa + 2, p.gamma, p.lambda, pc,
+                       g.out_host_dev, (const uint32_t *)hist, reinterpret_cast<uint32_t *>(g.finish_ctr.p), reinterpret_cast<uint64_t *>(g.out_host_dev + flag_at), stamp);
+        tm_mark("window_sum");
+        RT_CHECK(rt_last());
+        if (g.tm.enabled) RT_CHECK(rt_sync(st));
+        RT_CHECK(rt_wait_flag(flag_host, stamp, st));
         memcpy(host_windows, g.out_host, (size_t)npts * 128);
         if (p.stats) memcpy(g.hist_host, g.out_host + (size_t)npts * 128, 1024);
     }
@@ -424,7 +446,7 @@ static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars
     tm_mark("hist");
     LAUNCH_BARRIER(k_scan_a, 1, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.counts.p), TABLE_CB, reinterpret_cast<uint32_t *>(g.block_sums.p));
     LAUNCH_BARRIER(k_scan_b, 1, 1024, 0, st, reinterpret_cast<uint32_t *>(g.block_sums.p), 1u);
-    LAUNCH_BARRIER(k_scan_c<false>, 1, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.counts.p), TABLE_CB,
+    LAUNCH_BARRIER(k_scan_c<SCAN_BLOCK_SUMS>, 1, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.counts.p), TABLE_CB,
                    reinterpret_cast<const uint32_t *>(g.block_sums.p), reinterpret_cast<uint32_t *>(g.coarse_offsets.p),
                    reinterpret_cast<uint32_t *>(g.cursor.p), no_u32, 0u, no_u32, 0u, 0u, no_u32, no_u8);
     tm_mark("scan");
@@ -440,7 +462,7 @@ static int msm_launch_table(const Bases &bs, size_t first, const void *d_scalars
     const uint32_t fscan = ceil_div(TABLE_B, SCAN_TILE);
     LAUNCH_BARRIER(k_scan_a, fscan, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.fine_counts.p), TABLE_B, reinterpret_cast<uint32_t *>(g.block_sums.p));
     LAUNCH_BARRIER(k_scan_b, 1, 1024, 0, st, reinterpret_cast<uint32_t *>(g.block_sums.p), fscan);
-    LAUNCH_BARRIER(k_scan_c<false>, fscan, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.fine_counts.p), TABLE_B,
+    LAUNCH_BARRIER(k_scan_c<SCAN_BLOCK_SUMS>, fscan, SCAN_BLOCK, 0, st, reinterpret_cast<const uint32_t *>(g.fine_counts.p), TABLE_B,
                    reinterpret_cast<const uint32_t *>(g.block_sums.p), reinterpret_cast<uint32_t *>(g.offsets.p), reinterpret_cast<uint32_t *>(g.fine_cursor.p),
                    no_u32, 0u, plan, lanes, Lmin, heavy_count, reinterpret_cast<unsigned char *>(g.bucket_sums.p));
     tm_mark("bucket_count_scan");

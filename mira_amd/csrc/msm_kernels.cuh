@@ -205,17 +205,38 @@ KERNEL void k_scan_b(uint32_t *__restrict__ block_sums, uint32_t nblocks) {
 //   plan     {L, T} of k_accumulate -- segment length chosen once the number of non-zero digits is
 //            known: exactly one segment per resident lane (every SIMD slot busy for the whole kernel
 //            and all lanes finishing together), never shorter than min_L -- and heavy_ctr cleared
-// SOLO: ONE workgroup walks all the tiles itself, carrying the running total -- for small bucket counts
+// SCAN_SOLO: ONE workgroup walks all the tiles itself, carrying the running total -- for small bucket counts
 // (a commit of 2^17 pairs under 8-bit windows has 4096 buckets) one launch instead of three.
-template <bool SOLO = false>
+// SCAN_OWN_PREFIX: every workgroup first sums the counters in front of its tile itself (16-byte loads, all from L2) -- quadratic
+// in the number of tiles, so for the bucket counts of the small commits only (<= SCAN_OWN_PREFIX_TILES tiles: 2^16 counters, 128 KiB
+// read by the last workgroup); again one launch instead of three, and no block_sums.
+enum : int { SCAN_BLOCK_SUMS = 0, SCAN_SOLO = 1, SCAN_OWN_PREFIX = 2 };
+template <int MODE = SCAN_BLOCK_SUMS>
 KERNEL void k_scan_c(const uint32_t *__restrict__ counts, uint32_t NB, const uint32_t *__restrict__ block_sums,
                      uint32_t *__restrict__ offsets, uint32_t *__restrict__ cursor, uint32_t *__restrict__ cursor1, uint32_t fine_bits,
                      uint32_t *__restrict__ plan, uint32_t resident_lanes, uint32_t min_L, uint32_t *__restrict__ heavy_ctr,
                      unsigned char *__restrict__ bucket_sums) {
     __shared__ uint32_t buf[SCAN_BLOCK], carry_s;
     const uint32_t ntiles = (NB + SCAN_TILE - 1) / SCAN_TILE;
+    constexpr bool SOLO = MODE == SCAN_SOLO;
     if (SOLO) {
         if (threadIdx.x == 0) carry_s = 0;
+        __syncthreads();
+    }
+    if (MODE == SCAN_OWN_PREFIX) {
+        const U4 *cv = reinterpret_cast<const U4 *>(counts);
+        uint32_t pre = 0;
+        for (uint32_t q = threadIdx.x; q < blockIdx.x * (SCAN_TILE / 4); q += SCAN_BLOCK) {
+            const U4 v = cv[q];
+            pre += v.x + v.y + v.z + v.w;
+        }
+        buf[threadIdx.x] = pre;
+        __syncthreads();
+        for (uint32_t st = SCAN_BLOCK / 2; st > 0; st >>= 1) {
+            if (threadIdx.x < st) buf[threadIdx.x] += buf[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) carry_s = buf[0];
         __syncthreads();
     }
     for (uint32_t tile = SOLO ? 0 : blockIdx.x; tile < (SOLO ? ntiles : blockIdx.x + 1); tile++) {
@@ -233,7 +254,7 @@ KERNEL void k_scan_c(const uint32_t *__restrict__ counts, uint32_t NB, const uin
             buf[threadIdx.x] += add;
             __syncthreads();
         }
-        uint32_t run = (SOLO ? carry_s : block_sums[tile]) + buf[threadIdx.x] - s;
+        uint32_t run = (MODE != SCAN_BLOCK_SUMS ? carry_s : block_sums[tile]) + buf[threadIdx.x] - s;
         for (int k = 0; k < SCAN_ITEMS; k++) {
             if (base + k < NB) {
                 offsets[base + k] = run; cursor[base + k] = run;

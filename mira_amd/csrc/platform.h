@@ -43,6 +43,8 @@ static __device__ __forceinline__ uint32_t quad_lane() { return threadIdx.x & 3u
 template <int K> static __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, K * 0x55, 0xF, 0xF, true);   // quad_perm:[K,K,K,K]
 }
+// a word of mapped host memory the host spins on (ctx.h: rt_wait_flag)
+static __device__ __forceinline__ void store_release_system(uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 #define DYN_SHARED(type, name) extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw[]; type *name = reinterpret_cast<type *>(name##_raw)
 #else
 #include "../../tests/emu/emu.h"

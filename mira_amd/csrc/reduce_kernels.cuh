@@ -103,7 +103,10 @@ KERNEL void __launch_bounds__(512) k_bucket_tree(const unsigned char *__restrict
 template <class F>
 KERNEL void __launch_bounds__(512) k_set_finish(const unsigned char *__restrict__ nodes, uint32_t S0, uint32_t gamma, uint32_t lambda, PieceCfg pc,
                                                 unsigned char *__restrict__ out,
-                                                const uint32_t *__restrict__ hist) {   // planning statistics (or null): copied behind the pieces, one copy to the host for both
+                                                const uint32_t *__restrict__ hist,     // planning statistics (or null): copied behind the pieces, one copy to the host for both
+                                                uint32_t *__restrict__ done_ctr, uint64_t *__restrict__ flag, uint64_t stamp) {
+    // flag (or null): `out` is mapped host memory; the workgroup that finishes last stores `stamp` there, behind everybody's
+    // results (system-scope fences on both sides of the device-scope counter), and leaves the counter at zero for the next launch
     DYN_SHARED(unsigned char, slots);
     const uint32_t set = blockIdx.x;
     if (hist && set == 0)
@@ -115,13 +118,22 @@ KERNEL void __launch_bounds__(512) k_set_finish(const unsigned char *__restrict_
     __syncthreads();
     node_tree_quad<F>(slots, S0, gamma);
     const uint32_t p = threadIdx.x >> 2;
-    if (p >= pc.P) return;
-    // Horner over the bit positions of the piece, highest first; positions 1 .. lambda - 1 hold nothing
-    Xyzz29<F> acc = xyzz29_identity<F>();
-    for (int pos = (int)pc.start[p + 1] - 1; pos >= (int)pc.start[p]; pos--) {
-        acc = xyzz29_double_quad(acc);
-        if (pos == 0) xyzz29_add_quad(acc, xyzz29_load<F>(slots + XYZZ29_BYTES));
-        if (pos >= (int)lambda) xyzz29_add_quad(acc, xyzz29_load<F>(slots + (size_t)(2 + pos - (int)lambda) * XYZZ29_BYTES));
+    if (p < pc.P) {
+        // Horner over the bit positions of the piece, highest first; positions 1 .. lambda - 1 hold nothing
+        Xyzz29<F> acc = xyzz29_identity<F>();
+        for (int pos = (int)pc.start[p + 1] - 1; pos >= (int)pc.start[p]; pos--) {
+            acc = xyzz29_double_quad(acc);
+            if (pos == 0) xyzz29_add_quad(acc, xyzz29_load<F>(slots + XYZZ29_BYTES));
+            if (pos >= (int)lambda) xyzz29_add_quad(acc, xyzz29_load<F>(slots + (size_t)(2 + pos - (int)lambda) * XYZZ29_BYTES));
+        }
+        if (quad_lane() == 0) xyzz29_export_r256(out + ((size_t)set * pc.P + p) * 128, acc);
     }
-    if (quad_lane() == 0) xyzz29_export_r256(out + ((size_t)set * pc.P + p) * 128, acc);
+    if (!flag) return;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(done_ctr, 1u) == gridDim.x - 1) {
+        *done_ctr = 0;
+        __threadfence_system();
+        store_release_system(flag, stamp);
+    }
 }

@@ -36,6 +36,8 @@ template <class T> inline T atomicMax(T *p, T v) {
 }
 #define WAVE_SYNC() __syncthreads()   /* emulated lanes are OS threads: a wave-level exchange needs the block barrier (control flow is block-uniform wherever it is used) */
 inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+inline void __threadfence_system() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+inline void store_release_system(uint64_t *p, uint64_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
 inline unsigned __brev(unsigned x) {
     unsigned r = 0;
     for (int i = 0; i < 32; i++) r |= ((x >> i) & 1u) << (31 - i);

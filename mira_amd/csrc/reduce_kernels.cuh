@@ -111,9 +111,9 @@ KERNEL void __launch_bounds__(512) k_set_finish(const unsigned char *__restrict_
     const uint32_t set = blockIdx.x;
     if (hist && set == 0)
         for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) reinterpret_cast<uint32_t *>(out + (size_t)gridDim.x * pc.P * 128)[i] = hist[i];
-    const uint32_t words = (S0 << gamma) * (XYZZ29_BYTES / 4);
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(nodes + (size_t)set * (S0 << gamma) * XYZZ29_BYTES);
-    uint32_t *dst = reinterpret_cast<uint32_t *>(slots);
+    const uint32_t words = (S0 << gamma) * (XYZZ29_BYTES / 16);      // 16 bytes per lane and trip (a point is nine of them)
+    const U4 *src = reinterpret_cast<const U4 *>(nodes + (size_t)set * (S0 << gamma) * XYZZ29_BYTES);
+    U4 *dst = reinterpret_cast<U4 *>(slots);
     for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
     __syncthreads();
     node_tree_quad<F>(slots, S0, gamma);

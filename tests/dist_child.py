@@ -36,7 +36,9 @@ def main():
         out["too_long"] = None
     except cm.TooLongInput as e:
         out["too_long"] = [e.input_len, e.limit]
-    # the single-GPU planner on a fresh key (no statistics yet) picks the width the sharded key derives
+    # the single-GPU per-window planner on a fresh key (no statistics yet) picks the width the sharded key derives
+    # (the endomorphism split, which a lone GPU takes by default at this size, is not a sharded partial's business: off)
+    lib.tune(_lib.TUNE_GLV_AUTO_MAX_LOG, 0)
     plain = cm.CommitmentKey.synthetic(cid, n, seed=0x1234)
     plain.commit_device(d, n)
     c, w = ctypes.c_int32(), ctypes.c_int32()

@@ -44,7 +44,7 @@ static inline hipError_t rt_host_alloc_mapped(void **host, void **dev, size_t n)
 static inline hipError_t rt_wait_flag(const uint64_t *flag, uint64_t stamp, hipStream_t s) {
     for (uint64_t spins = 1;; spins++) {
         if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == stamp) return hipSuccess;
-        if ((spins & 0xFFF) == 0) {
+        if ((spins & 0xFFFF) == 0) {
             const hipError_t q = hipStreamQuery(s);
             if (q == hipSuccess) return __atomic_load_n(flag, __ATOMIC_ACQUIRE) == stamp ? hipSuccess : hipErrorUnknown;
             if (q != hipErrorNotReady) return q;

@@ -299,7 +299,8 @@ static int msm_launch_body(const Bases &bs, size_t first, const void *d_scalars,
                        g.out_host_dev, (const uint32_t *)hist, reinterpret_cast<uint32_t *>(g.finish_ctr.p), reinterpret_cast<uint64_t *>(g.out_host_dev + flag_at), stamp);
         tm_mark("window_sum");
         RT_CHECK(rt_last());
-        if (g.tm.enabled) RT_CHECK(rt_sync(st));
+        // a long commit waits in hipStreamSynchronize as before (nothing to gain there, and the spin asks the stream now and then)
+        if (g.tm.enabled || (size_t)n * p.count > ((size_t)1 << 21)) RT_CHECK(rt_sync(st));
         RT_CHECK(rt_wait_flag(flag_host, stamp, st));
         memcpy(host_windows, g.out_host, (size_t)npts * 128);
         if (p.stats) memcpy(g.hist_host, g.out_host + (size_t)npts * 128, 1024);

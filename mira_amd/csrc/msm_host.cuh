@@ -15,7 +15,10 @@
 static constexpr uint32_t FIXUP_HEAVY_GRID = 4;     // emulated lanes are OS threads: keep the idle grid small (stage A: a quarter of it)
 static constexpr uint32_t FIXUP_HEAVY_BLOCKS = 1;
 #else
-static constexpr uint32_t FIXUP_HEAVY_BLOCKS = 256; // workgroups of k_fixup_all that take the heavy sub-jobs: one per CU (they leave at once when there are none)
+#ifndef MIRA_FIXUP_HEAVY_BLOCKS
+#define MIRA_FIXUP_HEAVY_BLOCKS 256
+#endif
+static constexpr uint32_t FIXUP_HEAVY_BLOCKS = MIRA_FIXUP_HEAVY_BLOCKS; // workgroups of k_fixup_all that take the heavy sub-jobs: one per CU (they leave at once when there are none)
 static constexpr uint32_t FIXUP_HEAVY_GRID = 1024;   // waves of either heavy stage = 256 workgroups of 256 lanes, one per CU (the sub-jobs of stage A are sized to just fill them; dispatching 1024 mostly idle workgroups alone took 15 us)
 #endif
 

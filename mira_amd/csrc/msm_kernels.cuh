@@ -597,7 +597,8 @@ DEV void fixup_heavy_a(uint32_t block, uint32_t nblocks, unsigned char *red, con
     // sub-jobs [0, nheavy) come from the heavy runs; a FEW medium runs follow them as sub-jobs of their own (one each)
     const uint32_t nheavy = heavy_ctr[1], n_medium = heavy_ctr[5], qi = threadIdx.x >> 2;
     const uint32_t nsubs = nheavy + (medium_as_chains(heavy_ctr) ? 0u : n_medium);
-    uint32_t lg = nsubs > 4096 ? 1u : nsubs > 2048 ? 2u : nsubs > 1024 ? 3u : 4u;              // quads per sub-job = 2^lg
+    uint32_t lg = 4;                                                                            // quads per sub-job = 2^lg: as many as the stage's workgroups hold, 2 .. 16
+    while (lg > 1 && (nsubs << lg) > nblocks * (HEAVY_BLOCK_A / 4)) lg--;
     while ((1u << lg) > HEAVY_BLOCK_A / 4) lg--;                                                // (never more than a workgroup has)
     const uint32_t gq = 1u << lg, spb = (HEAVY_BLOCK_A / 4) >> lg, ql = qi & (gq - 1u);       // sub-jobs per workgroup
     for (uint32_t s0 = block * spb; s0 < nsubs; s0 += nblocks * spb) {

@@ -7,6 +7,9 @@
 // NTT host side
 using HFr = hostf::HFe<FrP>;
 static constexpr uint32_t NTT_PERSISTENT_GRID = 256;
+// g.ntt_consts: [0, 256) uploaded constants (omega, scales, zeta powers); [1024, 4096) the work counters of k_ntt_wave, one
+// 128-byte line per (pass, range): zeroed at the head of every transform
+static constexpr size_t NTT_CONSTS_BYTES = 4096, NTT_CTR_OFFSET = 1024, NTT_CTR_PASS_BYTES = NTTW_RANGES * NTTW_CTR_STRIDE * 4;
 static constexpr uint32_t NTT_SINGLE_TW_LOG = 16;      // post-twiddle exponents below 2^16: one 3 MiB table instead of a two-table product   // workgroups per resident round: one per CU times what fits a CU
 static HFr fr_root_of_unity(bool inverse) {
     // ROOT_OF_UNITY = 7^((r-1) >> 28); multiplicative generator 7, S = 28 (halo2curves bn256::Fr)
@@ -115,7 +118,7 @@ static int ntt_prepare_tables(uint32_t log_n, const uint64_t omega[4], const HFr
         if (full0) { set_error(""); return ntt_prepare_tables(log_n, omega, scale261, t, false); }
         return rc;
     }
-    if ((rc = g.ntt_consts.ensure(256))) return rc;
+    if ((rc = g.ntt_consts.ensure(NTT_CONSTS_BYTES))) return rc;
     RT_CHECK(rt_h2d(g.ntt_consts.p, omega, 32, g.stream));
     RT_CHECK(rt_h2d(reinterpret_cast<unsigned char *>(g.ntt_consts.p) + 32, scale261.l, 32, g.stream));
     unsigned char *tab = reinterpret_cast<unsigned char *>(g.ntt_set[slot].p);
@@ -164,6 +167,8 @@ static int ntt_device_locked(void *d_a, uint32_t log_n, const uint64_t omega[4],
     if (scale) memcpy(s_final.l, scale, 32);
     const HFr scale261 = hostf::mul(hostf::mul(s_final, hostf::from_u64<FrP>(32)), hostf::r2<FrP>());
     if ((rc = ntt_prepare_tables(log_n, omega, scale261, t))) return rc;
+    if ((rc = g.ntt_consts.ensure(NTT_CONSTS_BYTES))) return rc;
+    RT_CHECK(rt_memset(reinterpret_cast<unsigned char *>(g.ntt_consts.p) + NTT_CTR_OFFSET, 0, 3 * NTT_CTR_PASS_BYTES, g.stream));
     tm_mark("twiddle_tables");
     const unsigned char *tab = reinterpret_cast<const unsigned char *>(g.ntt_set[g.ntt_set_cur].p);
     unsigned char *scale_d = nullptr;
@@ -193,7 +198,7 @@ static int ntt_device_locked(void *d_a, uint32_t log_n, const uint64_t omega[4],
         // persistent grid: as many workgroups per CU as LDS and the 2048-lane limit allow (one for
         // 4096-point lines, eight for the 512-point lines of the three-pass schedule)
         if (use_wave && ps.log_len <= (uint32_t)NTTW_LOG) {
-            // one wave per 256 points, four waves per workgroup, three workgroups (12 waves) per CU
+            // one wave per 256 points, four waves per workgroup, NTTW_OCC workgroups per CU
             const uint32_t lpw = 1u << (NTTW_LOG - ps.log_len);
             const uint32_t nbg = ceil_div(ceil_div(ps.nlines, lpw), NTTW_WAVES);
             // the NTTW_WAVES * lpw lines of a workgroup form a tile when they are adjacent in memory
@@ -203,8 +208,9 @@ static int ntt_device_locked(void *d_a, uint32_t log_n, const uint64_t omega[4],
             if (NTTW_WAVES == 4 && ps.nlines % tl == 0 && ps.log_len >= 3)   // (the tile copy loops walk 8 columns per lane: lines of 8 points and more)
                 ps.coop = (adjacent(ps.in_hi, ps.in_lo) ? 1u : 0u) | (adjacent(ps.out_hi, ps.out_lo) ? 2u : 0u);
 #define NTTW_LAUNCH(COOP)                                                                                                                                  \
-    LAUNCH_BARRIER((k_ntt_wave<Fr29, COOP>), std::min<uint32_t>(nbg, NTT_PERSISTENT_GRID * 3), 64 * NTTW_WAVES, NTTW_LDS_BYTES, g.stream, src, dst, ps,       \
-                   tab + t.off_tw[p], lo_ptr(tw), tw >= 0 ? tab + t.off_hi[tw] : cnull, tw >= 0 ? cnull : (const unsigned char *)scale_d)
+    LAUNCH_BARRIER((k_ntt_wave<Fr29, COOP>), std::min<uint32_t>(nbg, NTT_PERSISTENT_GRID * NTTW_OCC), 64 * NTTW_WAVES, NTTW_LDS_BYTES, g.stream, src, dst, ps,       \
+                   tab + t.off_tw[p], lo_ptr(tw), tw >= 0 ? tab + t.off_hi[tw] : cnull, tw >= 0 ? cnull : (const unsigned char *)scale_d,                 \
+                   reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(g.ntt_consts.p) + NTT_CTR_OFFSET + p * NTT_CTR_PASS_BYTES))
             switch (ps.coop) {
                 case 0: NTTW_LAUNCH(0); break;
                 case 1: NTTW_LAUNCH(1); break;
@@ -252,7 +258,7 @@ static int distribute_powers_locked(void *d_a, uint32_t log_n, bool into_coset) 
     memcpy(pw, into_coset ? z.l : zi.l, 32);
     memcpy(pw + 4, into_coset ? zi.l : z.l, 32);
     int rc;
-    if ((rc = g.ntt_consts.ensure(256))) return rc;
+    if ((rc = g.ntt_consts.ensure(NTT_CONSTS_BYTES))) return rc;
     unsigned char *d_pw = reinterpret_cast<unsigned char *>(g.ntt_consts.p) + 128;
     RT_CHECK(rt_h2d(d_pw, pw, 64, g.stream));
     const uint64_t n = (uint64_t)1 << log_n;
@@ -297,3 +303,16 @@ int ntt_get_omega_or_inv(uint32_t k, bool inverse, uint64_t out[4]) {
     memcpy(out, w.l, 32);
     return MIRA_OK;
 }
+
+#ifdef NTTW_PROBE_STAMPS
+// timing probe only (ntt_kernels.cuh: NTTW_STAMP): the stamp buffer of the LAST k_ntt_wave launches
+extern "C" int mira_debug_ntt_stamps(uint64_t *out, size_t n_words) {
+    const size_t total = (size_t)NTTW_STAMP_WGS * (NTTW_STAMP_ITERS * NTTW_STAMP_SLOTS + 1);
+    if (n_words > total) n_words = total;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nttw_stamps), n_words * 8, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+extern "C" int mira_debug_ntt_stamps_clear() {
+    static std::vector<uint64_t> z((size_t)NTTW_STAMP_WGS * (NTTW_STAMP_ITERS * NTTW_STAMP_SLOTS + 1), 0);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_nttw_stamps), z.data(), z.size() * 8, 0, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
+}
+#endif

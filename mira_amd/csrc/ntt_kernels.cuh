@@ -229,7 +229,27 @@ KERNEL void __launch_bounds__(1024) k_ntt_lines(const unsigned char *__restrict_
 static constexpr int NTTW_LOG = 8;                       // 256 points per wave
 static constexpr int NTTW_WAVES = 4;                     // waves per workgroup; three workgroups per CU (41 KiB of LDS each)
 static constexpr int NTTW_PLANE = 256;                   // dwords per limb plane
-static constexpr size_t NTTW_LDS_BYTES = (size_t)NTTW_WAVES * 9 * NTTW_PLANE * 4 + 128 * 9 * 4;   // exchange planes + N/2 twiddles
+// Waves per SIMD and exchange planes per wave.  The transpose between two rounds is independent per limb, so a wave
+// may send its nine limbs through fewer than nine planes, a group of planes at a time (the DS unit serves a wave's
+// instructions in order): with NTTW_XPLANES <= 8 the planes of the four waves fit inside the 32 KiB tile they alias,
+// a workgroup needs 36.5 KiB of LDS and FOUR of them fit a CU (NTTW_OCC = 4, 128 VGPRs).
+#ifndef NTTW_OCC
+#define NTTW_OCC 3
+#endif
+#ifndef NTTW_XPLANES
+#define NTTW_XPLANES 9
+#endif
+static constexpr int NTTW_XP = NTTW_XPLANES;
+// Work distribution: the block-groups of a pass are cut into NTTW_RANGES contiguous ranges, one per XCD (workgroups b and
+// b + 8 share an XCD and its L2: neighbouring strided lines meet there), each with a counter in global memory (a 128-byte
+// line of its own).  A workgroup takes the next block-group of its range when it has finished one, and walks on through
+// the other ranges when its own is empty.  (A static stride per workgroup was measured: the SIMD issues for the oldest
+// wave first, so of the workgroups of a CU the one in wave slot 0 ran three times as fast as the one in slot 2 and left it
+// to finish the pass alone.)
+static constexpr uint32_t NTTW_RANGES = 8, NTTW_CTR_STRIDE = 32, NTTW_DONE = 0xFFFFFFFFu;
+static constexpr size_t NTTW_TILE_BYTES = 32768;
+static constexpr size_t NTTW_X_BYTES = (size_t)NTTW_WAVES * NTTW_XP * NTTW_PLANE * 4 > NTTW_TILE_BYTES ? (size_t)NTTW_WAVES * NTTW_XP * NTTW_PLANE * 4 : NTTW_TILE_BYTES;
+static constexpr size_t NTTW_LDS_BYTES = NTTW_X_BYTES + 128 * 9 * 4 + 16;   // exchange planes (under the tile) + N/2 twiddles + the next block-group (two words)
 
 // Strided lines: element q of a line is in_elem_stride elements away from element q - 1, but the
 // same element of the NEXT line is adjacent.  A lone wave reading its own line therefore issues 64
@@ -297,15 +317,23 @@ template <class F> DEV void nttw_bfly_one2(Fe29<F> &u, Fe29<F> &v) {
 
 // the four points of a lane are four named values (never an indexed array: a dynamically indexed
 // register array would be demoted to scratch memory)
-template <class F> DEV void nttw_put(uint32_t *X, const Fe29<F> &v, uint32_t slot) {
+template <class F, int K0, int K1> DEV void nttw_put(uint32_t *X, const Fe29<F> &v, uint32_t slot) {
 #pragma unroll
-    for (int k = 0; k < 9; k++) X[k * NTTW_PLANE + slot] = v.l[k];
+    for (int k = K0; k < K1; k++) X[(k - K0) * NTTW_PLANE + slot] = v.l[k];
 }
-template <class F> DEV void nttw_get(const uint32_t *X, Fe29<F> &v, uint32_t slot, double bound) {
+template <class F, int K0, int K1> DEV void nttw_get(const uint32_t *X, Fe29<F> &v, uint32_t slot, double bound) {
 #pragma unroll
-    for (int k = 0; k < 9; k++) v.l[k] = X[k * NTTW_PLANE + slot];
+    for (int k = K0; k < K1; k++) v.l[k] = X[(k - K0) * NTTW_PLANE + slot];
     F29_SET(v, bound);
     (void)bound;
+}
+// limbs K0 .. K1 - 1 of the wave's 256 points change layout: slots sp* (this round's results) -> slots sg* (the next round's operands)
+template <class F, int K0, int K1>
+DEV void nttw_xchg(uint32_t *X, Fe29<F> &x0, Fe29<F> &x1, Fe29<F> &x2, Fe29<F> &x3, const uint32_t (&sp)[4], const uint32_t (&sg)[4], double bound) {
+    nttw_put<F, K0, K1>(X, x0, sp[0]); nttw_put<F, K0, K1>(X, x1, sp[1]); nttw_put<F, K0, K1>(X, x2, sp[2]); nttw_put<F, K0, K1>(X, x3, sp[3]);
+    WAVE_SYNC();
+    nttw_get<F, K0, K1>(X, x0, sg[0], bound); nttw_get<F, K0, K1>(X, x1, sg[1], bound); nttw_get<F, K0, K1>(X, x2, sg[2], bound); nttw_get<F, K0, K1>(X, x3, sg[3], bound);
+    WAVE_SYNC();
 }
 template <class F> struct NttwIo {
     const unsigned char *src;
@@ -327,6 +355,9 @@ template <class F> struct NttwIo {
     // residue < 2 P < 2^255 that the next pass unpacks like any other value -- or, in the last pass,
     // times the final scale and canonical
     DEV Fe<typename F::Sat> finish(uint32_t line, uint32_t k, const Fe29<F> &x) const {
+#if defined(NTTW_PROBE_NOMATH) || defined(NTTW_PROBE_NOFINISH)   // timing probes (tools/build_probe_variants.sh): results wrong on purpose
+        return f29_pack(f29_carry(x));
+#endif
         if (ps.tw_shift != 0xFFFFFFFFu) {
             const uint64_t e = ps.tw_single == 2 ? (((uint64_t)line << m) | k) : (uint64_t)(line >> ps.tw_line_shift) * k;
             const Fe29<F> tw = ps.tw_single ? tw_load<F>(t_lo + (size_t)e * TW_BYTES)
@@ -391,31 +422,83 @@ template <class F> struct NttwIo {
     }
 };
 
+// thread 0 of a workgroup: the next block-group, or NTTW_DONE.  r = how many ranges this workgroup has left behind.
+DEV uint32_t nttw_grab(uint32_t *ctr, uint32_t &r, uint32_t nbg) {
+    const uint32_t per = (nbg + NTTW_RANGES - 1) / NTTW_RANGES;
+    while (r < NTTW_RANGES) {
+        const uint32_t x = (blockIdx.x + r) % NTTW_RANGES, lo = x * per, hi = lo + per < nbg ? lo + per : nbg;
+        if (lo < hi) {
+            const uint32_t i = atomicAdd(&ctr[x * NTTW_CTR_STRIDE], 1u);
+            if (i < hi - lo) return lo + i;
+        }
+        r++;
+    }
+    return NTTW_DONE;
+}
+
+// PHASE SHIFT between the workgroups that share a CU.  A grid starts within a microsecond and every workgroup does the
+// same work, so without it the NTTW_OCC workgroups of a CU -- one wave each on every SIMD -- walk in lockstep: all of
+// them wait for their tiles while the multiplier idles, then all of them multiply while the memory system idles (measured:
+// a pass costs its memory-only time PLUS its arithmetic-only time).  The workgroup in wave slot s of its SIMDs starts
+// s * NTTW_STAGGER_TICKS * 10 ns late (s_memrealtime: 100 MHz), a third of an iteration apart, so that one workgroup's
+// fill and drain run under the butterflies of the other two.  Speed only.
+#ifndef NTTW_STAGGER_TICKS
+#define NTTW_STAGGER_TICKS 0
+#endif
+DEV void nttw_stagger(uint32_t *lds) {
+#if !defined(MIRA_CPU_EMU) && NTTW_STAGGER_TICKS > 0
+    if (threadIdx.x == 0) {
+        uint32_t hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        lds[0] = (hwid & 15u) % (uint32_t)NTTW_OCC;               // WAVE_ID: the slot of this wave on its SIMD
+    }
+    __syncthreads();
+    const uint32_t slot = lds[0];
+    __syncthreads();
+    const uint64_t until = __builtin_amdgcn_s_memrealtime() + (uint64_t)slot * NTTW_STAGGER_TICKS;
+    while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(32);
+#else
+    (void)lds;
+#endif
+}
+
+// Timing probe (tools/build_probe_variants.sh ... -DNTTW_PROBE_STAMPS; never in the product build): lane 0 of every workgroup
+// writes s_memrealtime (100 MHz) at the phase boundaries of its first NTTW_STAMP_ITERS iterations to a buffer of its own.
+#ifdef NTTW_PROBE_STAMPS
+static constexpr uint32_t NTTW_STAMP_ITERS = 48, NTTW_STAMP_SLOTS = 8, NTTW_STAMP_WGS = 1024;
+__device__ uint64_t g_nttw_stamps[NTTW_STAMP_WGS * (NTTW_STAMP_ITERS * NTTW_STAMP_SLOTS + 1)];
+#define NTTW_STAMP(it, k) do { if (threadIdx.x == 0 && (it) < NTTW_STAMP_ITERS && blockIdx.x < NTTW_STAMP_WGS) { \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        g_nttw_stamps[(size_t)blockIdx.x * (NTTW_STAMP_ITERS * NTTW_STAMP_SLOTS + 1) + 1 + (it) * NTTW_STAMP_SLOTS + (k)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define NTTW_STAMP(it, k) ((void)0)
+#endif
+
 // COOP: bit 0 / bit 1 = the input / output lines of a workgroup move as one tile (NttPass::coop);
 // a compile-time choice so that neither path's registers burden the other
 template <class F, int COOP>
-KERNEL void __launch_bounds__(64 * NTTW_WAVES) __attribute__((amdgpu_waves_per_eu(3, 3))) k_ntt_wave(const unsigned char *__restrict__ src, unsigned char *__restrict__ dst, NttPass ps,
+KERNEL void __launch_bounds__(64 * NTTW_WAVES) __attribute__((amdgpu_waves_per_eu(NTTW_OCC, NTTW_OCC))) k_ntt_wave(const unsigned char *__restrict__ src, unsigned char *__restrict__ dst, NttPass ps,
                         const unsigned char *__restrict__ line_tw,   // omega_N^j, j < N/2, TW_BYTES each
                         const unsigned char *__restrict__ t_lo, const unsigned char *__restrict__ t_hi,
-                        const unsigned char *__restrict__ scale) {   // multiplier-form scale, or one, for the last pass
+                        const unsigned char *__restrict__ scale,     // multiplier-form scale, or one, for the last pass
+                        uint32_t *__restrict__ ctr) {                // NTTW_RANGES work counters of this launch, zero
     DYN_SHARED(uint32_t, lds);
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    uint32_t *X = lds + (size_t)wv * 9 * NTTW_PLANE;              // this wave's exchange planes
-    uint32_t *TW = lds + (size_t)NTTW_WAVES * 9 * NTTW_PLANE;     // the line's twiddles, 9 dwords each, shared
+    uint32_t *X = lds + (size_t)wv * NTTW_XP * NTTW_PLANE;        // this wave's exchange planes
+    uint32_t *TW = lds + NTTW_X_BYTES / 4;                        // the line's twiddles, 9 dwords each, shared
+    uint32_t *NEXT = TW + 128 * 9;                                // the block-group of the next iteration, by parity
     const uint32_t m = ps.log_len, N = 1u << m;
     for (uint32_t i = threadIdx.x; i < (N / 2) * 9; i += blockDim.x)
         TW[i] = reinterpret_cast<const uint32_t *>(line_tw + (size_t)(i / 9) * TW_BYTES)[i % 9];
     __syncthreads();
+    nttw_stagger(lds);
     const NttwIo<F> io{src, dst, t_lo, t_hi, scale, ps, ps.tw_shift == 0xFFFFFFFFu ? 0 : ((1u << ps.tw_shift) - 1u), (1u << ps.split) - 1u, m, N};
     const uint32_t log_lpw = NTTW_LOG - m, lpw = 1u << log_lpw;    // lines per wave
     const uint32_t rounds = (m + 1) / 2;
     // block-groups of NTTW_WAVES consecutive wave-groups (4 * lpw consecutive lines: their strided
     // elements share 128-byte lines); XCD-aware order as in k_ntt_lines
     const uint32_t ngroups = (ps.nlines + lpw - 1) >> log_lpw, nbg = (ngroups + NTTW_WAVES - 1) / NTTW_WAVES;
-    auto first_line = [&](uint32_t idx) {
-        const uint32_t bg = ((nbg & 7u) == 0) ? (idx & 7u) * (nbg >> 3) + (idx >> 3) : idx;
-        return (bg * NTTW_WAVES + wv) << log_lpw;                   // first line of this wave
-    };
+    auto first_line = [&](uint32_t bg) { return (bg * NTTW_WAVES + wv) << log_lpw; };   // first line of this wave
     // (a register prefetch of the next group's elements was measured: no gain -- the other waves of
     // the SIMD already cover the strided loads; nor did a fourth wave per SIMD, eight-wave workgroups at 128 VGPRs)
     // ALIASING INVARIANT: `tile` (32 KiB) lies over the exchange planes X of all four waves.  Every transition
@@ -423,28 +506,56 @@ KERNEL void __launch_bounds__(64 * NTTW_WAVES) __attribute__((amdgpu_waves_per_e
     // separated by a workgroup barrier, including the one from the last round of group g to the fill of group g + 1.
     U4 *tile = reinterpret_cast<U4 *>(lds);
     const uint32_t row0 = wv << log_lpw;                           // this wave's first row of the tile
-    for (uint32_t idx = blockIdx.x; idx < nbg; idx += gridDim.x) {
+#ifdef NTTW_PROBE_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < NTTW_STAMP_WGS) {
+        uint32_t hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_nttw_stamps[(size_t)blockIdx.x * (NTTW_STAMP_ITERS * NTTW_STAMP_SLOTS + 1)] = ((uint64_t)xcc << 32) | hwid;
+    }
+    uint32_t it_no = 0;
+#endif
+    uint32_t ranges_left = 0, par = 0;                             // (thread 0) ranges emptied; parity of the iteration
+    if (threadIdx.x == 0) NEXT[0] = nttw_grab(ctr, ranges_left, nbg);
+    __syncthreads();
+    uint32_t idx = NEXT[0];
+    while (idx != NTTW_DONE) {
         const uint32_t line0 = first_line(idx), line_blk0 = line0 - row0;
         Fe29<F> x0, x1, x2, x3;
+        NTTW_STAMP(it_no, 0);
+#ifndef NTTW_PROBE_NOMEM                                           // timing probe: no tile loads, no tile stores (results wrong on purpose)
+        if (COOP & 1) io.tile_fill(tile, line_blk0);
+#endif
+        // the next block-group: its counter answers behind this iteration's tile loads.  NEXT[par ^ 1] was last read
+        // before the barrier below of the iteration before, which every wave has passed
+        if (threadIdx.x == 0) NEXT[par ^ 1u] = nttw_grab(ctr, ranges_left, nbg);
+        __syncthreads();
+        const uint32_t idx_next = NEXT[par ^ 1u];
         if (COOP & 1) {
-            io.tile_fill(tile, line_blk0);
-            __syncthreads();
+            NTTW_STAMP(it_no, 1);
             const uint32_t tb = io.take_base(wv, lane);
             x0 = io.tile_take(tile, tb, 0); x1 = io.tile_take(tile, tb, 1); x2 = io.tile_take(tile, tb, 2); x3 = io.tile_take(tile, tb, 3);
             __syncthreads();                                       // the exchange planes overwrite the tile
+            NTTW_STAMP(it_no, 2);
         } else {
             x0 = ntt_unpack<F>(io.fetch(line0, nttw_pos(lane, 0, 0))); x1 = ntt_unpack<F>(io.fetch(line0, nttw_pos(lane, 1, 0)));
             x2 = ntt_unpack<F>(io.fetch(line0, nttw_pos(lane, 2, 0))); x3 = ntt_unpack<F>(io.fetch(line0, nttw_pos(lane, 3, 0)));
         }
+#ifdef NTTW_PROBE_NOMATH
+        for (uint32_t t = 0; t < 0; t++) {
+#else
         for (uint32_t t = 0; t < rounds; t++) {
+#endif
             if (t) {                                               // transpose: layout t-1 -> layout t (carried: see nttw_bfly)
-                nttw_put(X, f29_carry(x0), nttw_slot(nttw_pos(lane, 0, t - 1))); nttw_put(X, f29_carry(x1), nttw_slot(nttw_pos(lane, 1, t - 1)));
-                nttw_put(X, f29_carry(x2), nttw_slot(nttw_pos(lane, 2, t - 1))); nttw_put(X, f29_carry(x3), nttw_slot(nttw_pos(lane, 3, t - 1)));
-                WAVE_SYNC();
+                const uint32_t sp[4] = {nttw_slot(nttw_pos(lane, 0, t - 1)), nttw_slot(nttw_pos(lane, 1, t - 1)), nttw_slot(nttw_pos(lane, 2, t - 1)), nttw_slot(nttw_pos(lane, 3, t - 1))};
+                const uint32_t sg[4] = {nttw_slot(nttw_pos(lane, 0, t)), nttw_slot(nttw_pos(lane, 1, t)), nttw_slot(nttw_pos(lane, 2, t)), nttw_slot(nttw_pos(lane, 3, t))};
                 const double bound = 3.0 + 6.0 * t;                // + 3 per layer, + 1 for the product-free butterfly of layer 1
-                nttw_get(X, x0, nttw_slot(nttw_pos(lane, 0, t)), bound); nttw_get(X, x1, nttw_slot(nttw_pos(lane, 1, t)), bound);
-                nttw_get(X, x2, nttw_slot(nttw_pos(lane, 2, t)), bound); nttw_get(X, x3, nttw_slot(nttw_pos(lane, 3, t)), bound);
-                WAVE_SYNC();
+                x0 = f29_carry(x0); x1 = f29_carry(x1); x2 = f29_carry(x2); x3 = f29_carry(x3);
+                constexpr int KS = NTTW_XP < 9 ? NTTW_XP : 9;      // the limbs go through the planes in groups of KS
+                nttw_xchg<F, 0, KS>(X, x0, x1, x2, x3, sp, sg, bound);
+                if constexpr (KS < 9) nttw_xchg<F, KS, (2 * KS < 9 ? 2 * KS : 9)>(X, x0, x1, x2, x3, sp, sg, bound);
+                if constexpr (2 * KS < 9) nttw_xchg<F, 2 * KS, (3 * KS < 9 ? 3 * KS : 9)>(X, x0, x1, x2, x3, sp, sg, bound);
+                static_assert(3 * KS >= 9, "at most three groups of exchange planes");
             }
             const uint32_t s = 2 * t, j = lane & ((1u << s) - 1u);  // j = p mod 2^s
             if (s == 0) {
@@ -462,21 +573,34 @@ KERNEL void __launch_bounds__(64 * NTTW_WAVES) __attribute__((amdgpu_waves_per_e
             }
         }
         const uint32_t tl = rounds ? rounds - 1 : 0;
+        NTTW_STAMP(it_no, 3);
         if (COOP & 2) {
             __syncthreads();                                       // every wave is done with its exchange planes
+            NTTW_STAMP(it_no, 4);
             const uint32_t gb = io.give_base(wv, lane, tl);
             io.tile_give(tile, gb, line0, nttw_pos(lane, 0, tl), 0, tl, x0); io.tile_give(tile, gb, line0, nttw_pos(lane, 1, tl), 1, tl, x1);
             io.tile_give(tile, gb, line0, nttw_pos(lane, 2, tl), 2, tl, x2); io.tile_give(tile, gb, line0, nttw_pos(lane, 3, tl), 3, tl, x3);
+            NTTW_STAMP(it_no, 5);
             __syncthreads();
+            NTTW_STAMP(it_no, 6);
+#ifndef NTTW_PROBE_NOMEM
             io.tile_drain(tile, line_blk0);
+#endif
             __syncthreads();                                       // the next group's tile or exchange planes reuse the space
+            NTTW_STAMP(it_no, 7);
         } else {
             io.store(line0, nttw_pos(lane, 0, tl), x0); io.store(line0, nttw_pos(lane, 1, tl), x1);
             io.store(line0, nttw_pos(lane, 2, tl), x2); io.store(line0, nttw_pos(lane, 3, tl), x3);
             // `tile` aliases the exchange planes of ALL four waves: the next group's tile_fill must not start
             // while a slower wave is still between nttw_put and nttw_get (control flow is block-uniform)
             if (COOP & 1) __syncthreads();
+            NTTW_STAMP(it_no, 7);
         }
+#ifdef NTTW_PROBE_STAMPS
+        it_no++;
+#endif
+        idx = idx_next;
+        par ^= 1u;
     }
 }
 

@@ -395,19 +395,32 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
         from mira_amd import fft as F
         F.fft_device(d, k)                       # warm-up: builds the twiddle tables
         lib.check(lib.c.mira_set_timing(1))
-        reps, walls, acc = 7, [], {}
-        for _ in range(reps):                    # the GPU may still be ramping its clocks after a CPU-only leg: median, not mean
-            t0 = time.perf_counter()
+
+        def timed(reps):
+            walls, acc = [], {}
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                F.fft_device(d, k)
+                walls.append(time.perf_counter() - t0)
+                for name, ms in lib.timings():
+                    acc.setdefault(name, []).append(ms)
+            return sorted(walls)[reps // 2], {a: sorted(b)[len(b) // 2] for a, b in acc.items()}
+
+        # Two figures, because the chip's clock decides a VALU-bound 2 ms kernel: `first_transforms` = the median of the first
+        # seven transforms after this process has kept the GPU idle (what rounds 1-3 reported as "ms": the clock is still
+        # ramping); "ms" = the median of 40 transforms behind 20 untimed ones, i.e. under a sustained load, which is how a
+        # prover that keeps the GPU busy meets the transform (measured round 4: the same kernel reads 2.33 and 2.06 ms)
+        dt_first, acc_first = timed(7)
+        for _ in range(20):
             F.fft_device(d, k)
-            walls.append(time.perf_counter() - t0)
-            for name, ms in lib.timings():
-                acc.setdefault(name, []).append(ms)
-        dt = sorted(walls)[reps // 2]
-        acc = {a: sorted(b)[len(b) // 2] for a, b in acc.items()}
+        dt, acc = timed(40)
         lib.check(lib.c.mira_set_timing(0))
         passes = sorted(a for a in acc if a.startswith("ntt_pass") or a == "ntt_single")
         kern = sum(acc[a] for a in passes)                         # EVERY butterfly pass of the transform (2^24: three)
         ex["ntt_2p24"] = {"ms": round(dt * 1e3, 3), "M_elements_per_s": round(n / dt / 1e6, 2), "stages_ms": {a: round(b, 4) for a, b in acc.items()},
+                          "timing": "median of 40 transforms behind 20 untimed ones (sustained clock)",
+                          "first_transforms": {"ms": round(dt_first * 1e3, 3), "stages_ms": {a: round(b, 4) for a, b in acc_first.items()},
+                                               "timing": "median of the first 7 transforms after an idle GPU (the figure of rounds 1-3)"},
                           "roofline": {"bound": "hbm", "kernel": "k_ntt_wave", "passes": len(passes), "kernel_ms_all_passes": round(kern, 4),
                                        "achieved": round(NTT_BYTES_PER_ELEM * n / (kern * 1e-3) / 1e9, 2) if kern else None,
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -311,6 +311,7 @@ extern "C" int mira_debug_ntt_stamps(uint64_t *out, size_t n_words) {
     if (n_words > total) n_words = total;
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nttw_stamps), n_words * 8, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
+extern "C" int mira_debug_ntt_clk(uint64_t *out4) { return hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_nttw_clk), 32, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
 extern "C" int mira_debug_ntt_stamps_clear() {
     static std::vector<uint64_t> z((size_t)NTTW_STAMP_WGS * (NTTW_STAMP_ITERS * NTTW_STAMP_SLOTS + 1), 0);
     return hipMemcpyToSymbol(HIP_SYMBOL(g_nttw_stamps), z.data(), z.size() * 8, 0, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;

@@ -423,13 +423,30 @@ template <class F> struct NttwIo {
 };
 
 // thread 0 of a workgroup: the next block-group, or NTTW_DONE.  r = how many ranges this workgroup has left behind.
-DEV uint32_t nttw_grab(uint32_t *ctr, uint32_t &r, uint32_t nbg) {
+// The FIRST block-group of a workgroup costs no counter: workgroup b is at home in range b mod 8 and takes that range's
+// block-group number b / 8; the counter of a range hands out what lies behind the first ones of its home workgroups (a
+// transform of 2^20 points has hardly more block-groups than the grid has workgroups: with every first block-group
+// drawn from a counter, 96 workgroups queued on one address before anything started, 0.14 -> 0.20 ms).
+// Passes with fewer than NTTW_DYNAMIC_MIN block-groups per workgroup keep the static stride (block-groups b, b + grid, ...
+// in the XCD-aware order): nothing to balance, and the counters only cost (2^21 points: 0.26 -> 0.28 ms with them).
+static constexpr uint32_t NTTW_DYNAMIC_MIN = 4;
+DEV uint32_t nttw_grab(uint32_t *ctr, uint32_t &r, uint32_t nbg, bool first) {
+    if (nbg < NTTW_DYNAMIC_MIN * gridDim.x) {                      // r = the rounds of the stride behind this workgroup
+        const uint32_t i = blockIdx.x + (first ? 0u : ++r) * gridDim.x;
+        if (i >= nbg) return NTTW_DONE;
+        return (nbg & 7u) == 0 ? (i & 7u) * (nbg >> 3) + (i >> 3) : i;
+    }
     const uint32_t per = (nbg + NTTW_RANGES - 1) / NTTW_RANGES;
+    if (first) {
+        const uint32_t x = blockIdx.x % NTTW_RANGES, w = blockIdx.x / NTTW_RANGES, lo = x * per, hi = lo + per < nbg ? lo + per : nbg;
+        if (lo + w < hi) return lo + w;
+    }
     while (r < NTTW_RANGES) {
         const uint32_t x = (blockIdx.x + r) % NTTW_RANGES, lo = x * per, hi = lo + per < nbg ? lo + per : nbg;
-        if (lo < hi) {
+        const uint32_t at_home = gridDim.x > x ? (gridDim.x - x + NTTW_RANGES - 1) / NTTW_RANGES : 0u;   // each took lo + its number
+        if (lo + at_home < hi) {
             const uint32_t i = atomicAdd(&ctr[x * NTTW_CTR_STRIDE], 1u);
-            if (i < hi - lo) return lo + i;
+            if (lo + at_home + i < hi) return lo + at_home + i;
         }
         r++;
     }
@@ -467,6 +484,7 @@ DEV void nttw_stagger(uint32_t *lds) {
 #ifdef NTTW_PROBE_STAMPS
 static constexpr uint32_t NTTW_STAMP_ITERS = 48, NTTW_STAMP_SLOTS = 8, NTTW_STAMP_WGS = 1024;
 __device__ uint64_t g_nttw_stamps[NTTW_STAMP_WGS * (NTTW_STAMP_ITERS * NTTW_STAMP_SLOTS + 1)];
+__device__ uint64_t g_nttw_clk[4];      // workgroup 0: (s_memtime, s_memrealtime) at its start and at its end: the shader clock of the launch
 #define NTTW_STAMP(it, k) do { if (threadIdx.x == 0 && (it) < NTTW_STAMP_ITERS && blockIdx.x < NTTW_STAMP_WGS) { \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
         g_nttw_stamps[(size_t)blockIdx.x * (NTTW_STAMP_ITERS * NTTW_STAMP_SLOTS + 1) + 1 + (it) * NTTW_STAMP_SLOTS + (k)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
@@ -514,9 +532,10 @@ KERNEL void __launch_bounds__(64 * NTTW_WAVES) __attribute__((amdgpu_waves_per_e
         g_nttw_stamps[(size_t)blockIdx.x * (NTTW_STAMP_ITERS * NTTW_STAMP_SLOTS + 1)] = ((uint64_t)xcc << 32) | hwid;
     }
     uint32_t it_no = 0;
+    if (threadIdx.x == 0 && blockIdx.x == 0) { g_nttw_clk[0] = __builtin_amdgcn_s_memtime(); g_nttw_clk[1] = __builtin_amdgcn_s_memrealtime(); }
 #endif
     uint32_t ranges_left = 0, par = 0;                             // (thread 0) ranges emptied; parity of the iteration
-    if (threadIdx.x == 0) NEXT[0] = nttw_grab(ctr, ranges_left, nbg);
+    if (threadIdx.x == 0) NEXT[0] = nttw_grab(ctr, ranges_left, nbg, true);
     __syncthreads();
     uint32_t idx = NEXT[0];
     while (idx != NTTW_DONE) {
@@ -528,7 +547,7 @@ KERNEL void __launch_bounds__(64 * NTTW_WAVES) __attribute__((amdgpu_waves_per_e
 #endif
         // the next block-group: its counter answers behind this iteration's tile loads.  NEXT[par ^ 1] was last read
         // before the barrier below of the iteration before, which every wave has passed
-        if (threadIdx.x == 0) NEXT[par ^ 1u] = nttw_grab(ctr, ranges_left, nbg);
+        if (threadIdx.x == 0) NEXT[par ^ 1u] = nttw_grab(ctr, ranges_left, nbg, false);
         __syncthreads();
         const uint32_t idx_next = NEXT[par ^ 1u];
         if (COOP & 1) {
@@ -544,7 +563,7 @@ KERNEL void __launch_bounds__(64 * NTTW_WAVES) __attribute__((amdgpu_waves_per_e
 #ifdef NTTW_PROBE_NOMATH
         for (uint32_t t = 0; t < 0; t++) {
 #else
-        for (uint32_t t = 0; t < rounds; t++) {
+        for (uint32_t t = 0; t < rounds; t++) {                    // (the line length as a template parameter, with and without the rounds unrolled: +- 1 %, not kept)
 #endif
             if (t) {                                               // transpose: layout t-1 -> layout t (carried: see nttw_bfly)
                 const uint32_t sp[4] = {nttw_slot(nttw_pos(lane, 0, t - 1)), nttw_slot(nttw_pos(lane, 1, t - 1)), nttw_slot(nttw_pos(lane, 2, t - 1)), nttw_slot(nttw_pos(lane, 3, t - 1))};
@@ -602,6 +621,9 @@ KERNEL void __launch_bounds__(64 * NTTW_WAVES) __attribute__((amdgpu_waves_per_e
         idx = idx_next;
         par ^= 1u;
     }
+#ifdef NTTW_PROBE_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x == 0) { g_nttw_clk[2] = __builtin_amdgcn_s_memtime(); g_nttw_clk[3] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 }
 
 // a[i] *= powers[i % 3 - 1] for i % 3 != 0   (distribute_powers_zeta, reference src/fft.rs:205-226)

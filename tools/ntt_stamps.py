@@ -13,13 +13,17 @@ from mira_amd import commitment as cm, fft as F
 lib = _lib.load()
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 d = cm.synth_scalars_device(0, 1 << k, seed=5)
-for _ in range(3):
+for _ in range(int(os.environ.get("MIRA_PROBE_WARM", "30"))):
     F.fft_device(d, k)
 ITERS, SLOTS, WGS = 48, 8, 1024
 lib.c.mira_debug_ntt_stamps_clear()
 F.fft_device(d, k)
 buf = np.zeros(WGS * (ITERS * SLOTS + 1), dtype=np.uint64)
 assert lib.c.mira_debug_ntt_stamps(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(buf.size)) == 0
+clk = np.zeros(4, dtype=np.uint64)
+if hasattr(lib.c, "mira_debug_ntt_clk") and lib.c.mira_debug_ntt_clk(clk.ctypes.data_as(ctypes.c_void_p)) == 0:
+    dc, dt = int(clk[2]) - int(clk[0]), (int(clk[3]) - int(clk[1])) / 100.0
+    print("workgroup 0 of the last launch: %d s_memtime ticks in %.1f us = %.1f MHz" % (dc, dt, dc / dt if dt else 0))
 buf = buf.reshape(WGS, ITERS * SLOTS + 1)
 hw = buf[:, 0]
 st = buf[:, 1:].reshape(WGS, ITERS, SLOTS).astype(np.int64)

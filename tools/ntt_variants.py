@@ -21,7 +21,9 @@ def child(k):
     out = lib.download(d, (n, 4))
     digest = hashlib.sha256(out.tobytes()).hexdigest()[:16]
     lib.check(lib.c.mira_set_timing(1))
-    reps = int(os.environ.get("MIRA_PROBE_REPS", "8"))
+    reps = int(os.environ.get("MIRA_PROBE_REPS", "40"))
+    for _ in range(10):                                  # let the clock settle under the load before anything is counted
+        F.fft_device(d, k)
     tot = []
     acc = {}
     for _ in range(reps):

@@ -425,6 +425,22 @@ template <class F> HD Fe<typename F::Sat> f29_pack(const Fe29<F> &a) {
     s.l[7] = (n[7] >> 21) | (n[8] << 8);
     return s;
 }
+// the same for a value straight out of f29_mul / f29_mul2_add / f29_redc / f29_sqr: their limbs 0 .. 7 are masked to 29 bits, so
+// there is nothing to carry (24 instructions less per element)
+template <class F> HD Fe<typename F::Sat> f29_pack_product(const Fe29<F> &a) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) F29_ASSERT(a.l[i] <= M29);
+    Fe<typename F::Sat> s;
+    s.l[0] = a.l[0] | (a.l[1] << 29);
+    s.l[1] = (a.l[1] >> 3) | (a.l[2] << 26);
+    s.l[2] = (a.l[2] >> 6) | (a.l[3] << 23);
+    s.l[3] = (a.l[3] >> 9) | (a.l[4] << 20);
+    s.l[4] = (a.l[4] >> 12) | (a.l[5] << 17);
+    s.l[5] = (a.l[5] >> 15) | (a.l[6] << 14);
+    s.l[6] = (a.l[6] >> 18) | (a.l[7] << 11);
+    s.l[7] = (a.l[7] >> 21) | (a.l[8] << 8);
+    return s;
+}
 // reference layout (x * 2^256, canonical, saturated) -> loose x * 2^261
 template <class F> HD Fe29<F> f29_from_r256(const Fe<typename F::Sat> &s) {
     Fe29<F> k;

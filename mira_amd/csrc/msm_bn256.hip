@@ -23,3 +23,11 @@ int load_bases_file_bn256(Bases &b, int fd, bool validate, uint32_t *d_bad) {
     return load_bases_file<Fq29>(b, fd, validate, reinterpret_cast<const unsigned char *>(g.consts.p) + 128, d_bad);
 }
 int save_bases_file_bn256(const Bases &b, int fd) { return save_bases_file<Fq29>(b, fd); }
+
+#ifdef MSM_PROBE_STAMPS
+// timing probe only (msm_kernels.cuh): the stamps of the LAST bn256 k_accumulate launch
+extern "C" int mira_debug_acc_stamps(uint64_t *out, size_t n_words) {
+    if (n_words > 4096 * 3) n_words = 4096 * 3;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_acc_stamps), n_words * 8, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif

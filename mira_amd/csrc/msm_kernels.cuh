@@ -384,6 +384,11 @@ template <bool ADD, class F> DEV Xyzz29<F> run_start(const unsigned char *bucket
     if constexpr (ADD) return xyzz29_load<F>(bucket_sums + (size_t)bucket * XYZZ29_BYTES);
     else return xyzz29_identity<F>();
 }
+// Timing probe (tools/build_probe_variants.sh ... -DMSM_PROBE_STAMPS; never in the product build): lane 0 of every wave of
+// k_accumulate writes its hardware id and s_memrealtime (100 MHz) at its start and at its end.
+#ifdef MSM_PROBE_STAMPS
+static __device__ uint64_t g_acc_stamps[4096 * 3];
+#endif
 template <class F, bool ADD>
 KERNEL void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) k_accumulate(const uint32_t *__restrict__ sorted, const uint32_t *__restrict__ offsets, uint32_t NB,
                          const unsigned char *__restrict__ bases,
@@ -391,6 +396,9 @@ KERNEL void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) k_
                          unsigned char *__restrict__ head_part, unsigned char *__restrict__ tail_part, uint32_t *__restrict__ tail_key,
                          uint32_t *__restrict__ heavy_ctr, U4 *__restrict__ runs, U4 *__restrict__ subs, U4 *__restrict__ meds) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+#ifdef MSM_PROBE_STAMPS
+    const uint64_t probe_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const uint32_t total = offsets[NB];
     const uint32_t L = plan[0];
     const uint64_t start64 = (uint64_t)t * L;
@@ -452,6 +460,13 @@ KERNEL void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) k_
     // its tail partial: the list is complete when this kernel ends, so the sub-jobs of the heavy runs and the short chains of all
     // the others are summed side by side in ONE launch (k_fixup_all) instead of one after the other (round 3: k_fixup wrote the
     // list, k_fixup_heavy_a followed -- 49 + 42 us of a 0.54 ms commit of 2^17 pairs, both latency-bound on mostly idle SIMDs).
+#ifdef MSM_PROBE_STAMPS
+    if ((threadIdx.x & 63u) == 0 && (t >> 6) < 4096u) {
+        uint32_t hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        g_acc_stamps[(t >> 6) * 3] = hwid; g_acc_stamps[(t >> 6) * 3 + 1] = probe_t0; g_acc_stamps[(t >> 6) * 3 + 2] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     if (holds_tail) {
         const uint32_t span = (run_end - 1) / L - t;          // lanes t + 1 .. t + span hold head partials of this run
         if (span > (uint32_t)HEAVY_SPAN && span <= (uint32_t)MEDIUM_SPAN) {

@@ -36,6 +36,11 @@ template <class F> HD Fe<typename F::Sat> f29_canonical(const Fe29<F> &v) {
     F29_ASSERT(F29_GET(v) <= 2.0);
     return reduce_once(f29_pack(v));
 }
+// the same for a value straight out of the multiplier (limbs masked: f29_pack_product)
+template <class F> HD Fe<typename F::Sat> ntt_canonical_product(const Fe29<F> &v) {
+    F29_ASSERT(F29_GET(v) <= 2.0);
+    return reduce_once(f29_pack_product(v));
+}
 // an element as a pass reads it: canonical from the caller, or what the previous pass left (< 2 P, see NttwIo::finish)
 template <class F> HD Fe29<F> ntt_unpack(const Fe<typename F::Sat> &s) {
     Fe29<F> r = f29_unpack<F>(s);
@@ -202,7 +207,7 @@ KERNEL void __launch_bounds__(1024) k_ntt_lines(const unsigned char *__restrict_
             } else {
                 v = f29_mul(v, tw_load<F>(scale));
             }
-            fe_store(out + (size_t)k * ps.out_elem_stride * 32, f29_canonical(v));
+            fe_store(out + (size_t)k * ps.out_elem_stride * 32, ntt_canonical_product(v));   // v: a product or a reduction in every branch
         }
         __syncthreads();                                 // LDS is rewritten by the next line
     }
@@ -362,10 +367,10 @@ template <class F> struct NttwIo {
             const uint64_t e = ps.tw_single == 2 ? (((uint64_t)line << m) | k) : (uint64_t)(line >> ps.tw_line_shift) * k;
             const Fe29<F> tw = ps.tw_single ? tw_load<F>(t_lo + (size_t)e * TW_BYTES)
                                             : f29_mul(tw_load<F>(t_hi + (size_t)(e >> ps.tw_shift) * TW_BYTES), tw_load<F>(t_lo + (size_t)(e & lo_mask) * TW_BYTES));
-            return f29_pack(f29_mul(x, tw));
+            return f29_pack_product(f29_mul(x, tw));
         }
-        if (ps.prescaled) return f29_canonical(f29_redc(x));
-        return f29_canonical(f29_mul(x, tw_load<F>(scale)));
+        if (ps.prescaled) return ntt_canonical_product(f29_redc(x));
+        return ntt_canonical_product(f29_mul(x, tw_load<F>(scale)));
     }
     DEV void store(uint32_t line0, uint32_t p, const Fe29<F> &x) const {
         const uint32_t k = p & (N - 1), line = line0 + (p >> m);
@@ -566,8 +571,11 @@ KERNEL void __launch_bounds__(64 * NTTW_WAVES) __attribute__((amdgpu_waves_per_e
         for (uint32_t t = 0; t < rounds; t++) {                    // (the line length as a template parameter, with and without the rounds unrolled: +- 1 %, not kept)
 #endif
             if (t) {                                               // transpose: layout t-1 -> layout t (carried: see nttw_bfly)
-                const uint32_t sp[4] = {nttw_slot(nttw_pos(lane, 0, t - 1)), nttw_slot(nttw_pos(lane, 1, t - 1)), nttw_slot(nttw_pos(lane, 2, t - 1)), nttw_slot(nttw_pos(lane, 3, t - 1))};
-                const uint32_t sg[4] = {nttw_slot(nttw_pos(lane, 0, t)), nttw_slot(nttw_pos(lane, 1, t)), nttw_slot(nttw_pos(lane, 2, t)), nttw_slot(nttw_pos(lane, 3, t))};
+                // nttw_slot is GF(2)-linear and nttw_pos(lane, r, t) = nttw_pos(lane, 0, t) ^ r << 2 t: one slot per lane and layout
+                // with vector instructions, the other three by an XOR with a wave-uniform constant
+                const uint32_t sp0 = nttw_slot(nttw_pos(lane, 0, t - 1)), sg0 = nttw_slot(nttw_pos(lane, 0, t));
+                const uint32_t sp[4] = {sp0, sp0 ^ nttw_slot(1u << (2 * t - 2)), sp0 ^ nttw_slot(2u << (2 * t - 2)), sp0 ^ nttw_slot(3u << (2 * t - 2))};
+                const uint32_t sg[4] = {sg0, sg0 ^ nttw_slot(1u << (2 * t)), sg0 ^ nttw_slot(2u << (2 * t)), sg0 ^ nttw_slot(3u << (2 * t))};
                 const double bound = 3.0 + 6.0 * t;                // + 3 per layer, + 1 for the product-free butterfly of layer 1
                 x0 = f29_carry(x0); x1 = f29_carry(x1); x2 = f29_carry(x2); x3 = f29_carry(x3);
                 constexpr int KS = NTTW_XP < 9 ? NTTW_XP : 9;      // the limbs go through the planes in groups of KS

@@ -34,6 +34,7 @@ SYMBOLS = [
 ]
 TUNE_STAGED_MIN_N, TUNE_TABLE_MIN_N, TUNE_PLAN_HIST_MIN_N, TUNE_NTT_MAX_LOG_LINE, TUNE_NTT_WAVE, TUNE_HOST_CHUNK_MIN_N, TUNE_NTT_SINGLE_TW_LOG, TUNE_NTT_FULL_TW_MAX_LOG, TUNE_TABLE_WIDTH, TUNE_JIT_LOADS_AHEAD, TUNE_MIN_SEGMENT, TUNE_GLV = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 TUNE_REDUCE_PIECES, TUNE_REDUCE_LAMBDA, TUNE_REDUCE_QUAD, TUNE_SHARED_MIN_N, TUNE_PASS_ENTRIES_LOG, TUNE_GLV_AUTO_MAX_LOG, TUNE_WIDTH_TRIALS = 12, 13, 14, 15, 16, 17, 18
+TUNE_NTT_GRID = 19
 TABLE_GLV = 2   # mira_msm_precompute_ex(handle, MIRA_TABLE_GLV): the endomorphism copy of a key
 
 

@@ -1090,7 +1090,7 @@ int mira_msm_combine(int curve, const uint64_t *partials, size_t nparts, int32_t
 }
 int mira_set_tuning(int knob, int64_t value) {
     std::lock_guard<std::mutex> lk(g_lock);
-    if (knob < 0 || knob > MIRA_TUNE_WIDTH_TRIALS || (knob == MIRA_TUNE_PASS_ENTRIES_LOG && value > 32)) { set_error("unknown tuning knob"); return MIRA_E_BAD_ARG; }
+    if (knob < 0 || knob > MIRA_TUNE_NTT_GRID || (knob == MIRA_TUNE_PASS_ENTRIES_LOG && value > 32)) { set_error("unknown tuning knob"); return MIRA_E_BAD_ARG; }
     g.tune[knob] = value;
     return MIRA_OK;
 }

@@ -208,7 +208,7 @@ static int ntt_device_locked(void *d_a, uint32_t log_n, const uint64_t omega[4],
             if (NTTW_WAVES == 4 && ps.nlines % tl == 0 && ps.log_len >= 3)   // (the tile copy loops walk 8 columns per lane: lines of 8 points and more)
                 ps.coop = (adjacent(ps.in_hi, ps.in_lo) ? 1u : 0u) | (adjacent(ps.out_hi, ps.out_lo) ? 2u : 0u);
 #define NTTW_LAUNCH(COOP)                                                                                                                                  \
-    LAUNCH_BARRIER((k_ntt_wave<Fr29, COOP>), std::min<uint32_t>(nbg, NTT_PERSISTENT_GRID * NTTW_OCC), 64 * NTTW_WAVES, NTTW_LDS_BYTES, g.stream, src, dst, ps,       \
+    LAUNCH_BARRIER((k_ntt_wave<Fr29, COOP>), std::min<uint32_t>(nbg, (uint32_t)std::max<size_t>(1, tuned(MIRA_TUNE_NTT_GRID, NTT_PERSISTENT_GRID * NTTW_OCC))), 64 * NTTW_WAVES, NTTW_LDS_BYTES, g.stream, src, dst, ps,       \
                    tab + t.off_tw[p], lo_ptr(tw), tw >= 0 ? tab + t.off_hi[tw] : cnull, tw >= 0 ? cnull : (const unsigned char *)scale_d,                 \
                    reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(g.ntt_consts.p) + NTT_CTR_OFFSET + p * NTT_CTR_PASS_BYTES))
             switch (ps.coop) {

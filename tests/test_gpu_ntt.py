@@ -66,6 +66,22 @@ def test_full_size_2p24_properties(gpu_lib):
     assert (fe[2] == C.f_mul(C.FIELD_FR, w, w)).all()
 
 
+@pytest.mark.parametrize("k,grid", [(23, -1), (20, 100), (20, 5), (22, 37)])
+def test_block_groups_from_counters(gpu_lib, k, grid):
+    """The work distribution of k_ntt_wave (ntt_kernels.cuh: nttw_grab) under real concurrency: 2^23 on the default grid
+    (8 192 block-groups of 256- and 128-point lines for 768 workgroups), and grids that are no multiple of the eight ranges --
+    100 and 37 workgroups (uneven homes), 5 (three ranges nobody is at home in) -- bit-exact against the oracle."""
+    from mira_amd import _lib
+    a = C.synth_scalars(0, 1 << k, seed=900 + k)
+    want = C.fft(a, k)
+    gpu_lib.tune(_lib.TUNE_NTT_GRID, grid)
+    try:
+        assert (F.fft(a, k) == want).all()
+        assert (F.ifft(want, k) == a).all()
+    finally:
+        gpu_lib.tune(_lib.TUNE_NTT_GRID, -1)
+
+
 def test_three_pass_2p25_vs_oracle(gpu_lib):
     """log_n 25..28 take three passes of lines (n = n1 n2 n3): 2^25 bit-exact against the oracle,
     forward and inverse."""

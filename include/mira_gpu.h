@@ -203,9 +203,9 @@ int mira_msm_last_table_bits(int32_t *table_bits);
  * measured is kept for the rest of the key's life (commits of >= 2^12 pairs, unforced widths, not the ranks of a sharded MSM); 0: the
  * planner's tables alone decide */
 #define MIRA_TUNE_WIDTH_TRIALS 18
-/* workgroups in the persistent grid of the wave-level NTT kernel (default: 256 CUs x the workgroups that fit one).  A pass with at
- * least four block-groups per workgroup hands them out through per-XCD counters; tests set a small grid so that this path, its
- * ranges without a home workgroup included, runs at sizes the CPU emulation reaches */
+/* workgroups in the persistent grid of the NTT kernels (default: 256 CUs x the workgroups that fit one).  A pass with at least
+ * four block-groups (wave-level kernel) or lines (workgroup-level kernel) per workgroup hands them out through per-XCD counters;
+ * tests set a small grid so that this path, its ranges without a home workgroup included, runs at sizes the CPU emulation reaches */
 #define MIRA_TUNE_NTT_GRID 19
 int mira_set_tuning(int knob, int64_t value);
 

@@ -191,7 +191,7 @@ static int ntt_device_locked(void *d_a, uint32_t log_n, const uint64_t omega[4],
     unsigned char *a = reinterpret_cast<unsigned char *>(d_a);
     const unsigned char *cnull = nullptr;
     auto threads_for = [](uint32_t m) { return std::min<uint32_t>(1024, std::max<uint32_t>(64, (1u << m) / 2)); };
-    auto lds_for = [](uint32_t m) { return ((size_t)NTT_LDS_BYTES_PER_ELEM << m) + 16 + ((size_t)NTT_LDS_BYTES_PER_ELEM << NTT_LDS_TW_LOG); };
+    auto lds_for = [](uint32_t m) { return ((size_t)NTT_LDS_BYTES_PER_ELEM << m) + 16 + ((size_t)NTT_LDS_BYTES_PER_ELEM << NTT_LDS_TW_LOG) + 16; };   // line, twiddles, the next lines' numbers
     const bool use_wave = ntt_use_wave(log_n);
     auto lo_ptr = [&](int tw) { return tw < 0 ? (const unsigned char *)nullptr : (tw == 0 && t.single[0] == 2) ? tab + t.off_full : tab + t.off_lo[tw]; };
     auto run = [&](NttPass ps, const unsigned char *src, unsigned char *dst, uint32_t p, int tw, const char *name) {
@@ -222,9 +222,13 @@ static int ntt_device_locked(void *d_a, uint32_t log_n, const uint64_t omega[4],
             return;
         }
         const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(8, (160 * 1024) / lds_for(ps.log_len)), 2048 / threads_for(ps.log_len)));
-        LAUNCH_BARRIER(k_ntt_lines<Fr29>, std::min<uint32_t>(ps.nlines, NTT_PERSISTENT_GRID * per_cu), threads_for(ps.log_len), lds_for(ps.log_len), g.stream, src, dst, ps,
-                       tab + t.off_tw[p], lo_ptr(tw), tw >= 0 ? tab + t.off_hi[tw] : cnull,
-                       tw >= 0 ? cnull : (const unsigned char *)scale_d);
+        const uint32_t grid = std::min<uint32_t>(ps.nlines, (uint32_t)std::max<size_t>(1, tuned(MIRA_TUNE_NTT_GRID, NTT_PERSISTENT_GRID * per_cu)));
+#define NTTL_LAUNCH(COUNTERS)                                                                                                                              \
+    LAUNCH_BARRIER((k_ntt_lines<Fr29, COUNTERS>), grid, threads_for(ps.log_len), lds_for(ps.log_len), g.stream, src, dst, ps,                                \
+                   tab + t.off_tw[p], lo_ptr(tw), tw >= 0 ? tab + t.off_hi[tw] : cnull, tw >= 0 ? cnull : (const unsigned char *)scale_d,                   \
+                   reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(g.ntt_consts.p) + NTT_CTR_OFFSET + p * NTT_CTR_PASS_BYTES))
+        if (ps.nlines >= NTTW_DYNAMIC_MIN * grid) NTTL_LAUNCH(true); else NTTL_LAUNCH(false);
+#undef NTTL_LAUNCH
         tm_mark(name);
     };
     const uint64_t n1 = (uint64_t)1 << t.m[0], n2 = (uint64_t)1 << t.m[1], n3 = (uint64_t)1 << t.m[2];
@@ -290,7 +294,8 @@ int ntt_kind_device(void *d_a, uint32_t log_n, NttKind kind, const uint64_t *ome
 int ntt_init() {
 #ifndef MIRA_CPU_EMU
     // a 4096-point line is 128 KiB of LDS, above the 64 KiB default
-    RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_lines<Fr29>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_lines<Fr29, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_lines<Fr29, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_wave<Fr29, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTTW_LDS_BYTES));
     RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_wave<Fr29, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTTW_LDS_BYTES));
     RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_wave<Fr29, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTTW_LDS_BYTES));

@@ -87,6 +87,53 @@ struct NttPass {
     uint32_t prescaled;        // last pass only: the pass before left every element times 2^261 (times the ifft scale): finish with f29_redc, not a product
 };
 
+// Work distribution: the block-groups of a pass are cut into NTTW_RANGES contiguous ranges, one per XCD (workgroups b and
+// b + 8 share an XCD and its L2: neighbouring strided lines meet there), each with a counter in global memory (a 128-byte
+// line of its own).  A workgroup takes the next block-group of its range when it has finished one, and walks on through
+// the other ranges when its own is empty.  (A static stride per workgroup was measured: the SIMD issues for the oldest
+// wave first, so of the workgroups of a CU the one in wave slot 0 ran three times as fast as the one in slot 2 and left it
+// to finish the pass alone.)
+static constexpr uint32_t NTTW_RANGES = 8, NTTW_CTR_STRIDE = 32, NTTW_DONE = 0xFFFFFFFFu;
+// thread 0 of a workgroup: the next block-group, or NTTW_DONE.  r = how many ranges this workgroup has left behind.
+// The FIRST block-group of a workgroup costs no counter: workgroup b is at home in range b mod 8 and takes that range's
+// block-group number b / 8; the counter of a range hands out what lies behind the first ones of its home workgroups (a
+// transform of 2^20 points has hardly more block-groups than the grid has workgroups: with every first block-group
+// drawn from a counter, 96 workgroups queued on one address before anything started, 0.14 -> 0.20 ms).
+// Passes with fewer than NTTW_DYNAMIC_MIN block-groups per workgroup keep the static stride (block-groups b, b + grid, ...
+// in the XCD-aware order): nothing to balance, and the counters only cost (2^21 points: 0.26 -> 0.28 ms with them).
+static constexpr uint32_t NTTW_DYNAMIC_MIN = 4;
+// the first block-group of this workgroup: a function of its number alone, so every lane may evaluate it (k_ntt_lines does).
+// A grid never has more workgroups than the pass has block-groups, and under the counters a range holds at least half a grid of
+// them: every workgroup has a first one.
+DEV uint32_t nttw_first(uint32_t nbg) {
+    if (nbg < NTTW_DYNAMIC_MIN * gridDim.x) {
+        const uint32_t i = blockIdx.x;
+        return i >= nbg ? NTTW_DONE : (nbg & 7u) == 0 ? (i & 7u) * (nbg >> 3) + (i >> 3) : i;
+    }
+    const uint32_t per = (nbg + NTTW_RANGES - 1) / NTTW_RANGES;
+    const uint32_t x = blockIdx.x % NTTW_RANGES, w = blockIdx.x / NTTW_RANGES, lo = x * per, hi = lo + per < nbg ? lo + per : nbg;
+    return lo + w < hi ? lo + w : NTTW_DONE;
+}
+// every further one (ONE lane of the workgroup calls this)
+DEV uint32_t nttw_grab(uint32_t *ctr, uint32_t &r, uint32_t nbg) {
+    if (nbg < NTTW_DYNAMIC_MIN * gridDim.x) {                      // r = the rounds of the stride behind this workgroup
+        const uint32_t i = blockIdx.x + ++r * gridDim.x;
+        if (i >= nbg) return NTTW_DONE;
+        return (nbg & 7u) == 0 ? (i & 7u) * (nbg >> 3) + (i >> 3) : i;
+    }
+    const uint32_t per = (nbg + NTTW_RANGES - 1) / NTTW_RANGES;
+    while (r < NTTW_RANGES) {
+        const uint32_t x = (blockIdx.x + r) % NTTW_RANGES, lo = x * per, hi = lo + per < nbg ? lo + per : nbg;
+        const uint32_t at_home = gridDim.x > x ? (gridDim.x - x + NTTW_RANGES - 1) / NTTW_RANGES : 0u;   // each took lo + its number
+        if (lo + at_home < hi) {
+            const uint32_t i = atomicAdd(&ctr[x * NTTW_CTR_STRIDE], 1u);
+            if (lo + at_home + i < hi) return lo + at_home + i;
+        }
+        r++;
+    }
+    return NTTW_DONE;
+}
+
 // One workgroup per line.  blockDim.x = max(64, N/2) capped at 1024.  dynamic LDS = N * 36 B + 16 + 256 * 36 B.
 //
 // Inside the line every value stays a loose 9 x 29-bit element (field29.cuh): a butterfly is one
@@ -114,11 +161,15 @@ template <class F> struct NttLds {
     }
 };
 
-template <class F>
+// COUNTERS: lines come from the per-XCD counters (the host asks for it where a workgroup has four lines or more: 2^25 and up);
+// without, the static stride, and not a word of LDS or an instruction more than it needs -- the two-pass transforms of 2^9 ..
+// 2^19 points are one line per workgroup and 20 us per pass (measured with the counter path's bookkeeping in: + 1 us per pass)
+template <class F, bool COUNTERS>
 KERNEL void __launch_bounds__(1024) k_ntt_lines(const unsigned char *__restrict__ src, unsigned char *__restrict__ dst, NttPass ps,
                         const unsigned char *__restrict__ line_tw,   // omega_N^j, j < N/2, TW_BYTES each
                         const unsigned char *__restrict__ t_lo, const unsigned char *__restrict__ t_hi,
-                        const unsigned char *__restrict__ scale) {   // multiplier-form scale, or one, for the last pass
+                        const unsigned char *__restrict__ scale,     // multiplier-form scale, or one, for the last pass
+                        uint32_t *__restrict__ ctr) {                // NTTW_RANGES work counters of this launch, zero
     using S = typename F::Sat;
     DYN_SHARED(U4, lds);
     const uint32_t N = 1u << ps.log_len;
@@ -137,19 +188,15 @@ KERNEL void __launch_bounds__(1024) k_ntt_lines(const unsigned char *__restrict_
         for (uint32_t j = threadIdx.x; j < cnt; j += blockDim.x)
             T.store(j, tw_load<F>(line_tw + (size_t)(j << (ps.log_len - tw_layers)) * TW_BYTES));
     }
-    // Persistent workgroups: each walks lines blockIdx.x, blockIdx.x + gridDim.x, ...  The next
-    // line's elements are fetched into registers before the butterfly layers of the current line
-    // start, so the strided HBM gather is hidden behind ~100k cycles of arithmetic.
-    // XCD-aware order: workgroups b and b+8 share an XCD (and its L2); each XCD gets a contiguous
-    // range of lines so neighbouring strided lines (which share 128-B lines) meet in one L2.
-    // Speed only; any mapping is correct.
-    auto line_of = [&](uint32_t idx) {
-        return ((ps.nlines & 7u) == 0) ? (idx & 7u) * (ps.nlines >> 3) + (idx >> 3) : idx;
-    };
+    // Persistent workgroups.  Lines are handed out like the block-groups of k_ntt_wave (nttw_grab: a static stride while a
+    // workgroup has fewer than four lines, per-XCD counters above: the workgroups of a CU run at different speeds, the SIMD
+    // issues for its oldest wave first).  The next line's elements are fetched into registers before the butterfly layers
+    // of the current line start, so the strided HBM gather is hidden behind ~100k cycles of arithmetic -- hence the line
+    // after that is asked for beside that prefetch, a whole iteration before its number is needed.
+    uint32_t *NEXT = reinterpret_cast<uint32_t *>(tbase + 2 * (size_t)(1u << NTT_LDS_TW_LOG) + (1u << NTT_LDS_TW_LOG) / 4);   // two words, by iteration parity
     constexpr int PRE = 4;                               // N / blockDim.x <= 4 (4096 points, 1024 lanes)
     Fe<S> pre[PRE];
-    auto fetch = [&](uint32_t idx) {
-        const uint32_t fl = line_of(idx);
+    auto fetch = [&](uint32_t fl) {
         const unsigned char *in = src + ((size_t)(fl >> ps.split) * ps.in_hi + (size_t)(fl & split_mask) * ps.in_lo) * 32;
 #pragma unroll
         for (int k = 0; k < PRE; k++) {
@@ -157,10 +204,15 @@ KERNEL void __launch_bounds__(1024) k_ntt_lines(const unsigned char *__restrict_
             if (q < N) pre[k] = fe_load<S>(in + (size_t)q * ps.in_elem_stride * 32);
         }
     };
-    uint32_t idx = blockIdx.x;
-    if (idx < ps.nlines) fetch(idx);
-    for (; idx < ps.nlines; idx += gridDim.x) {
-        const uint32_t line = line_of(idx);
+    // every lane works out the workgroup's first line for itself (no counter is involved); lane 0 asks for the second one
+    // beside the first line's loads and publishes it behind the first barrier
+    uint32_t ranges_left = 0, par = 0, pend = NTTW_DONE;           // pend (thread 0): the line to fetch in the coming iteration
+    uint32_t stride_i = blockIdx.x;                                // (static stride) lines stride_i, stride_i + grid, ... in the XCD-aware order
+    auto stride_line = [&](uint32_t i) { return i >= ps.nlines ? NTTW_DONE : (ps.nlines & 7u) == 0 ? (i & 7u) * (ps.nlines >> 3) + (i >> 3) : i; };
+    uint32_t line = COUNTERS ? nttw_first(ps.nlines) : stride_line(stride_i);
+    if (line != NTTW_DONE) fetch(line);
+    if (COUNTERS && threadIdx.x == 0 && line != NTTW_DONE) pend = nttw_grab(ctr, ranges_left, ps.nlines);
+    while (line != NTTW_DONE) {
 #pragma unroll
         for (int k = 0; k < PRE; k++) {
             uint32_t q = threadIdx.x + k * blockDim.x;
@@ -169,8 +221,18 @@ KERNEL void __launch_bounds__(1024) k_ntt_lines(const unsigned char *__restrict_
                 L.store(r, ntt_unpack<F>(pre[k]));
             }
         }
-        __syncthreads();
-        if (idx + gridDim.x < ps.nlines) fetch(idx + gridDim.x);
+        uint32_t line_next;
+        if constexpr (COUNTERS) {
+            if (threadIdx.x == 0) NEXT[par] = pend;
+            __syncthreads();
+            line_next = NEXT[par];
+        } else {
+            __syncthreads();
+            stride_i += gridDim.x;
+            line_next = stride_line(stride_i);
+        }
+        if (line_next != NTTW_DONE) fetch(line_next);
+        if (COUNTERS && threadIdx.x == 0) pend = line_next != NTTW_DONE ? nttw_grab(ctr, ranges_left, ps.nlines) : NTTW_DONE;   // answers beside the prefetch
         for (uint32_t s = 0; s < ps.log_len; s++) {
             const uint32_t half = 1u << s;
             const double bound = 2.0 + 3.0 * s;
@@ -210,6 +272,7 @@ KERNEL void __launch_bounds__(1024) k_ntt_lines(const unsigned char *__restrict_
             fe_store(out + (size_t)k * ps.out_elem_stride * 32, ntt_canonical_product(v));   // v: a product or a reduction in every branch
         }
         __syncthreads();                                 // LDS is rewritten by the next line
+        line = line_next; par ^= 1u;
     }
 }
 
@@ -245,13 +308,6 @@ static constexpr int NTTW_PLANE = 256;                   // dwords per limb plan
 #define NTTW_XPLANES 9
 #endif
 static constexpr int NTTW_XP = NTTW_XPLANES;
-// Work distribution: the block-groups of a pass are cut into NTTW_RANGES contiguous ranges, one per XCD (workgroups b and
-// b + 8 share an XCD and its L2: neighbouring strided lines meet there), each with a counter in global memory (a 128-byte
-// line of its own).  A workgroup takes the next block-group of its range when it has finished one, and walks on through
-// the other ranges when its own is empty.  (A static stride per workgroup was measured: the SIMD issues for the oldest
-// wave first, so of the workgroups of a CU the one in wave slot 0 ran three times as fast as the one in slot 2 and left it
-// to finish the pass alone.)
-static constexpr uint32_t NTTW_RANGES = 8, NTTW_CTR_STRIDE = 32, NTTW_DONE = 0xFFFFFFFFu;
 static constexpr size_t NTTW_TILE_BYTES = 32768;
 static constexpr size_t NTTW_X_BYTES = (size_t)NTTW_WAVES * NTTW_XP * NTTW_PLANE * 4 > NTTW_TILE_BYTES ? (size_t)NTTW_WAVES * NTTW_XP * NTTW_PLANE * 4 : NTTW_TILE_BYTES;
 static constexpr size_t NTTW_LDS_BYTES = NTTW_X_BYTES + 128 * 9 * 4 + 16;   // exchange planes (under the tile) + N/2 twiddles + the next block-group (two words)
@@ -427,37 +483,6 @@ template <class F> struct NttwIo {
     }
 };
 
-// thread 0 of a workgroup: the next block-group, or NTTW_DONE.  r = how many ranges this workgroup has left behind.
-// The FIRST block-group of a workgroup costs no counter: workgroup b is at home in range b mod 8 and takes that range's
-// block-group number b / 8; the counter of a range hands out what lies behind the first ones of its home workgroups (a
-// transform of 2^20 points has hardly more block-groups than the grid has workgroups: with every first block-group
-// drawn from a counter, 96 workgroups queued on one address before anything started, 0.14 -> 0.20 ms).
-// Passes with fewer than NTTW_DYNAMIC_MIN block-groups per workgroup keep the static stride (block-groups b, b + grid, ...
-// in the XCD-aware order): nothing to balance, and the counters only cost (2^21 points: 0.26 -> 0.28 ms with them).
-static constexpr uint32_t NTTW_DYNAMIC_MIN = 4;
-DEV uint32_t nttw_grab(uint32_t *ctr, uint32_t &r, uint32_t nbg, bool first) {
-    if (nbg < NTTW_DYNAMIC_MIN * gridDim.x) {                      // r = the rounds of the stride behind this workgroup
-        const uint32_t i = blockIdx.x + (first ? 0u : ++r) * gridDim.x;
-        if (i >= nbg) return NTTW_DONE;
-        return (nbg & 7u) == 0 ? (i & 7u) * (nbg >> 3) + (i >> 3) : i;
-    }
-    const uint32_t per = (nbg + NTTW_RANGES - 1) / NTTW_RANGES;
-    if (first) {
-        const uint32_t x = blockIdx.x % NTTW_RANGES, w = blockIdx.x / NTTW_RANGES, lo = x * per, hi = lo + per < nbg ? lo + per : nbg;
-        if (lo + w < hi) return lo + w;
-    }
-    while (r < NTTW_RANGES) {
-        const uint32_t x = (blockIdx.x + r) % NTTW_RANGES, lo = x * per, hi = lo + per < nbg ? lo + per : nbg;
-        const uint32_t at_home = gridDim.x > x ? (gridDim.x - x + NTTW_RANGES - 1) / NTTW_RANGES : 0u;   // each took lo + its number
-        if (lo + at_home < hi) {
-            const uint32_t i = atomicAdd(&ctr[x * NTTW_CTR_STRIDE], 1u);
-            if (lo + at_home + i < hi) return lo + at_home + i;
-        }
-        r++;
-    }
-    return NTTW_DONE;
-}
-
 // PHASE SHIFT between the workgroups that share a CU.  A grid starts within a microsecond and every workgroup does the
 // same work, so without it the NTTW_OCC workgroups of a CU -- one wave each on every SIMD -- walk in lockstep: all of
 // them wait for their tiles while the multiplier idles, then all of them multiply while the memory system idles (measured:
@@ -540,7 +565,7 @@ KERNEL void __launch_bounds__(64 * NTTW_WAVES) __attribute__((amdgpu_waves_per_e
     if (threadIdx.x == 0 && blockIdx.x == 0) { g_nttw_clk[0] = __builtin_amdgcn_s_memtime(); g_nttw_clk[1] = __builtin_amdgcn_s_memrealtime(); }
 #endif
     uint32_t ranges_left = 0, par = 0;                             // (thread 0) ranges emptied; parity of the iteration
-    if (threadIdx.x == 0) NEXT[0] = nttw_grab(ctr, ranges_left, nbg, true);
+    if (threadIdx.x == 0) NEXT[0] = nttw_first(nbg);
     __syncthreads();
     uint32_t idx = NEXT[0];
     while (idx != NTTW_DONE) {
@@ -552,7 +577,7 @@ KERNEL void __launch_bounds__(64 * NTTW_WAVES) __attribute__((amdgpu_waves_per_e
 #endif
         // the next block-group: its counter answers behind this iteration's tile loads.  NEXT[par ^ 1] was last read
         // before the barrier below of the iteration before, which every wave has passed
-        if (threadIdx.x == 0) NEXT[par ^ 1u] = nttw_grab(ctr, ranges_left, nbg, false);
+        if (threadIdx.x == 0) NEXT[par ^ 1u] = nttw_grab(ctr, ranges_left, nbg);
         __syncthreads();
         const uint32_t idx_next = NEXT[par ^ 1u];
         if (COOP & 1) {

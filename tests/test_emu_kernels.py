@@ -175,15 +175,17 @@ def test_emu_ntt_pass_schedules(emu_lib, max_line, ks, wave):
         emu_lib.tune(_lib.TUNE_NTT_WAVE, -1)
 
 
+@pytest.mark.parametrize("wave", [1, 0])
 @pytest.mark.parametrize("grid", [3, 8, 13])
-def test_emu_ntt_wave_block_groups_from_counters(emu_lib, grid):
-    """k_ntt_wave hands the block-groups of a pass out through per-XCD counters once a workgroup has four of them or more
-    (ntt_kernels.cuh: nttw_grab).  On the GPU that starts at 2^22 points; MIRA_TUNE_NTT_GRID makes the grid small enough for the
-    emulation: 3 workgroups (five of the eight ranges have no home workgroup: their block-groups are all taken by workgroups that
-    walk on from their own range), 8 (one per range) and 13 (uneven homes) -- 2^15 points in three passes of 32-point lines are
-    32 block-groups per pass, 2^13 are eight (the static stride)."""
+def test_emu_ntt_block_groups_from_counters(emu_lib, grid, wave):
+    """Both NTT kernels hand the block-groups (k_ntt_wave) / lines (k_ntt_lines) of a pass out through per-XCD counters once a
+    workgroup has four of them or more (ntt_kernels.cuh: nttw_first, nttw_grab).  On the GPU that starts at 2^22 and 2^25 points;
+    MIRA_TUNE_NTT_GRID makes the grid small enough for the emulation: 3 workgroups (five of the eight ranges have no home
+    workgroup: their block-groups are all taken by workgroups that walk on from their own range), 8 (one per range) and 13 (uneven
+    homes) -- 2^15 points in three passes of 32-point lines are 32 block-groups (1 024 lines) per pass, 2^13 are eight block-groups
+    (the static stride of the wave-level kernel)."""
     emu_lib.tune(_lib.TUNE_NTT_MAX_LOG_LINE, 5)
-    emu_lib.tune(_lib.TUNE_NTT_WAVE, 1)
+    emu_lib.tune(_lib.TUNE_NTT_WAVE, wave)
     emu_lib.tune(_lib.TUNE_NTT_GRID, grid)
     try:
         for k in (15, 13):

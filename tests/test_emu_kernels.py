@@ -184,15 +184,17 @@ def test_emu_ntt_block_groups_from_counters(emu_lib, grid, wave):
     workgroup: their block-groups are all taken by workgroups that walk on from their own range), 8 (one per range) and 13 (uneven
     homes) -- 2^15 points in three passes of 32-point lines are 32 block-groups (1 024 lines) per pass, 2^13 are eight block-groups
     (the static stride of the wave-level kernel)."""
-    emu_lib.tune(_lib.TUNE_NTT_MAX_LOG_LINE, 5)
+    # the workgroup-level kernel is a workgroup per line on the emulation: 16-point lines, 256 of them per pass of 2^12 points
+    max_line, sizes, inv = (5, (15, 13), 14) if wave else (4, (12,), 11)
+    emu_lib.tune(_lib.TUNE_NTT_MAX_LOG_LINE, max_line)
     emu_lib.tune(_lib.TUNE_NTT_WAVE, wave)
     emu_lib.tune(_lib.TUNE_NTT_GRID, grid)
     try:
-        for k in (15, 13):
+        for k in sizes:
             a = C.synth_scalars(0, 1 << k, seed=4100 + k + grid)
             assert (F.fft(a, k, lib=emu_lib) == C.fft(a, k)).all(), k
-        a = C.synth_scalars(0, 1 << 14, seed=4200 + grid)
-        assert (F.ifft(a, 14, lib=emu_lib) == C.ifft(a, 14)).all()
+        a = C.synth_scalars(0, 1 << inv, seed=4200 + grid)
+        assert (F.ifft(a, inv, lib=emu_lib) == C.ifft(a, inv)).all()
     finally:
         emu_lib.tune(_lib.TUNE_NTT_MAX_LOG_LINE, -1)
         emu_lib.tune(_lib.TUNE_NTT_WAVE, -1)

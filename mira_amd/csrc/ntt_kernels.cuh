@@ -483,32 +483,6 @@ template <class F> struct NttwIo {
     }
 };
 
-// PHASE SHIFT between the workgroups that share a CU.  A grid starts within a microsecond and every workgroup does the
-// same work, so without it the NTTW_OCC workgroups of a CU -- one wave each on every SIMD -- walk in lockstep: all of
-// them wait for their tiles while the multiplier idles, then all of them multiply while the memory system idles (measured:
-// a pass costs its memory-only time PLUS its arithmetic-only time).  The workgroup in wave slot s of its SIMDs starts
-// s * NTTW_STAGGER_TICKS * 10 ns late (s_memrealtime: 100 MHz), a third of an iteration apart, so that one workgroup's
-// fill and drain run under the butterflies of the other two.  Speed only.
-#ifndef NTTW_STAGGER_TICKS
-#define NTTW_STAGGER_TICKS 0
-#endif
-DEV void nttw_stagger(uint32_t *lds) {
-#if !defined(MIRA_CPU_EMU) && NTTW_STAGGER_TICKS > 0
-    if (threadIdx.x == 0) {
-        uint32_t hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        lds[0] = (hwid & 15u) % (uint32_t)NTTW_OCC;               // WAVE_ID: the slot of this wave on its SIMD
-    }
-    __syncthreads();
-    const uint32_t slot = lds[0];
-    __syncthreads();
-    const uint64_t until = __builtin_amdgcn_s_memrealtime() + (uint64_t)slot * NTTW_STAGGER_TICKS;
-    while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(32);
-#else
-    (void)lds;
-#endif
-}
-
 // Timing probe (tools/build_probe_variants.sh ... -DNTTW_PROBE_STAMPS; never in the product build): lane 0 of every workgroup
 // writes s_memrealtime (100 MHz) at the phase boundaries of its first NTTW_STAMP_ITERS iterations to a buffer of its own.
 #ifdef NTTW_PROBE_STAMPS
@@ -539,7 +513,6 @@ KERNEL void __launch_bounds__(64 * NTTW_WAVES) __attribute__((amdgpu_waves_per_e
     for (uint32_t i = threadIdx.x; i < (N / 2) * 9; i += blockDim.x)
         TW[i] = reinterpret_cast<const uint32_t *>(line_tw + (size_t)(i / 9) * TW_BYTES)[i % 9];
     __syncthreads();
-    nttw_stagger(lds);
     const NttwIo<F> io{src, dst, t_lo, t_hi, scale, ps, ps.tw_shift == 0xFFFFFFFFu ? 0 : ((1u << ps.tw_shift) - 1u), (1u << ps.split) - 1u, m, N};
     const uint32_t log_lpw = NTTW_LOG - m, lpw = 1u << log_lpw;    // lines per wave
     const uint32_t rounds = (m + 1) / 2;

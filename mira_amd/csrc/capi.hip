@@ -143,19 +143,19 @@ static int upload_consts() {
 // LDS trees of general additions (5 us per level here).  A batch is count * W windows of one launch
 // sequence: the additions scale, the latency does not; its W * (count - 1) * B extra counters are
 // scanned at 5 800 per microsecond.
-static const int plan_log_n[10] = {6, 10, 13, 15, 16, 17, 18, 19, 20, 21};   // (all rows re-measured in round 4 on the rebuilt bucket reduction, one box: profiles/r04_b_plan_calibrate.txt)
+static const int plan_log_n[10] = {6, 10, 13, 15, 16, 17, 18, 19, 20, 21};   // (all rows re-measured at the END of round 4, per-window path alone -- PLAIN=1 tools/plan_calibrate.py, one box: profiles/r04_o_plan_calibrate.txt; the table of the middle of the round still had c = 8 level with 13 at 2^17, where the later tail work had moved 12 and 13 by 8 %: planned plain commits of 2^17 pairs took c = 8, 0.58 ms against 0.49)
 static const double plan_wall_us[10][17] = {
     //            c = 4     5     6     7     8     9    10    11    12    13    14    15    16
-    {0, 0, 0, 0,   194,   198,   224,   240,   288,   293,   386,   321,   291,   322,   479,   418,   419},
-    {0, 0, 0, 0,   277,   262,   268,   269,   228,   279,   319,   300,   363,   365,   565,   497,   506},
-    {0, 0, 0, 0,   297,   309,   301,   309,   278,   570,   502,   343,   357,   399,   487,   468,   500},
-    {0, 0, 0, 0,   385,   392,   407,   345,   338,   421,   438,   386,   389,   439,   547,   510,   539},
-    {0, 0, 0, 0,   501,   479,   494,   526,   393,   447,   518,   529,   447,   461,   553,   507,   560},
-    {0, 0, 0, 0,   790,   696,   762,   696,   541,   582,   621,   693,   537,   534,   639,   638,   742},
-    {0, 0, 0, 0,  1311,  1122,  1040,  1008,   821,   842,   867,   909,   751,   728,   831,   747,   775},
-    {0, 0, 0, 0,  2484,  2073,  1835,  1706,  1398,  1510,  1376,  1352,  1153,  1084,  1168,  1042,  1030},
-    {0, 0, 0, 0,  4859,  4059,  3524,  3252,  2722,  2714,  2427,  2320,  1988,  1857,  1923,  1707,  1667},
-    {0, 0, 0, 0,  9587,  7989,  7020,  6310,  5318,  5421,  4734,  4386,  3878,  3519,  3494,  3064,  2980},
+    {0, 0, 0, 0,   193,   194,   229,   233,   265,   253,   294,   317,   281,   308,   466,   396,   413},
+    {0, 0, 0, 0,   276,   235,   234,   241,   222,   259,   280,   287,   336,   363,   549,   475,   495},
+    {0, 0, 0, 0,   300,   298,   305,   298,   275,   265,   271,   289,   298,   340,   468,   450,   483},
+    {0, 0, 0, 0,   373,   389,   420,   362,   362,   387,   352,   337,   354,   352,   493,   461,   514},
+    {0, 0, 0, 0,   496,   479,   499,   551,   418,   466,   485,   424,   406,   385,   488,   483,   547},
+    {0, 0, 0, 0,   780,   699,   688,   718,   569,   599,   619,   565,   493,   495,   602,   579,   609},
+    {0, 0, 0, 0,  1333,  1170,  1075,  1045,   854,   865,   862,   773,   720,   698,   802,   757,   775},
+    {0, 0, 0, 0,  2484,  2089,  1895,  1758,  1442,  1535,  1416,  1232,  1146,  1061,  1152,  1081,  1055},
+    {0, 0, 0, 0,  4911,  4127,  3654,  3255,  2757,  2781,  2492,  2218,  1987,  1860,  1927,  1747,  1743},
+    {0, 0, 0, 0,  9931,  8222,  7233,  6390,  5410,  5416,  4749,  4231,  3851,  3523,  3506,  3160,  3013},
 };
 static double plan_table_us(uint32_t c, double n_eff) {
     const double x = std::log2(std::max(n_eff, 1.0));
@@ -214,23 +214,23 @@ static double plan_cost_us(uint32_t c, double n, uint32_t count, const double *b
 }
 
 // The GLV split (glv.cuh) has a table of its own: wall time in microseconds of one commit of 2^glv_log_n[r] uniform pairs -- twice
-// as many half-length scalars -- under width c (tools/glv_probe.py --calibrate; re-measured in round 4 on the rebuilt bucket reduction, profiles/r04_c_glv.txt).  The widths that cut
+// as many half-length scalars -- under width c (tools/glv_probe.py --calibrate; re-measured at the end of round 4, profiles/r04_o_plan_calibrate.txt).  The widths that cut
 // 128 bits evenly stand out (9 at 2^17, 13 at 2^18 - 2^19, 16 beyond): a last window that holds only a few bits of every half is a
 // handful of very heavy buckets.
 static const int glv_log_n[11] = {10, 12, 14, 15, 16, 17, 18, 19, 20, 21, 22};
 static const double glv_wall_us[11][17] = {
     //                c = 5      6      7      8      9     10     11     12     13     14     15     16
-    {    0,     0,     0,     0,     0,   267,   259,   239,   219,   258,   236,   310,   272,   300,   409,   529,   495},
-    {    0,     0,     0,     0,     0,   246,   246,   257,   250,   272,   269,   282,   304,   271,   373,   532,   510},
-    {    0,     0,     0,     0,     0,   302,   309,   298,   286,   344,   327,   332,   332,   332,   393,   516,   441},
-    {    0,     0,     0,     0,     0,   369,   369,   342,   320,   336,   392,   414,   354,   360,   430,   505,   510},
-    {    0,     0,     0,     0,     0,   483,   455,   430,   439,   387,   437,   498,   496,   383,   465,   523,   568},
-    {    0,     0,     0,     0,     0,   734,   646,   593,   586,   522,   553,   561,   645,   492,   562,   615,   619},
-    {    0,     0,     0,     0,     0,  1143,   997,   918,   864,   840,   811,   807,   852,   669,   741,   778,   760},
-    {    0,     0,     0,     0,     0,  2121,  1815,  1595,  1439,  1434,  1319,  1245,  1243,  1032,  1089,  1113,  1075},
-    {    0,     0,     0,     0,     0,  3979,  3405,  2992,  2699,  2690,  2371,  2204,  2111,  1822,  1841,  1802,  1718},   // (c < 9: not measured, extrapolated)
-    {    0,     0,     0,     0,     0,  7880,  6743,  5925,  5345,  5327,  4622,  4219,  4064,  3488,  3418,  3450,  3102},
-    {    0,     0,     0,     0,     0, 16179, 13844, 12165, 10974, 10937,  9540,  8698,  8069,  7162,  6963,  6795,  6019},
+    {    0,     0,     0,     0,     0,   258,   231,   209,   201,   229,   222,   256,   258,   287,   383,   497,   484},
+    {    0,     0,     0,     0,     0,   247,   245,   250,   225,   243,   226,   247,   273,   261,   351,   487,   491},
+    {    0,     0,     0,     0,     0,   297,   312,   301,   285,   342,   305,   295,   299,   290,   364,   450,   431},
+    {    0,     0,     0,     0,     0,   360,   364,   349,   319,   339,   365,   330,   306,   309,   387,   470,   487},
+    {    0,     0,     0,     0,     0,   483,   451,   428,   437,   397,   473,   470,   384,   332,   403,   479,   537},
+    {    0,     0,     0,     0,     0,   731,   640,   601,   589,   533,   594,   599,   496,   441,   509,   571,   623},
+    {    0,     0,     0,     0,     0,  1169,  1025,   939,   877,   862,   868,   835,   693,   627,   703,   745,   759},
+    {    0,     0,     0,     0,     0,  2116,  1857,  1663,  1467,  1465,  1387,  1308,  1117,  1017,  1078,  1108,  1079},
+    {    0,     0,     0,     0,     0,  4043,  3548,  3177,  2803,  2799,  2505,  2297,  1998,  1807,  1829,  1841,  1741},   // (c < 9: not measured, scaled from the 2^19 row)
+    {    0,     0,     0,     0,     0,  8188,  7186,  6435,  5677,  5669,  5023,  4617,  4092,  3643,  3666,  3548,  3264},   // (c < 9: not measured, scaled from the 2^19 row)
+    {    0,     0,     0,     0,     0, 16300, 14305, 12810, 11300, 11285,  9870,  8977,  8082,  7357,  7152,  6959,  6222},   // (c < 9: not measured, scaled from the 2^19 row)
 };
 static double glv_table_us(uint32_t c, double pairs) {
     const double x = std::log2(std::max(pairs, 1.0));

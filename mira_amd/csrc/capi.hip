@@ -323,13 +323,13 @@ static MsmPlan make_plan_shared(size_t n, const Bases::SharedSet &set, uint64_t 
 // n.  MIRA_TUNE_TABLE_WIDTH names a width outright (calibration, tests).
 static const int shared_log_n[6] = {12, 14, 16, 17, 19, 21};
 static const double shared_wall_us[6][17] = {
-    //                          c = 8     9    10    11    12    13    14    15    16
-    {0, 0, 0, 0, 0, 0, 0, 0,   238,   249,   244,   285,   285,   285,   293,   268,   311},
-    {0, 0, 0, 0, 0, 0, 0, 0,   294,   301,   309,   324,   347,   322,   348,   283,   298},
-    {0, 0, 0, 0, 0, 0, 0, 0,   366,   363,   375,   405,   453,   411,   441,   418,   437},
-    {0, 0, 0, 0, 0, 0, 0, 0,   532,   512,   506,   514,   571,   519,   539,   501,   532},
-    {0, 0, 0, 0, 0, 0, 0, 0,  1412,  1438,  1290,  1211,  1218,  1082,  1117,   978,   955},
-    {0, 0, 0, 0, 0, 0, 0, 0,  5677,  5603,  4802,  4429,  4033,  3733,  3514,  3057,  2926},
+    //                          c = 8     9    10    11    12    13    14    15    16      (re-measured at the end of round 4: profiles/r04_o_plan_calibrate.txt)
+    {0, 0, 0, 0, 0, 0, 0, 0,   199,   216,   208,   233,   223,   212,   239,   244,   296},
+    {0, 0, 0, 0, 0, 0, 0, 0,   261,   270,   283,   294,   315,   308,   278,   269,   293},
+    {0, 0, 0, 0, 0, 0, 0, 0,   355,   337,   348,   381,   448,   472,   434,   368,   423},
+    {0, 0, 0, 0, 0, 0, 0, 0,   520,   501,   491,   498,   564,   534,   557,   468,   497},
+    {0, 0, 0, 0, 0, 0, 0, 0,  1522,  1544,  1404,  1318,  1306,  1196,  1189,  1026,  1021},
+    {0, 0, 0, 0, 0, 0, 0, 0,  5978,  5853,  5072,  4661,  4298,  3998,  3751,  3341,  3243},
 };
 static double shared_cost_us(uint32_t c, double n) {
     const double x = std::log2(std::max(n, 1.0));

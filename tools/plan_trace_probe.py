@@ -6,9 +6,9 @@ lib = _lib.load()
 glv = int(os.environ.get("GLV", "0"))
 lib.tune(_lib.TUNE_GLV_AUTO_MAX_LOG, -1 if glv else 0)
 for n in [int(a) for a in sys.argv[1:]] or [131072]:
-    key = cm.CommitmentKey.synthetic(0, n); d = cm.synth_scalars_device(0, n)
+    kind = int(os.environ.get("KIND", "0")); key = cm.CommitmentKey.synthetic(0, n); d = cm.synth_scalars_device(0, n, kind=kind)
     row = []
-    for i in range(16):
+    for i in range(20):
         t0 = time.perf_counter(); key.commit_device(d, n); dt = (time.perf_counter() - t0) * 1e3
         c, w = ctypes.c_int32(), ctypes.c_int32()
         lib.check(lib.c.mira_msm_last_plan(ctypes.byref(c), ctypes.byref(w)))

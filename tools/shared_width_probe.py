@@ -12,8 +12,8 @@ widths = list(range(8, 17))
 print("n kind per-window " + " ".join(f"c={c}" for c in widths) + " chosen", flush=True)
 for n, kind in cases:
     key = cm.CommitmentKey.synthetic(0, n); d = cm.synth_scalars_device(0, n, kind=kind)
-    def med(reps=9):
-        key.commit_device(d, n); key.commit_device(d, n)
+    def med(reps=15):
+        [key.commit_device(d, n) for _ in range(6)]
         ts = []
         for _ in range(reps):
             t0 = time.perf_counter(); out = key.commit_device(d, n); ts.append((time.perf_counter() - t0) * 1e3)

@@ -24,3 +24,16 @@ for name, fn in (("batch 6 x 2^17", batch), ("ntt 2^24", ntt)):
             t0 = time.perf_counter(); fn(); cold.append((time.perf_counter() - t0) * 1e3)
         row.append("%gs: %.3f" % (pause, sorted(cold)[2]))
     print("%-16s sustained %.3f ms; first call after a pause of  %s" % (name, warm, "  ".join(row)), flush=True)
+
+# where the penalty sits: the kernels' own event timings of the first call after a pause beside its wall time
+lib.check(lib.c.mira_set_timing(1))
+for name, fn in (("batch 6 x 2^17", batch), ("ntt 2^24", ntt)):
+    for pause in (0.0, 1.0):
+        walls, kerns = [], []
+        for _ in range(5):
+            for _ in range(10): fn()
+            if pause: time.sleep(pause)
+            t0 = time.perf_counter(); fn(); walls.append((time.perf_counter() - t0) * 1e3)
+            kerns.append(sum(ms for _, ms in lib.timings()))
+        print("%-16s pause %gs: wall %.3f ms, kernels (events) %.3f ms" % (name, pause, sorted(walls)[2], sorted(kerns)[2]), flush=True)
+lib.check(lib.c.mira_set_timing(0))

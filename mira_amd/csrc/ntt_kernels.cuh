@@ -517,11 +517,11 @@ KERNEL void __launch_bounds__(64 * NTTW_WAVES) __attribute__((amdgpu_waves_per_e
     const uint32_t log_lpw = NTTW_LOG - m, lpw = 1u << log_lpw;    // lines per wave
     const uint32_t rounds = (m + 1) / 2;
     // block-groups of NTTW_WAVES consecutive wave-groups (4 * lpw consecutive lines: their strided
-    // elements share 128-byte lines); XCD-aware order as in k_ntt_lines
+    // elements share 128-byte lines), handed out by nttw_first / nttw_grab
     const uint32_t ngroups = (ps.nlines + lpw - 1) >> log_lpw, nbg = (ngroups + NTTW_WAVES - 1) / NTTW_WAVES;
     auto first_line = [&](uint32_t bg) { return (bg * NTTW_WAVES + wv) << log_lpw; };   // first line of this wave
-    // (a register prefetch of the next group's elements was measured: no gain -- the other waves of
-    // the SIMD already cover the strided loads; nor did a fourth wave per SIMD, eight-wave workgroups at 128 VGPRs)
+    // (measured without gain, rounds 2 - 4: a register prefetch of the next group's elements, issued at the top or in front of the
+    // drain; a fourth wave per SIMD, as eight-wave workgroups or with the exchange through five planes; Shoup products)
     // ALIASING INVARIANT: `tile` (32 KiB) lies over the exchange planes X of all four waves.  Every transition
     // between a tile phase (fill / take, give / drain) and an exchange phase (put / get of ANY wave) is therefore
     // separated by a workgroup barrier, including the one from the last round of group g to the fill of group g + 1.

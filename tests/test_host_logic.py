@@ -270,3 +270,24 @@ def test_width_trials_settle_and_never_change_the_point(emu_lib):
     finally:
         lib.tune(_lib_mod.TUNE_WIDTH_TRIALS, -1); lib.tune(_lib_mod.TUNE_GLV_AUTO_MAX_LOG, -1)
         lib.free(d); key.close()
+
+
+def test_planner_tables_are_sane(emu_lib):
+    """The window width comes from measured wall-time tables (capi.hip: plan_wall_us, glv_wall_us, shared_wall_us) that go stale
+    whenever a tail kernel changes (round 4: the mid-round table cost planned 2^17-pair commits 17 %).  This cannot re-measure them;
+    it pins what every calibration so far agrees on, so that a mis-typed row shows: widths never shrink as commits grow from 2^18 pairs
+    (12 and 13 bits tie below), the fold step's 2^16 .. 2^18-pair commits take 12 or 13 bits, and everything from 2^21 pairs takes the
+    full 16 -- a pure function of n (the ranks of a sharded MSM rely on that)."""
+    import ctypes
+
+    def plan(n):
+        c = ctypes.c_int32()
+        emu_lib.check(emu_lib.c.mira_msm_plan_window_bits(n, ctypes.byref(c)))
+        return c.value
+    widths = [plan(1 << k) for k in range(6, 29)]
+    assert all(4 <= c <= 16 for c in widths)
+    from18 = widths[18 - 6:]
+    assert from18 == sorted(from18), widths
+    assert all(plan(1 << k) in (12, 13) for k in (16, 17, 18)), widths
+    assert all(plan(1 << k) == 16 for k in range(21, 29)), widths
+    assert plan(3 << 20) == plan(3 << 20) and plan(0) == plan(1)

@@ -721,7 +721,7 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
         for c in plan:
             for width in (15, 13):
                 keys[c].precompute(width)
-        for _ in range(3):
+        for _ in range(6):                                       # (the library times every set of a key on the first commits of a shape, twice each)
             run(False); run(True)
         t16, single16 = [], []
         for _ in range(5):
@@ -965,7 +965,8 @@ def extras(lib, cm, with_cpu, skip_key_load=False):
         for s_ in st.values():
             for width in (15, 13):
                 s_["key"].precompute(width)
-        fold_step()
+        for _ in range(6):                                       # the trials among the two sets settle (two commits per set and shape)
+            fold_step()
         walls16 = []
         for _ in range(5):
             t0 = time.perf_counter(); spans16, last16 = fold_step(); walls16.append(((time.perf_counter() - t0) * 1e3, spans16))

@@ -358,11 +358,13 @@ static const Bases::SharedSet *pick_shared(const Bases &bs, size_t n, uint32_t c
         if (bitlen_hist) {
             double adds, load, u_adds, u_load;
             plan_len_stats(set.c, h, &adds, &load);
-            n_eff = std::max(1.0, adds / set.W);
+            // the dense vector with as many additions: the table was measured on UNIFORM field elements, which have u_adds non-zero
+            // digits each, not W (a 15-bit set has 18 tables for the 17 digits of a uniform scalar) -- as plan_cost_us counts
+            plan_len_stats(set.c, plan_uniform_fractions(), &u_adds, &u_load);
+            n_eff = std::max(1.0, adds / u_adds);
             // ... plus what the length distribution makes heavy beyond a uniform vector with as many additions (the measured table
             // holds the latter): 32-bit witness values under 15-bit windows share TWO top-digit values, under 16-bit windows all
             // carry a one into the third window, under 13-bit windows they spread over 32
-            plan_len_stats(set.c, plan_uniform_fractions(), &u_adds, &u_load);
             heavy = std::max(0.0, plan_heavy_us(adds, load, 1) - plan_heavy_us(u_adds * n_eff, u_load * n_eff, 1));
         }
         // a batch is count bucket sets to reduce: ~1 ns per bucket of every further set (6 x 2^15 buckets: 0.19 ms of k_reduce_chunks
@@ -551,6 +553,25 @@ static void trial_report(Bases::WidthTrial &t, double us, uint32_t c_min, uint32
     t.done = true;
 }
 
+// ... and the same among a key's shared-bucket table sets: the model (pick_shared) ranks them for dense vectors; for the witness
+// vectors of a fold step it was 12 % off (14 x 2^17 scalars: the 11-bit set, 0.82 ms, where the 15-bit one takes 0.73).  A shape's first
+// commits go through every set the key has, twice each, and the fastest is kept (kind bit 2 marks these records; steps = the set's
+// position in the key's list).
+static const Bases::SharedSet *trial_set(const Bases &bs, const Bases::WidthTrial &t, const Bases::SharedSet *model) {
+    const uint32_t c = t.done ? t.best_c : t.cur_c;
+    for (const auto &set : bs.shared) if (set.c == c) return &set;
+    return model;
+}
+static void trial_report_sets(Bases::WidthTrial &t, double us, const Bases &bs) {
+    if (t.done) return;
+    t.cur_us = t.cur_runs == 0 ? us : std::min(t.cur_us, us);
+    if (++t.cur_runs < TRIAL_RUNS) return;
+    if (t.best_us == 0 || t.cur_us < 0.98 * t.best_us) { t.best_us = t.cur_us; t.best_c = t.cur_c; }
+    for (; (size_t)t.steps < bs.shared.size(); t.steps++)
+        if (bs.shared[(size_t)t.steps].c != t.c0) { t.cur_c = bs.shared[(size_t)t.steps].c; t.cur_runs = 0; t.steps++; return; }   // (the model's set went first)
+    t.done = true;
+}
+
 // allow_pieces: the caller combines the points itself with horner_pieces (a commit of this process); else the public partial
 // format, one point per window (*shape then has P = 1).
 static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scalars, size_t n, uint64_t *out_partial,
@@ -620,6 +641,10 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
     if (!d_scalars) { set_error("null scalars"); return MIRA_E_BAD_ARG; }
     // fixed-base mode: window tables present, MSM large enough to be throughput-bound, no forced width
     if (set) {                                               // shared buckets through the per-window launch sequence
+        Bases::WidthTrial *strial = (!sharded && bs.shared.size() > 1 && tuned(MIRA_TUNE_TABLE_WIDTH, 0) == 0 && !(can_hist && !stat_any))
+                                        ? trial_for(bs, n, 1, 4u | (h_scalars ? 2u : 0u), set->c) : nullptr;
+        if (strial) set = trial_set(bs, *strial, set);
+        const auto t_set = std::chrono::steady_clock::now();
         MsmPlan ps = make_plan_shared(n, *set, bs.n);
         if (allow_pieces && !g.windows_dst) plan_reduction(ps, default_pieces(ps, MIRA_MAX_WINDOWS));
         *shape = PartialShape{0, 1, ps.cb, ps.pieces};       // the pieces of ONE bucket set (P = 1: its sum)
@@ -627,6 +652,7 @@ static int msm_partial_locked(uint64_t handle, size_t first, const void *d_scala
         ps.stats = can_hist;
         rc = bs.curve == MIRA_CURVE_BN256 ? msm_launch_bn256(bs, first, d_scalars, h_scalars, n, ps, out_partial)
                                           : msm_launch_grumpkin(bs, first, d_scalars, h_scalars, n, ps, out_partial);
+        if (rc == MIRA_OK && strial) trial_report_sets(*strial, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_set).count(), bs);
         if (rc == MIRA_OK && can_hist) {                     // msm_launch ends with a stream synchronisation
             memcpy(bs.stat_hist, g.hist_host, sizeof bs.stat_hist);
             bs.stat_n = n; bs.stat_kind = 0;
@@ -685,6 +711,11 @@ static int msm_batch_device_locked(uint64_t handle, const void *d_scalars, size_
     const int32_t forced_c = bs.forced_c ? bs.forced_c : g.forced_c;
     const Bases::SharedSet *set = (forced_c == 0 && n >= tuned(MIRA_TUNE_SHARED_MIN_N, TABLE16_MIN_N)) ? pick_shared(bs, n, (uint32_t)std::min<size_t>(count, 64), false) : nullptr;
     if (set) {
+        // which of the key's sets: the model's choice, checked against the others on the first batches of the shape (trial_report_sets)
+        Bases::WidthTrial *strial = (bs.shared.size() > 1 && tuned(MIRA_TUNE_TABLE_WIDTH, 0) == 0 && count <= 64)
+                                        ? trial_for(bs, n, (uint32_t)count, 4u | (h_batch ? 2u : 0u), set->c) : nullptr;
+        if (strial) set = trial_set(bs, *strial, set);
+        const auto t_set = std::chrono::steady_clock::now();
         const uint32_t Ws = (256 + set->c - 1) / set->c;
         const size_t per = std::max<size_t>(1, std::min<size_t>(64, (size_t)(((1ull << 32) - 1) / ((uint64_t)n * Ws))));
         std::vector<uint64_t> sums;
@@ -705,6 +736,7 @@ static int msm_batch_device_locked(uint64_t handle, const void *d_scalars, size_
                 else horner_pieces<FrP>(w, sh, out_affine + (done + b) * 8);
             }
         }
+        if (strial) trial_report_sets(*strial, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_set).count(), bs);
         return MIRA_OK;
     }
     // the GLV split (glv.cuh) where the key has its endomorphism copy: 2 n half-length scalars per commitment, half the windows
@@ -981,7 +1013,7 @@ static int precompute_locked(uint64_t handle, int32_t window_bits) {
         tmp.tables = nullptr; tmp.table_c = tmp.table_w = 0;
         rc = bs.curve == MIRA_CURVE_BN256 ? build_tables_bn256(tmp, (uint32_t)window_bits, W) : build_tables_grumpkin(tmp, (uint32_t)window_bits, W);
         if (rc) return rc;
-        if (tmp.tables) bs.shared.push_back({tmp.tables, (uint32_t)window_bits, W});
+        if (tmp.tables) { bs.shared.push_back({tmp.tables, (uint32_t)window_bits, W}); bs.trials.clear(); }   // the trials among the sets start again
         return MIRA_OK;
     }
     if (window_bits == MIRA_TABLE_GLV) {                       // the interleaved key [P_i, phi(P_i)] of the GLV split

@@ -34,6 +34,7 @@ for n, kind in cases:
             print("   c", c, {a: round(b, 3) for a, b in lib.timings()}, flush=True)
             lib.check(lib.c.mira_set_timing(0))
     lib.check(lib.c.mira_set_tuning(_lib.TUNE_TABLE_WIDTH, -1))
+    for _ in range(24): key.commit_device(d, n)          # the trials among the nine sets (two commits each) settle first
     t, got = med()
     tb = ctypes.c_int32()
     lib.check(lib.c.mira_msm_last_table_bits(ctypes.byref(tb)))

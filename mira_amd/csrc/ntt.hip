@@ -56,8 +56,13 @@ static bool ntt_use_wave(uint32_t log_n) {
     if (mode > 0) return log_n <= 3 * NTTW_LOG;
     return log_n <= NTTW_LOG || (log_n >= 20 && log_n <= 3 * NTTW_LOG);
 }
+// One workgroup can hold a line of 2^12 points, but it is ONE workgroup on one CU walking twelve layers behind barriers: 2^12 points
+// took 92 us as a single line and take 40 us as two passes of 64-point lines on 64 CUs (2^11: 57 -> 39, 2^10: 42 -> 38; 2^9 stays a
+// single line, 35 against 37: tools/ntt_small_probe.py).  The single line is for 2^9 points and fewer.
+static constexpr uint32_t NTT_SINGLE_LINE_MAX_LOG = 9;
 static uint32_t ntt_max_log_line(uint32_t log_n) {
-    if (g.tune[MIRA_TUNE_NTT_MAX_LOG_LINE] < 0) return ntt_use_wave(log_n) ? NTTW_LOG : NTT_MAX_LOG_LINE;
+    if (g.tune[MIRA_TUNE_NTT_MAX_LOG_LINE] < 0)
+        return ntt_use_wave(log_n) ? NTTW_LOG : (log_n > NTT_SINGLE_LINE_MAX_LOG && log_n <= NTT_MAX_LOG_LINE) ? NTT_SINGLE_LINE_MAX_LOG : NTT_MAX_LOG_LINE;
     const int v = (int)g.tune[MIRA_TUNE_NTT_MAX_LOG_LINE];
     return (uint32_t)std::min(std::max(v, 1), NTT_MAX_LOG_LINE);
 }

@@ -144,8 +144,18 @@ def test_emu_ntt(emu_lib, k):
         assert mont_to_ints(F.coset_ifft(a, lib=emu_lib), P.R_MOD) == [int(v, 16) for v in g["coset_ifft"]]
 
 
+def test_emu_ntt_single_line_of_4096_points(emu_lib, tune):
+    """2^10 .. 2^12 points take two passes since round 4 (one workgroup walking twelve layers was 2.3 x slower than 64 of them walking
+    six twice); MIRA_TUNE_NTT_MAX_LOG_LINE = 12 still reaches the single 4096-point line (128 KiB of LDS, twiddles of nine layers in LDS)."""
+    tune(_lib.TUNE_NTT_MAX_LOG_LINE, 12)
+    for k in (12, 11):
+        a = C.synth_scalars(0, 1 << k, seed=1100 + k)
+        assert (F.fft(a, k, lib=emu_lib) == C.fft(a, k)).all()
+        assert (F.ifft(a, k, lib=emu_lib) == C.ifft(a, k)).all()
+
+
 def test_emu_ntt_four_step(emu_lib):
-    k = 13   # first size that takes the two-pass (column / twiddle / row) route
+    k = 13   # two passes (column / twiddle / row); 2^10 .. 2^12 take the same route with shorter lines
     a = C.synth_scalars(0, 1 << k, seed=5)
     assert (F.fft(a, k, lib=emu_lib) == C.fft(a, k)).all()
     w = C.get_omega_or_inv(k, True)

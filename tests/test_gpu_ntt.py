@@ -82,6 +82,19 @@ def test_block_groups_from_counters(gpu_lib, k, grid):
         gpu_lib.tune(_lib.TUNE_NTT_GRID, -1)
 
 
+def test_single_line_kernel_up_to_4096_points(gpu_lib):
+    """2^10 .. 2^12 points take two passes by default; the single line (one workgroup, up to 128 KiB of LDS) stays reachable."""
+    from mira_amd import _lib
+    gpu_lib.tune(_lib.TUNE_NTT_MAX_LOG_LINE, 12)
+    try:
+        for k in (10, 11, 12):
+            a = C.synth_scalars(0, 1 << k, seed=1200 + k)
+            assert (F.fft(a, k) == C.fft(a, k)).all(), k
+            assert (F.ifft(a, k) == C.ifft(a, k)).all(), k
+    finally:
+        gpu_lib.tune(_lib.TUNE_NTT_MAX_LOG_LINE, -1)
+
+
 def test_three_pass_2p25_vs_oracle(gpu_lib):
     """log_n 25..28 take three passes of lines (n = n1 n2 n3): 2^25 bit-exact against the oracle,
     forward and inverse."""

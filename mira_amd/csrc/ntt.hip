@@ -173,7 +173,6 @@ static int ntt_device_locked(void *d_a, uint32_t log_n, const uint64_t omega[4],
     const HFr scale261 = hostf::mul(hostf::mul(s_final, hostf::from_u64<FrP>(32)), hostf::r2<FrP>());
     if ((rc = ntt_prepare_tables(log_n, omega, scale261, t))) return rc;
     if ((rc = g.ntt_consts.ensure(NTT_CONSTS_BYTES))) return rc;
-    RT_CHECK(rt_memset(reinterpret_cast<unsigned char *>(g.ntt_consts.p) + NTT_CTR_OFFSET, 0, 3 * NTT_CTR_PASS_BYTES, g.stream));
     tm_mark("twiddle_tables");
     const unsigned char *tab = reinterpret_cast<const unsigned char *>(g.ntt_set[g.ntt_set_cur].p);
     unsigned char *scale_d = nullptr;
@@ -190,7 +189,13 @@ static int ntt_device_locked(void *d_a, uint32_t log_n, const uint64_t omega[4],
             if (sh > 35 && w + 1 < 4) v |= s.l[w + 1] << (64 - sh);
             scale36[i] = (uint32_t)(v & 0x1FFFFFFFu);
         }
-        RT_CHECK(rt_h2d(reinterpret_cast<unsigned char *>(g.ntt_consts.p) + 64, scale36, 48, g.stream));
+        // (uploaded when it changes: a forward transform after a forward transform has the scale of one already)
+        static uint32_t uploaded36[12];
+        static const void *uploaded_to = nullptr;
+        if (uploaded_to != g.ntt_consts.p || memcmp(uploaded36, scale36, 48) != 0) {
+            RT_CHECK(rt_h2d(reinterpret_cast<unsigned char *>(g.ntt_consts.p) + 64, scale36, 48, g.stream));
+            memcpy(uploaded36, scale36, 48); uploaded_to = g.ntt_consts.p;
+        }
         scale_d = reinterpret_cast<unsigned char *>(g.ntt_consts.p) + 64;
     }
     unsigned char *a = reinterpret_cast<unsigned char *>(d_a);
@@ -212,8 +217,13 @@ static int ntt_device_locked(void *d_a, uint32_t log_n, const uint64_t omega[4],
             auto adjacent = [&](uint64_t hi, uint64_t lo) { return ps.split == 0 ? hi == 1 : (lo == 1 && tl <= ((uint64_t)1 << ps.split)); };
             if (NTTW_WAVES == 4 && ps.nlines % tl == 0 && ps.log_len >= 3)   // (the tile copy loops walk 8 columns per lane: lines of 8 points and more)
                 ps.coop = (adjacent(ps.in_hi, ps.in_lo) ? 1u : 0u) | (adjacent(ps.out_hi, ps.out_lo) ? 2u : 0u);
+            const uint32_t wgrid = std::min<uint32_t>(nbg, (uint32_t)std::max<size_t>(1, tuned(MIRA_TUNE_NTT_GRID, NTT_PERSISTENT_GRID * NTTW_OCC)));
+            // the pass's work counters, zero -- only where the kernel will draw from them (nttw_grab: four block-groups per workgroup and
+            // more): a small transform is 25 us of kernels, a memset in front of it a fifth of that
+            if (nbg >= NTTW_DYNAMIC_MIN * wgrid)
+                (void)rt_memset(reinterpret_cast<unsigned char *>(g.ntt_consts.p) + NTT_CTR_OFFSET + p * NTT_CTR_PASS_BYTES, 0, NTT_CTR_PASS_BYTES, g.stream);   // (a failure surfaces in rt_last below)
 #define NTTW_LAUNCH(COOP)                                                                                                                                  \
-    LAUNCH_BARRIER((k_ntt_wave<Fr29, COOP>), std::min<uint32_t>(nbg, (uint32_t)std::max<size_t>(1, tuned(MIRA_TUNE_NTT_GRID, NTT_PERSISTENT_GRID * NTTW_OCC))), 64 * NTTW_WAVES, NTTW_LDS_BYTES, g.stream, src, dst, ps,       \
+    LAUNCH_BARRIER((k_ntt_wave<Fr29, COOP>), wgrid, 64 * NTTW_WAVES, NTTW_LDS_BYTES, g.stream, src, dst, ps,                                                \
                    tab + t.off_tw[p], lo_ptr(tw), tw >= 0 ? tab + t.off_hi[tw] : cnull, tw >= 0 ? cnull : (const unsigned char *)scale_d,                 \
                    reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(g.ntt_consts.p) + NTT_CTR_OFFSET + p * NTT_CTR_PASS_BYTES))
             switch (ps.coop) {
@@ -232,7 +242,10 @@ static int ntt_device_locked(void *d_a, uint32_t log_n, const uint64_t omega[4],
     LAUNCH_BARRIER((k_ntt_lines<Fr29, COUNTERS>), grid, threads_for(ps.log_len), lds_for(ps.log_len), g.stream, src, dst, ps,                                \
                    tab + t.off_tw[p], lo_ptr(tw), tw >= 0 ? tab + t.off_hi[tw] : cnull, tw >= 0 ? cnull : (const unsigned char *)scale_d,                   \
                    reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(g.ntt_consts.p) + NTT_CTR_OFFSET + p * NTT_CTR_PASS_BYTES))
-        if (ps.nlines >= NTTW_DYNAMIC_MIN * grid) NTTL_LAUNCH(true); else NTTL_LAUNCH(false);
+        if (ps.nlines >= NTTW_DYNAMIC_MIN * grid) {
+            (void)rt_memset(reinterpret_cast<unsigned char *>(g.ntt_consts.p) + NTT_CTR_OFFSET + p * NTT_CTR_PASS_BYTES, 0, NTT_CTR_PASS_BYTES, g.stream);
+            NTTL_LAUNCH(true);
+        } else NTTL_LAUNCH(false);
 #undef NTTL_LAUNCH
         tm_mark(name);
     };

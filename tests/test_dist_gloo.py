@@ -8,6 +8,8 @@ import numpy as np
 import pytest
 import torch.multiprocessing as mp
 
+from conftest import free_port
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -46,7 +48,7 @@ def _worker(rank, world, port, n, cid, out_dir):
 def test_sharded_commit_world2(tmp_path, emu_lib, cid):
     from oracle import cref as C
     world, n = 2, 301
-    port = 29500 + (os.getpid() % 2000) + cid
+    port = free_port()
     mp.spawn(_worker, args=(world, port, n, cid, str(tmp_path)), nprocs=world, join=True)
     r0, r1 = np.load(tmp_path / "rank0.npy"), np.load(tmp_path / "rank1.npy")
     assert (r0 == r1).all()                                # every rank holds the same commitment
@@ -112,7 +114,7 @@ def test_sharded_commit_world8(tmp_path, emu_lib):
     """The strong-scaling path of bench.py --gpus 8 on eight CPU ranks (gloo + the emulation library)."""
     from oracle import cref as C
     world, n, cid = 8, 203, 0
-    port = 31500 + (os.getpid() % 2000)
+    port = free_port()
     mp.spawn(_worker8, args=(world, port, n, str(tmp_path)), nprocs=world, join=True)
     got = [np.load(tmp_path / f"rank{r}.npy") for r in range(world)]
     assert all((g == got[0]).all() for g in got)          # every rank holds the same commitments

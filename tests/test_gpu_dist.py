@@ -10,6 +10,7 @@ import sys
 import numpy as np
 import pytest
 
+from conftest import free_port
 from oracle import cref as C
 
 pytestmark = pytest.mark.gpu
@@ -26,7 +27,7 @@ def clean_env():
 @pytest.mark.parametrize("cid", [0, 1])
 def test_sharded_commit_over_rccl_world1(gpu_lib, cid):
     n = 1 << 16
-    port = str(29600 + (os.getpid() % 1000) + cid)
+    port = str(free_port())
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dist_child.py"), str(n), str(cid), port], capture_output=True, text=True, timeout=600, env=clean_env())
     assert p.returncode == 0, p.stderr[-3000:]
     out = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])

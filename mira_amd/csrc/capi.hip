@@ -281,8 +281,8 @@ static MsmPlan make_plan(size_t n, int32_t forced_c, uint32_t count = 1, uint64_
     p.B = 1u << (p.c - 1);
     p.count = count; p.stride = stride; p.Wt = p.W * count;
     p.NB = p.Wt * p.B;
-    // histogram / scatter tiling: about two workgroups per CU, at least 1024 points per tile
-    uint32_t want_tiles = std::max<uint32_t>(1, 512 / p.Wt);
+    // histogram / scatter tiling: about one workgroup per CU, at least 1024 points per tile (msm_host.cuh tiles each point chunk the same way)
+    uint32_t want_tiles = std::max<uint32_t>(1, MSM_HIST_WGS / p.Wt);
     p.tile = std::max<uint32_t>(1024, ceil_div(n, want_tiles));
     p.tile = (p.tile + 1023) / 1024 * 1024;
     p.ntiles = ceil_div(n, p.tile);

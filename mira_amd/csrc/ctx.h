@@ -180,6 +180,10 @@ void tm_end();
 static inline size_t tuned(int knob, size_t dflt) { return g.tune[knob] < 0 ? dflt : (size_t)g.tune[knob]; }
 static inline uint32_t ceil_div(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
+#ifndef MSM_HIST_WGS
+#define MSM_HIST_WGS 256      // workgroups of k_hist / k_scatter over one chunk: one per CU -- every workgroup zeroes and flushes a whole bucket set
+                              // (B global atomics), so fewer of them win until a CU is left idle (profiles/r04_x_hist_workgroups.txt; probe builds override it)
+#endif
 // window width c, W windows, B = 2^(c-1) buckets per window, histogram tiling; accumulate:
 // `lanes` resident lanes, minimum segment length L, at most T segments; reduction chunk m
 struct MsmPlan {

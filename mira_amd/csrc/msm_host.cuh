@@ -184,8 +184,8 @@ static int msm_launch_body(const Bases &bs, size_t first, const void *d_scalars,
                 RT_CHECK(rt_h2d(const_cast<unsigned char *>(sc), reinterpret_cast<const unsigned char *>(h_scalars) + lo * 32, ns * 32, cs));
             if (cs != st) RT_CHECK(rt_stream_wait(st, cs, g.copy_events[k]));
         }
-        // histogram / scatter tiling of this chunk: about two workgroups per CU, at least 1024 points per tile
-        const uint32_t tile = (std::max<uint32_t>(1024, ceil_div(nc, std::max<uint32_t>(1, 512 / p.Wt))) + 1023) / 1024 * 1024, ntiles = ceil_div(nc, tile);
+        // histogram / scatter tiling of this chunk: about one workgroup per CU, at least 1024 points per tile
+        const uint32_t tile = (std::max<uint32_t>(1024, ceil_div(nc, std::max<uint32_t>(1, MSM_HIST_WGS / p.Wt))) + 1023) / 1024 * 1024, ntiles = ceil_div(nc, tile);
         const bool staged = nc * p.count >= staged_min_n && p.c >= 9;   // a batch is count MSMs' worth of entries
         if (p.glv)
             LAUNCH((k_digits<FS, true>), dim3(ceil_div(ns, 256), p.count), 256, 0, st, sc, (uint32_t)ns, stride_k, p.c, p.W,

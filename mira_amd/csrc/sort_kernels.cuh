@@ -19,7 +19,13 @@ static constexpr uint32_t STAGE_TILE = 16384;      // entries per workgroup tile
 // The per-window path (<= 2^15 buckets per window) takes half-size tiles: 74 KiB of LDS instead of 148,
 // so TWO level-2 workgroups share a CU and one's loads overlap the other's ranking (level 1 + level 2
 // 0.49 -> 0.42 ms at 2^22 pairs, 0.14 -> 0.11 at 2^20).  Its tiles span ~64 buckets; 2048 keys are plenty.
-static constexpr uint32_t STAGE_TILE_PW = 8192, STAGE_MAX_KEYS2_PW = 2048;
+#ifndef MSM_STAGE_TILE_PW
+#define MSM_STAGE_TILE_PW 8192      // (probe builds override these two)
+#endif
+#ifndef MSM_STAGE_KEYS_PW
+#define MSM_STAGE_KEYS_PW 2048
+#endif
+static constexpr uint32_t STAGE_TILE_PW = MSM_STAGE_TILE_PW, STAGE_MAX_KEYS2_PW = MSM_STAGE_KEYS_PW;
 static constexpr uint32_t STAGE_MAX_BINS1 = 512;   // coarse bins per window handled in LDS
 static constexpr uint32_t STAGE_MAX_KEYS2 = 4096;  // bucket range one level-2 tile may span in LDS
 

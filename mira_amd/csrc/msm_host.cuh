@@ -2,6 +2,9 @@
 // the per-curve translation units.
 #pragma once
 #include "ctx.h"
+#ifndef MSM_DIGITS_BLOCK
+#define MSM_DIGITS_BLOCK 256   // lanes per workgroup of k_digits (probe builds override it)
+#endif
 #include "msm_kernels.cuh"
 #include "table_kernels.cuh"
 #include "sort_kernels.cuh"
@@ -188,10 +191,10 @@ static int msm_launch_body(const Bases &bs, size_t first, const void *d_scalars,
         const uint32_t tile = (std::max<uint32_t>(1024, ceil_div(nc, std::max<uint32_t>(1, MSM_HIST_WGS / p.Wt))) + 1023) / 1024 * 1024, ntiles = ceil_div(nc, tile);
         const bool staged = nc * p.count >= staged_min_n && p.c >= 9;   // a batch is count MSMs' worth of entries
         if (p.glv)
-            LAUNCH((k_digits<FS, true>), dim3(ceil_div(ns, 256), p.count), 256, 0, st, sc, (uint32_t)ns, stride_k, p.c, p.W,
+            LAUNCH((k_digits<FS, true>), dim3(ceil_div(ns, MSM_DIGITS_BLOCK), p.count), MSM_DIGITS_BLOCK, 0, st, sc, (uint32_t)ns, stride_k, p.c, p.W,
                    reinterpret_cast<int16_t *>(g.digits.p), reinterpret_cast<uint32_t *>(g.counts.p), p.NB + 1, hist, hist_clear);
         else
-        LAUNCH(k_digits<FS>, dim3(ceil_div(nc, 256), p.count), 256, 0, st, sc, (uint32_t)nc, stride_k, p.c, p.W,
+        LAUNCH(k_digits<FS>, dim3(ceil_div(nc, MSM_DIGITS_BLOCK), p.count), MSM_DIGITS_BLOCK, 0, st, sc, (uint32_t)nc, stride_k, p.c, p.W,
                reinterpret_cast<int16_t *>(g.digits.p), reinterpret_cast<uint32_t *>(g.counts.p), p.NB + 1, hist, hist_clear);
         tm_mark("digits");
         LAUNCH_BARRIER_FLEX(k_hist, dim3(ntiles, p.Wt), 1024, (size_t)p.B * 4, st, reinterpret_cast<const int16_t *>(g.digits.p), (uint32_t)nc,

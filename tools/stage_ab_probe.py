@@ -7,7 +7,7 @@ if os.environ.get("MIRA_PROBE_LIB"):
     _lib.LIB_PATH = os.path.abspath(os.environ["MIRA_PROBE_LIB"])
 lib = _lib.load()
 name = os.path.basename(os.environ.get("MIRA_PROBE_LIB", "tree"))
-for log_n, c in ((19, 0), (20, 16), (22, 16), (24, 16)):
+for log_n, c in ((17, 0), (20, 16), (22, 16)):
     n = 1 << log_n
     key = cm.CommitmentKey.synthetic(0, n); d = cm.synth_scalars_device(0, n)
     lib.check(lib.c.mira_msm_set_window_bits(c))
